@@ -1,0 +1,147 @@
+/* gpk.h -- C ABI of libgpk.so: the MI355X (gfx950) kernels behind the dense
+ * Gaussian-process inference hot path of wesselb/stheno.
+ *
+ * The reference is pure Python; its arithmetic for this path lives in the
+ * un-vendored packages `mlkernels` (kernel evaluation), `matrix` and `lab`
+ * (Cholesky / triangular solves / reductions, dispatched to LAPACK).  Each
+ * entry point below replaces the op named in its comment at the reference
+ * call site given as file:line (paths relative to the reference repository).
+ * INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *  - All matrices are ROW-MAJOR with a leading dimension `ld*` in ELEMENTS.
+ *  - `batch` independent problems are laid out with a stride `s*` in ELEMENTS
+ *    (stheno's batched computation: README.md:744-766, random.py:261,274).
+ *  - Every pointer named x/y/a/b/l/out/... is a DEVICE pointer owned by the
+ *    caller; term descriptors (`kinds`, `variances`, `inv_ls`) are HOST arrays.
+ *  - `dtype`: GPK_F32 or GPK_F64; all device buffers of a call share it.
+ *  - `stream` is a hipStream_t passed as void*.  Calls only ENQUEUE work: no
+ *    allocation, no free, no host synchronisation, no retained pointers, no
+ *    global state.  Thread-safe for distinct streams/buffers.
+ *  - Return value: 0 on success; -k if argument k (1-based) is invalid;
+ *    GPK_ERR_LAUNCH if a kernel launch failed.  No C++ exception crosses the ABI.
+ */
+#ifndef GPK_H
+#define GPK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPK_F32 0
+#define GPK_F64 1
+
+#define GPK_OK 0
+#define GPK_ERR_LAUNCH (-100)
+
+/* kernel term kinds; one term = variance * kappa(dist(x, y) * inv_ls) */
+#define GPK_K_EQ 0        /* exp(-r^2/2)                        mlkernels.EQ        */
+#define GPK_K_MATERN12 1  /* exp(-r)                            mlkernels.Exp       */
+#define GPK_K_MATERN32 2  /* (1+sqrt3 r) exp(-sqrt3 r)          mlkernels.Matern32  */
+#define GPK_K_MATERN52 3  /* (1+sqrt5 r+5r^2/3) exp(-sqrt5 r)   mlkernels.Matern52  */
+#define GPK_K_LINEAR 4    /* <x, y>                             mlkernels.Linear    */
+#define GPK_K_CONST 5     /* 1                                  mlkernels.OneKernel */
+#define GPK_MAX_TERMS 8
+
+#define GPK_DIAG_BLOCK 128 /* order of the diagonal blocks whose inverses gpk_potrf leaves in `dinv` */
+
+int gpk_version(void);
+
+/* Kernel matrix  out[i][j] (+)= sum_t variances[t] * kappa_kinds[t](x_i, y_j; inv_ls[t])
+ * and, if `symmetric` (x and y are the same points), + diag_add + diag_vec[i] on i == j.
+ * Replaces mlkernels `pairwise` + `B.add(K, noise)`:  stheno/model/fdd.py:79,
+ * stheno/model/observations.py:139 (K_x), :285-286 (K_zx, K_z).
+ *   x: n x d (ldx), y: m x d (ldy), out: n x m (ld).  lower_only: skip tiles above the diagonal.
+ *   diag_vec: nullable, n values per batch (stride s_diag).  accumulate: out += instead of out =. */
+int gpk_kmat(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms,
+             const void* x, int64_t n, int64_t ldx, int64_t sx, const void* y, int64_t m, int64_t ldy,
+             int64_t sy, int d, void* out, int64_t ld, int64_t so, int64_t batch, int lower_only,
+             int symmetric, double diag_add, const void* diag_vec, int64_t s_diag, int accumulate,
+             void* stream);
+
+/* Kernel diagonal  out[i] = k(x_i, x_i).  Replaces mlkernels `elwise`:
+ * stheno/model/fdd.py:66, stheno/model/observations.py:304. */
+int gpk_kdiag(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms,
+              const void* x, int64_t n, int64_t ldx, int64_t sx, int d, void* out, int64_t so,
+              int64_t batch, void* stream);
+
+/* Number of elements of the `dinv` workspace gpk_potrf needs per batch entry. */
+int64_t gpk_dinv_elems(int64_t n);
+
+/* In-place lower Cholesky  A = L L^T  (strict upper triangle of the diagonal
+ * blocks is zeroed, the rest of the upper triangle is left untouched: use
+ * gpk_tril for a clean factor).  `dinv` receives inv(L_cc) of every 128x128
+ * diagonal block ([batch][ceil(n/128)][128][128], identity-padded); `info`
+ * (int per batch entry, MUST be zeroed by the caller) receives the LAPACK-style
+ * order of the first non-positive pivot, 0 if none.  nbo: outer block (multiple
+ * of 128; <= 0 selects the default).
+ * Replaces `B.cholesky(B.reg(K))` (LAPACK potrf): implicit under B.logdet / B.iqf_diag at
+ * stheno/random.py:274-276, explicit at stheno/model/observations.py:300. */
+int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,
+              int* info, int nbo, void* stream);
+
+/* Merge the 128-block inverses into inverses of sb x sb diagonal blocks
+ * (sb in {128, 256, 512}); dinv_sb: [batch][ceil(n/sb)][sb][sb];
+ * tmp: >= ceil(n/sb) * sb * sb / 4 elements.  Part of the blocked TRSM below. */
+int gpk_trtri_merge(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
+                    const void* dinv128, int sb, void* dinv_sb, void* tmp, void* stream);
+
+/* B <- L^{-1} B, many right-hand sides (MFMA GEMM sweep).  tmp: batch * sb * nrhs elements.
+ * Replaces `B.solve(L, .)` / the solves inside `B.iqf` (LAPACK trsm):
+ * stheno/model/observations.py:301,322,327,329; mlkernels.PosteriorMean/PosteriorKernel
+ * constructed at observations.py:148-168. */
+int gpk_trsm_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
+                   int sb, void* b, int64_t nrhs, int64_t ldb, int64_t sb_stride, void* tmp,
+                   int64_t batch, void* stream);
+
+/* B <- L^{-1} B, nrhs <= 8 (GEMV sweep, HBM-bound).  tmp: batch * sb * nrhs elements.
+ * Replaces the solve inside `B.iqf_diag(var, y - mean)`: stheno/random.py:276,
+ * stheno/model/observations.py:335. */
+int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
+                   int sb, void* b, int nrhs, int64_t ldb, int64_t sb_stride, void* tmp, int64_t batch,
+                   void* stream);
+
+/* C = alpha * op(A) op(B)^T-style contraction + beta * C on MFMA:
+ *   C[m][n] = alpha * sum_k a(m,k) b(n,k) + beta * C[m][n]
+ * a_kmajor != 0: A stored M x K (k contiguous); else stored K x M.  Same for B (N x K / K x N).
+ * lower_only: only tiles on/below the diagonal (SYRK).  Replaces the dense products
+ * `B.mm` / `B.matmul` / `B.iqf` outer products: stheno/model/observations.py:322-323,
+ * mlkernels.PosteriorKernel (full covariance), `B.sample` (L xi): stheno/random.py:351. */
+int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
+             const void* a, int64_t lda, int64_t sa, const void* b, int64_t ldb, int64_t sb, double beta,
+             void* c, int64_t ldc, int64_t sc, int64_t batch, int lower_only, void* stream);
+
+/* out[b] = 2 * sum_i log L[i][i].  Replaces `B.logdet`: stheno/random.py:274,
+ * stheno/model/observations.py:334. */
+int gpk_logdet_chol(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
+                    void* out, void* stream);
+
+/* Number of row chunks (workspace sizing) used by gpk_colreduce for `rows` rows. */
+int64_t gpk_colreduce_chunks(int64_t rows);
+
+/* Fused column reductions of V (rows x cols):
+ *   out_dot[j] = sum_i V[i][j] w[i]   (skipped if out_dot or w is NULL)
+ *   out_ss[j]  = sum_i V[i][j]^2      (skipped if out_ss is NULL)
+ * ws: 2 * batch * gpk_colreduce_chunks(rows) * cols elements.  Deterministic (two-stage).
+ * Replaces `B.iqf_diag` / `B.matmul_diag(V, V, tr_a=True)` (random.py:276, observations.py:305)
+ * and the mean contraction of mlkernels.PosteriorMean. */
+int gpk_colreduce(int dtype, const void* v, int64_t rows, int64_t cols, int64_t ld, int64_t sv,
+                  const void* w, int64_t sw, void* out_dot, void* out_ss, void* ws, int64_t batch,
+                  void* stream);
+
+/* Zero the strict upper triangle (clean Cholesky factor for `B.cholesky` consumers). */
+int gpk_tril(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* stream);
+
+/* A[i][i] += s + (v ? v[i] : 0):  `B.add(var, Diagonal)` / `B.reg`: stheno/model/fdd.py:79. */
+int gpk_add_diag(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, double s, const void* v,
+                 int64_t sv, int64_t batch, void* stream);
+
+/* Strided 2-D copy (rows x cols). */
+int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, int64_t ldd, int64_t sd,
+               int64_t rows, int64_t cols, int64_t batch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_H */

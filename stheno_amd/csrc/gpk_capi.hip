@@ -1,0 +1,105 @@
+// gpk_capi.hip -- the extern "C" boundary declared in include/gpk.h: dtype
+// dispatch onto the templated launchers.  No torch types, no exceptions.
+#include "gpk_common.hpp"
+#include "../../include/gpk.h"
+
+#define DISPATCH(dtype, CALL_F32, CALL_F64)  \
+    do {                                     \
+        if ((dtype) == GPK_F32) {            \
+            typedef float T;                 \
+            return CALL_F32;                 \
+        } else if ((dtype) == GPK_F64) {     \
+            typedef double T;                \
+            return CALL_F64;                 \
+        }                                    \
+        return -1;                           \
+    } while (0)
+
+#define D1(dtype, EXPR) DISPATCH(dtype, EXPR, EXPR)
+
+extern "C" {
+
+int gpk_version(void) { return 100; }
+
+int64_t gpk_colreduce_chunks(int64_t rows) { return gpk_colreduce_nchunks_impl(rows); }
+
+int64_t gpk_dinv_elems(int64_t n) { return gpk_cdiv(n > 0 ? n : 1, GPK_DB) * GPK_DB * GPK_DB; }
+
+int gpk_kmat(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms,
+             const void* x, int64_t n, int64_t ldx, int64_t sx, const void* y, int64_t m, int64_t ldy,
+             int64_t sy, int d, void* out, int64_t ld, int64_t so, int64_t batch, int lower_only,
+             int symmetric, double diag_add, const void* diag_vec, int64_t s_diag, int accumulate,
+             void* stream) {
+    D1(dtype, gpk_kmat_launch<T>(kinds, variances, inv_ls, nterms, (const T*)x, n, ldx, sx, (const T*)y, m,
+                                 ldy, sy, d, (T*)out, ld, so, batch, lower_only, symmetric, diag_add,
+                                 (const T*)diag_vec, s_diag, accumulate, (hipStream_t)stream));
+}
+
+int gpk_kdiag(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms,
+              const void* x, int64_t n, int64_t ldx, int64_t sx, int d, void* out, int64_t so,
+              int64_t batch, void* stream) {
+    D1(dtype, gpk_kdiag_launch<T>(kinds, variances, inv_ls, nterms, (const T*)x, n, ldx, sx, d, (T*)out, so,
+                                  batch, (hipStream_t)stream));
+}
+
+int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,
+              int* info, int nbo, void* stream) {
+    D1(dtype, gpk_potrf_launch<T>((T*)a, n, ld, batch, sa, (T*)dinv, info, nbo, (hipStream_t)stream));
+}
+
+int gpk_trtri_merge(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
+                    const void* dinv128, int sb, void* dinv_sb, void* tmp, void* stream) {
+    D1(dtype, gpk_trtri_merge_launch<T>((const T*)l, n, ld, batch, sl, (const T*)dinv128, sb, (T*)dinv_sb,
+                                        (T*)tmp, (hipStream_t)stream));
+}
+
+int gpk_trsm_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
+                   int sb, void* b, int64_t nrhs, int64_t ldb, int64_t sb_stride, void* tmp,
+                   int64_t batch, void* stream) {
+    D1(dtype, gpk_trsm_launch<T>((const T*)l, n, ld, sl, (const T*)dinv_sb, sb, (T*)b, nrhs, ldb, sb_stride,
+                                 (T*)tmp, batch, (hipStream_t)stream));
+}
+
+int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
+                   int sb, void* b, int nrhs, int64_t ldb, int64_t sb_stride, void* tmp, int64_t batch,
+                   void* stream) {
+    D1(dtype, gpk_trsv_launch<T>((const T*)l, n, ld, sl, (const T*)dinv_sb, sb, (T*)b, nrhs, ldb, sb_stride,
+                                 (T*)tmp, batch, (hipStream_t)stream));
+}
+
+int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
+             const void* a, int64_t lda, int64_t sa, const void* b, int64_t ldb, int64_t sb, double beta,
+             void* c, int64_t ldc, int64_t sc, int64_t batch, int lower_only, void* stream) {
+    D1(dtype, gpk_gemm_launch<T>(a_kmajor != 0, b_kmajor != 0, m, n, k, (T)alpha, (const T*)a, lda, sa,
+                                 (const T*)b, ldb, sb, (T)beta, (T*)c, ldc, sc, batch, lower_only != 0,
+                                 (hipStream_t)stream));
+}
+
+int gpk_logdet_chol(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
+                    void* out, void* stream) {
+    D1(dtype, gpk_logdet_launch<T>((const T*)l, n, ld, sl, batch, (T*)out, (hipStream_t)stream));
+}
+
+int gpk_colreduce(int dtype, const void* v, int64_t rows, int64_t cols, int64_t ld, int64_t sv,
+                  const void* w, int64_t sw, void* out_dot, void* out_ss, void* ws, int64_t batch,
+                  void* stream) {
+    D1(dtype, gpk_colreduce_launch<T>((const T*)v, rows, cols, ld, sv, (const T*)w, sw, (T*)out_dot,
+                                      (T*)out_ss, (T*)ws, batch, (hipStream_t)stream));
+}
+
+int gpk_tril(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* stream) {
+    D1(dtype, gpk_tril_launch<T>((T*)a, n, ld, sa, batch, (hipStream_t)stream));
+}
+
+int gpk_add_diag(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, double s, const void* v,
+                 int64_t sv, int64_t batch, void* stream) {
+    D1(dtype, gpk_add_diag_launch<T>((T*)a, n, ld, sa, (T)s, (const T*)v, sv, batch, (hipStream_t)stream));
+}
+
+int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, int64_t ldd, int64_t sd,
+               int64_t rows, int64_t cols, int64_t batch, void* stream) {
+    D1(dtype, gpk_copy2d_launch<T>((const T*)src, lds, ss, (T*)dst, ldd, sd, rows, cols, batch,
+                                   (hipStream_t)stream));
+}
+
+}  // extern "C"

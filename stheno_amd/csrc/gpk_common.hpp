@@ -1,0 +1,135 @@
+// gpk_common.hpp -- shared device/host helpers for the gpk (GP kernels) library.
+//
+// Target: AMD Instinct MI355X (gfx950, CDNA4) only.  64-wide wavefronts, MFMA
+// 16x16x4 in f64/f32, 160 KiB LDS per CU, 8 XCDs x 32 CUs.
+//
+// Storage convention everywhere in this library: ROW-MAJOR matrices with an
+// explicit leading dimension in ELEMENTS, an optional batch dimension with a
+// batch stride in ELEMENTS, raw device pointers, a hipStream_t.  No function
+// allocates, frees, retains pointers or synchronises (see include/gpk.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GPK_WAVE 64
+#define GPK_TILE 128      // GEMM block tile (rows and cols)
+#define GPK_DB 128        // diagonal block factorised in LDS by one workgroup
+#define GPK_MAX_TERMS 8
+
+// status codes (mirrored in include/gpk.h)
+#define GPK_OK 0
+#define GPK_ERR_ARG(i) (-(i))
+#define GPK_ERR_LAUNCH (-100)
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct Traits;
+
+// f64: v_mfma_f64_16x16x4_f64.  A/B: one f64 per lane, lane l holds
+// A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15].  C/D: 4 f64 per
+// lane, reg i of lane l is C[row = (l >> 4) + 4 i][col = l & 15]  (NOT the f32
+// map -- see cdna_hip_programming.md section 3).
+template <>
+struct Traits<double> {
+    typedef f64x4 acc_t;
+    typedef f64x2 vec_t;                 // 16-byte global/LDS vector
+    static constexpr int VEC = 2;        // elements per 16 bytes
+    static constexpr int BK = 16;        // K-chunk staged per LDS stage = 128 bytes
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) + 4 * i; }
+};
+
+// f32: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain, f32 vector rate).  A/B as
+// above; C/D reg i of lane l is C[row = 4 (l >> 4) + i][col = l & 15].
+template <>
+struct Traits<float> {
+    typedef f32x4 acc_t;
+    typedef f32x4 vec_t;
+    static constexpr int VEC = 4;
+    static constexpr int BK = 32;        // 128 bytes
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) * 4 + i; }
+};
+
+static inline int64_t gpk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#define GPK_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return GPK_ERR_LAUNCH;        \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// Internal (C++) entry points shared between translation units.  All enqueue
+// on `stream` and return a status; none synchronise.
+// ---------------------------------------------------------------------------
+
+// op(A) is M x K, op(B) is N x K ("B transposed" convention):
+//   C[m][n] = alpha * sum_k a(m,k) b(n,k) + beta * C[m][n]
+// a_kmaj: A stored M x K row-major (k contiguous), else stored K x M (m contiguous).
+// b_kmaj: B stored N x K row-major (k contiguous), else stored K x N (n contiguous).
+// lower_only: compute only tiles with tile_col <= tile_row (SYRK-style; M == N).
+template <typename T>
+int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
+                    const T* A, int64_t lda, int64_t sA, const T* B, int64_t ldb, int64_t sB,
+                    T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, bool lower_only,
+                    hipStream_t stream);
+
+// Same with a second batch level (blockIdx.z) -- used to batch over regularly strided
+// sub-blocks of one matrix.
+template <typename T>
+int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
+                     const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
+                     int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
+                     int64_t batch, int64_t batch2, bool lower_only, hipStream_t stream);
+
+template <typename T>
+int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
+                     int* info, int nbo, hipStream_t stream);
+
+template <typename T>
+int gpk_copy2d_launch(const T* src, int64_t lds, int64_t ss, T* dst, int64_t ldd, int64_t sd,
+                      int64_t rows, int64_t cols, int64_t batch, hipStream_t stream);
+
+template <typename T>
+int gpk_set_identity_launch(T* dst, int64_t n, int64_t ld, int64_t sd, int64_t batch,
+                            hipStream_t stream);
+
+template <typename T>
+int gpk_trtri_merge_launch(const T* L, int64_t n, int64_t ld, int64_t batch, int64_t bstride,
+                           const T* dinv128, int sb, T* dinv_sb, T* tmp, hipStream_t stream);
+template <typename T>
+int gpk_trsm_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
+                    int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
+                    int nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_logdet_launch(const T* L, int64_t n, int64_t ld, int64_t sL, int64_t batch, T* out,
+                      hipStream_t stream);
+int64_t gpk_colreduce_nchunks_impl(int64_t rows);
+template <typename T>
+int gpk_colreduce_launch(const T* V, int64_t rows, int64_t cols, int64_t ld, int64_t sV, const T* w,
+                         int64_t sw, T* odot, T* oss, T* ws, int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_tril_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_add_diag_launch(T* A, int64_t n, int64_t ld, int64_t sA, T s, const T* v, int64_t sv,
+                        int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_kmat_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                    const T* X, int64_t n, int64_t ldx, int64_t sX, const T* Y, int64_t m, int64_t ldy,
+                    int64_t sY, int d, T* out, int64_t ld, int64_t sO, int64_t batch, int lower_only,
+                    int symmetric, double diag_add, const T* diag_vec, int64_t sDiag, int accumulate,
+                    hipStream_t stream);
+template <typename T>
+int gpk_kdiag_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                     const T* X, int64_t n, int64_t ldx, int64_t sX, int d, T* out, int64_t sO,
+                     int64_t batch, hipStream_t stream);

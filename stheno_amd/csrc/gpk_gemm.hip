@@ -1,0 +1,356 @@
+// gpk_gemm.hip -- the one dense contraction of the GP hot path, on MFMA.
+//
+//   C[m][n] = alpha * sum_k a(m,k) * b(n,k) + beta * C[m][n]
+//
+// Used for: the Cholesky trailing SYRK update, the panel TRSM (multiplication by
+// an inverted diagonal block), the strip update, the merge of diagonal-block
+// inverses, the blocked TRSM behind posterior conditioning, and the SYRK of
+// the inducing-point ELBO.  (Call sites in the reference that this replaces:
+// LAPACK dpotrf/dtrsm/dgemm underneath B.cholesky / B.iqf / B.solve,
+// stheno/random.py:274-276, stheno/model/observations.py:300-335.)
+//
+// Design (gfx950):
+//  * 128x128 block tile, 256 threads = 4 waves in a 2x2 grid, each wave owns a
+//    64x64 sub-tile = 4x4 MFMA 16x16x4 fragments (f64: 128 accumulator VGPRs).
+//    __launch_bounds__(256, 2): two workgroups per CU, so one workgroup's
+//    global->LDS staging overlaps the other's MFMA phase.
+//  * K is consumed in 128-byte chunks (16 f64 / 32 f32), register-staged
+//    (global_load_dwordx4 -> ds_write_b128) into a double-buffered LDS tile,
+//    one barrier per chunk; the next chunk's global loads are issued before the
+//    current chunk's MFMAs.
+//  * LDS image of a k-contiguous operand: [128 rows][128 B], 16-byte chunks
+//    XOR-swizzled with (row >> 1) & 7 so that the MFMA fragment reads
+//    (16 rows x 2 k per 32-lane group) are bank-conflict-free for f64 and the
+//    8-lane ds_write_b128 groups are conflict-free.  An operand stored with the
+//    row index contiguous is staged as [BK][128 + 16] (pad keeps the two
+//    k-rows of a 32-lane group on different bank halves).
+//  * blockIdx -> tile mapping is XCD-aware for big grids: workgroup b runs on
+//    XCD b % 8, and each XCD walks 8x8 super-tiles so that the 64 tiles in
+//    flight on one XCD share 16 operand panels in that XCD's 4 MiB L2.
+//  * accumulators are initialised with C * (beta / alpha) so the epilogue is a
+//    pure store of alpha * acc (exact for alpha = -1, beta = 1).
+#include "gpk_common.hpp"
+
+namespace {
+
+constexpr int OP_BYTES = 18432;               // one operand tile, either LDS image
+constexpr int STAGE_BYTES = 2 * OP_BYTES;     // A + B
+constexpr int RMAJ_PITCH = 144;               // elements per k-row of the row-contiguous image
+
+template <typename T>
+struct GemmArgs {
+    const T* A;
+    const T* B;
+    T* C;
+    int64_t lda, ldb, ldc, sA, sB, sC;
+    int64_t sA2, sB2, sC2;      // second (blockIdx.z) batch level
+    int M, N, K;
+    T alpha, beta_over_alpha;
+    int has_beta;
+    int tiles_m, tiles_n;
+    int lower_only;
+    int swizzle;
+    int n_super;
+    int SN;
+};
+
+__device__ __forceinline__ void tri_decode(int s, int& I, int& J) {
+    int i = (int)((sqrtf(8.f * (float)s + 1.f) - 1.f) * 0.5f);
+    while ((i + 1) * (i + 2) / 2 <= s) ++i;
+    while (i * (i + 1) / 2 > s) --i;
+    I = i;
+    J = s - i * (i + 1) / 2;
+}
+
+template <typename T>
+__device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& ti, int& tj) {
+    if (!p.swizzle) {
+        if (p.lower_only) {
+            tri_decode(bid, ti, tj);
+            return ti < p.tiles_m;
+        }
+        ti = bid / p.tiles_n;
+        tj = bid - ti * p.tiles_n;
+        return ti < p.tiles_m;
+    }
+    const int xcd = bid & 7, local = bid >> 3;
+    const int s = (local >> 6) * 8 + xcd, w = local & 63;
+    if (s >= p.n_super) return false;
+    int I, J;
+    if (p.lower_only) {
+        tri_decode(s, I, J);
+    } else {
+        I = s / p.SN;
+        J = s - I * p.SN;
+    }
+    ti = I * 8 + (w >> 3);
+    tj = J * 8 + (w & 7);
+    return ti < p.tiles_m && tj < p.tiles_n && (!p.lower_only || tj <= ti);
+}
+
+// ---- global -> registers ---------------------------------------------------
+template <typename T, bool KMAJ, bool EDGE>
+__device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[4], const T* __restrict__ base,
+                                      int64_t ld, int r0, int k0, int R, int K, int tid) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    if (KMAJ) {
+        const int c = tid & 7, rr0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + rr0 + 32 * i;
+            const int k = k0 + c * VEC;
+            const T* p = base + (int64_t)row * ld + k;
+            if (!EDGE) {
+                r[i] = *reinterpret_cast<const vec_t*>(p);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) r[i][v] = (row < R && k + v < K) ? p[v] : T(0);
+            }
+        }
+    } else {
+        constexpr int CPR = GPK_TILE / VEC;   // 16-byte chunks per k-row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i;
+            const int krow = id / CPR, cc = id % CPR;
+            const int k = k0 + krow;
+            const int row = r0 + cc * VEC;
+            const T* p = base + (int64_t)k * ld + row;
+            if (!EDGE) {
+                r[i] = *reinterpret_cast<const vec_t*>(p);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) r[i][v] = (k < K && row + v < R) ? p[v] : T(0);
+            }
+        }
+    }
+}
+
+// ---- registers -> LDS --------------------------------------------------------
+template <typename T, bool KMAJ>
+__device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_t (&r)[4], int tid) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    if (KMAJ) {
+        const int c = tid & 7, rr0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = rr0 + 32 * i;
+            const int off = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4);
+            *reinterpret_cast<vec_t*>(lds + off) = r[i];
+        }
+    } else {
+        constexpr int CPR = GPK_TILE / VEC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i;
+            const int krow = id / CPR, cc = id % CPR;
+            const int off = krow * (RMAJ_PITCH * (int)sizeof(T)) + cc * 16;
+            *reinterpret_cast<vec_t*>(lds + off) = r[i];
+        }
+    }
+}
+
+// ---- LDS -> MFMA operand -----------------------------------------------------
+// rowbase: first tile row of this 16-row fragment; lr = lane & 15; k = element index in chunk.
+template <typename T, bool KMAJ>
+__device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int k, int swz) {
+    constexpr int VEC = Traits<T>::VEC;
+    int off;
+    if (KMAJ) {
+        const int chunk = k / VEC, within = k % VEC;
+        off = (rowbase + lr) * 128 + ((chunk ^ swz) << 4) + within * (int)sizeof(T);
+    } else {
+        off = k * (RMAJ_PITCH * (int)sizeof(T)) + (rowbase + lr) * (int)sizeof(T);
+    }
+    return *reinterpret_cast<const T*>(lds + off);
+}
+
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs<T> p) {
+    typedef typename Traits<T>::acc_t acc_t;
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int BK = Traits<T>::BK;
+
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    int ti, tj;
+    if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int swz = (lr >> 1) & 7;
+
+    const int64_t b = blockIdx.y, b2 = blockIdx.z;
+    const T* __restrict__ A = p.A + b * p.sA + b2 * p.sA2;
+    const T* __restrict__ B = p.B + b * p.sB + b2 * p.sB2;
+    T* __restrict__ C = p.C + b * p.sC + b2 * p.sC2;
+
+    const int m0 = ti * GPK_TILE, n0 = tj * GPK_TILE;
+
+    acc_t acc[4][4];
+    if (p.has_beta) {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wm * 64 + fi * 16 + Traits<T>::crow(lane, i);
+                    const int col = n0 + wn * 64 + fj * 16 + lr;
+                    T v = T(0);
+                    if (!EDGE || (row < p.M && col < p.N)) v = C[(int64_t)row * p.ldc + col];
+                    acc[fi][fj][i] = v * p.beta_over_alpha;
+                }
+    } else {
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[fi][fj][i] = T(0);
+    }
+
+    const int nk = (p.K + BK - 1) / BK;
+    vec_t ra[4], rb[4];
+
+    gload<T, A_KMAJ, EDGE>(ra, A, p.lda, m0, 0, p.M, p.K, tid);
+    gload<T, B_KMAJ, EDGE>(rb, B, p.ldb, n0, 0, p.N, p.K, tid);
+    sstore<T, A_KMAJ>(smem, ra, tid);
+    sstore<T, B_KMAJ>(smem + OP_BYTES, rb, tid);
+    __syncthreads();
+
+    for (int kc = 0; kc < nk; ++kc) {
+        const char* sA = smem + (kc & 1) * STAGE_BYTES;
+        const char* sB = sA + OP_BYTES;
+        const bool more = (kc + 1 < nk);
+        if (more) {
+            gload<T, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid);
+            gload<T, B_KMAJ, EDGE>(rb, B, p.ldb, n0, (kc + 1) * BK, p.N, p.K, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            T a[4], bb[4];
+            const int k = kk * 4 + kq;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                a[f] = fragread<T, A_KMAJ>(sA, wm * 64 + f * 16, lr, k, swz);
+                bb[f] = fragread<T, B_KMAJ>(sB, wn * 64 + f * 16, lr, k, swz);
+            }
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < 4; ++fj)
+                    acc[fi][fj] = Traits<T>::mfma(a[fi], bb[fj], acc[fi][fj]);
+        }
+        if (more) {
+            char* dA = smem + ((kc + 1) & 1) * STAGE_BYTES;
+            sstore<T, A_KMAJ>(dA, ra, tid);
+            sstore<T, B_KMAJ>(dA + OP_BYTES, rb, tid);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int fj = 0; fj < 4; ++fj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + wm * 64 + fi * 16 + Traits<T>::crow(lane, i);
+                const int col = n0 + wn * 64 + fj * 16 + lr;
+                if (!EDGE || (row < p.M && col < p.N))
+                    C[(int64_t)row * p.ldc + col] = p.alpha * acc[fi][fj][i];
+            }
+}
+
+template <typename T, bool EDGE>
+void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, const GemmArgs<T>& args) {
+    if (a_kmaj && b_kmaj)
+        hipLaunchKernelGGL((gemm_kernel<T, true, true, EDGE>), grid, dim3(256), 0, stream, args);
+    else if (a_kmaj && !b_kmaj)
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, EDGE>), grid, dim3(256), 0, stream, args);
+    else if (!a_kmaj && b_kmaj)
+        hipLaunchKernelGGL((gemm_kernel<T, false, true, EDGE>), grid, dim3(256), 0, stream, args);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, EDGE>), grid, dim3(256), 0, stream, args);
+}
+
+}  // namespace
+
+template <typename T>
+int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
+                     const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
+                     int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
+                     int64_t batch, int64_t batch2, bool lower_only, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return GPK_OK;
+    if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || batch > 65535 || batch2 > 65535)
+        return GPK_ERR_ARG(3);
+    if (alpha == T(0)) return GPK_ERR_ARG(6);   // scale-only is not a use of this path
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int BK = Traits<T>::BK;
+
+    GemmArgs<T> g;
+    g.A = A; g.B = B; g.C = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA = sA; g.sB = sB; g.sC = sC;
+    g.sA2 = sA2; g.sB2 = sB2; g.sC2 = sC2;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K;
+    g.alpha = alpha;
+    g.has_beta = (beta != T(0)) ? 1 : 0;
+    g.beta_over_alpha = g.has_beta ? beta / alpha : T(0);
+    g.tiles_m = (int)gpk_cdiv(M, GPK_TILE);
+    g.tiles_n = (int)gpk_cdiv(N, GPK_TILE);
+    g.lower_only = lower_only ? 1 : 0;
+
+    const int64_t total = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
+                                     : (int64_t)g.tiles_m * g.tiles_n;
+    int64_t gridx;
+    g.swizzle = (total >= 1024) ? 1 : 0;
+    g.n_super = 0;
+    g.SN = 1;
+    if (g.swizzle) {
+        const int SM = (g.tiles_m + 7) / 8;
+        g.SN = (g.tiles_n + 7) / 8;
+        g.n_super = lower_only ? SM * (SM + 1) / 2 : SM * g.SN;
+        gridx = gpk_cdiv(g.n_super, 8) * 8 * 64;
+    } else {
+        gridx = total;
+    }
+
+    const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&
+                         (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
+                         (sA2 % VEC == 0) && (sB2 % VEC == 0);
+    const bool edge = !aligned || (M % GPK_TILE) || (N % GPK_TILE) || (K % BK);
+
+    dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
+    if (edge)
+        launch_layout<T, true>(a_kmaj, b_kmaj, grid, stream, g);
+    else
+        launch_layout<T, false>(a_kmaj, b_kmaj, grid, stream, g);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
+                    const T* A, int64_t lda, int64_t sA, const T* B, int64_t ldb, int64_t sB,
+                    T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, bool lower_only,
+                    hipStream_t stream) {
+    return gpk_gemm_launch2<T>(a_kmaj, b_kmaj, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C,
+                               ldc, sC, 0, batch, 1, lower_only, stream);
+}
+
+#define GPK_INST(T)                                                                                  \
+    template int gpk_gemm_launch2<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,    \
+                                     int64_t, int64_t, const T*, int64_t, int64_t, int64_t, T, T*,   \
+                                     int64_t, int64_t, int64_t, int64_t, int64_t, bool, hipStream_t); \
+    template int gpk_gemm_launch<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,     \
+                                    int64_t, const T*, int64_t, int64_t, T, T*, int64_t, int64_t,    \
+                                    int64_t, bool, hipStream_t);
+GPK_INST(double)
+GPK_INST(float)

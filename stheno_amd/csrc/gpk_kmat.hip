@@ -1,0 +1,277 @@
+// gpk_kmat.hip -- fused pairwise-distance + kernel evaluation.
+//
+//   out[i][j] (+)= sum_t variance_t * kappa_t( x_i, y_j ; inv_ls_t )  [+ diag_add + diag_vec[i] if i == j]
+//
+// Replaces: mlkernels `pairwise` for EQ / Matern12 (Exp) / Matern32 / Matern52 /
+// Linear and Sum / Scaled / Stretched combinations of them, plus the
+// `B.add(k(x), noise)` of stheno/model/fdd.py:79 and observations.py:139,286
+// (the noise / jitter diagonal is fused into the same pass), and `elwise`
+// (fdd.py:66, observations.py:304) as gpk_kdiag.  Formula evidence for EQ:
+// exp(-0.5 * pw_dists2), tests/model/test_model.py:342-345.
+//
+// HBM-write-bound.  One workgroup (4 waves) produces a 32 x (64*VEC) tile:
+// every wave-store is one full, contiguous 1 KiB row segment (16 B per lane);
+// the X rows of the tile sit in LDS and are read as wave-uniform broadcasts, the
+// Y rows of a lane live in registers.  Squared distances are accumulated as
+// direct differences (no |a|^2 + |b|^2 - 2ab cancellation).
+#include "gpk_common.hpp"
+
+enum { GPK_K_EQ = 0, GPK_K_MATERN12 = 1, GPK_K_MATERN32 = 2, GPK_K_MATERN52 = 3, GPK_K_LINEAR = 4, GPK_K_CONST = 5 };
+
+namespace {
+
+constexpr int TM = 32;   // tile rows
+constexpr int RW = 8;    // rows per wave
+constexpr int DC = 8;    // input dimensions per staged chunk
+
+template <typename T>
+struct KTermT {
+    int kind;
+    T variance;
+    T ils2;   // squared inverse length scale
+};
+
+template <typename T>
+struct KmatArgs {
+    const T* X;
+    const T* Y;
+    T* out;
+    const T* diag_vec;
+    int64_t ldx, ldy, sX, sY, ld, sO, sDiag;
+    int n, m, d;
+    int nterms;
+    KTermT<T> terms[GPK_MAX_TERMS];
+    T diag_add;
+    int symmetric, lower_only, accumulate, need_dot, vec_ok;
+};
+
+template <typename T>
+__device__ __forceinline__ T gpk_exp(T x);
+template <>
+__device__ __forceinline__ double gpk_exp<double>(double x) { return exp(x); }
+template <>
+__device__ __forceinline__ float gpk_exp<float>(float x) { return expf(x); }
+template <typename T>
+__device__ __forceinline__ T gpk_sqrtk(T x);
+template <>
+__device__ __forceinline__ double gpk_sqrtk<double>(double x) { return sqrt(x); }
+template <>
+__device__ __forceinline__ float gpk_sqrtk<float>(float x) { return sqrtf(x); }
+
+template <typename T>
+__device__ __forceinline__ T eval_terms(const KmatArgs<T>& p, T r2, T dot) {
+    T val = T(0);
+    for (int t = 0; t < p.nterms; ++t) {
+        const int kind = p.terms[t].kind;
+        const T q = r2 * p.terms[t].ils2;
+        T k;
+        if (kind == GPK_K_EQ) {
+            k = gpk_exp<T>(T(-0.5) * q);
+        } else if (kind == GPK_K_MATERN12) {
+            k = gpk_exp<T>(-gpk_sqrtk<T>(q));
+        } else if (kind == GPK_K_MATERN32) {
+            const T s = gpk_sqrtk<T>(T(3) * q);
+            k = (T(1) + s) * gpk_exp<T>(-s);
+        } else if (kind == GPK_K_MATERN52) {
+            const T s = gpk_sqrtk<T>(T(5) * q);
+            k = (T(1) + s + s * s * T(1.0 / 3.0)) * gpk_exp<T>(-s);
+        } else if (kind == GPK_K_LINEAR) {
+            k = dot * p.terms[t].ils2;
+        } else {
+            k = T(1);
+        }
+        val += p.terms[t].variance * k;
+    }
+    return val;
+}
+
+template <typename T, bool DOT>
+__global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> p) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int TN = 64 * VEC;
+    __shared__ T xs[TM * DC];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.y * TM;
+    const int col0 = blockIdx.x * TN;
+    if (p.lower_only && col0 > row0 + TM - 1) return;
+
+    const int64_t b = blockIdx.z;
+    const T* __restrict__ X = p.X + b * p.sX;
+    const T* __restrict__ Y = p.Y + b * p.sY;
+    T* __restrict__ out = p.out + b * p.sO;
+
+    const int colb = col0 + lane * VEC;   // first of this lane's VEC columns
+
+    T r2[RW][VEC];
+    T dt[RW][VEC];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            r2[r][v] = T(0);
+            dt[r][v] = T(0);
+        }
+
+    for (int dc = 0; dc < p.d; dc += DC) {
+        __syncthreads();
+        {   // stage X chunk: TM*DC = 256 elements, one per thread
+            const int r = tid / DC, j = tid % DC;
+            const int row = row0 + r;
+            xs[tid] = (row < p.n && dc + j < p.d) ? X[(int64_t)row * p.ldx + dc + j] : T(0);
+        }
+        T yv[VEC][DC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const int col = colb + v;
+                yv[v][j] = (col < p.m && dc + j < p.d) ? Y[(int64_t)col * p.ldy + dc + j] : T(0);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int rl = wave * RW + r;
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const T xv = xs[rl * DC + j];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const T df = xv - yv[v][j];
+                    r2[r][v] += df * df;
+                    if (DOT) dt[r][v] += xv * yv[v][j];
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = row0 + wave * RW + r;
+        if (row >= p.n) continue;
+        T vals[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int col = colb + v;
+            T val = eval_terms<T>(p, r2[r][v], dt[r][v]);
+            if (p.symmetric && col == row) {
+                val += p.diag_add;
+                if (p.diag_vec != nullptr) val += p.diag_vec[b * p.sDiag + row];
+            }
+            vals[v] = val;
+        }
+        T* o = out + (int64_t)row * p.ld + colb;
+        if (p.vec_ok && colb + VEC <= p.m) {
+            vec_t w;
+            if (p.accumulate) {
+                w = *reinterpret_cast<const vec_t*>(o);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) w[v] += vals[v];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) w[v] = vals[v];
+            }
+            *reinterpret_cast<vec_t*>(o) = w;
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (colb + v < p.m) o[v] = p.accumulate ? o[v] + vals[v] : vals[v];
+        }
+    }
+}
+
+template <typename T>
+struct KdiagArgs {
+    const T* X;
+    T* out;
+    int64_t ldx, sX, sO;
+    int n, d, nterms;
+    KTermT<T> terms[GPK_MAX_TERMS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void kdiag_kernel(KdiagArgs<T> p) {
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const T* x = p.X + b * p.sX + i * p.ldx;
+    T nrm = T(0);
+    for (int j = 0; j < p.d; ++j) nrm += x[j] * x[j];
+    T val = T(0);
+    for (int t = 0; t < p.nterms; ++t)
+        val += p.terms[t].variance * (p.terms[t].kind == GPK_K_LINEAR ? nrm * p.terms[t].ils2 : T(1));
+    p.out[b * p.sO + i] = val;
+}
+
+}  // namespace
+
+// terms: host arrays of length nterms
+template <typename T>
+int gpk_kmat_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                    const T* X, int64_t n, int64_t ldx, int64_t sX, const T* Y, int64_t m, int64_t ldy,
+                    int64_t sY, int d, T* out, int64_t ld, int64_t sO, int64_t batch, int lower_only,
+                    int symmetric, double diag_add, const T* diag_vec, int64_t sDiag, int accumulate,
+                    hipStream_t stream) {
+    if (n <= 0 || m <= 0 || batch <= 0) return GPK_OK;
+    if (nterms < 0 || nterms > GPK_MAX_TERMS) return GPK_ERR_ARG(4);
+    if (n > INT32_MAX || m > INT32_MAX || batch > 65535) return GPK_ERR_ARG(6);
+    if (d < 0) return GPK_ERR_ARG(13);
+    constexpr int VEC = Traits<T>::VEC;
+    KmatArgs<T> a;
+    a.X = X; a.Y = Y; a.out = out; a.diag_vec = diag_vec;
+    a.ldx = ldx; a.ldy = ldy; a.sX = sX; a.sY = sY; a.ld = ld; a.sO = sO; a.sDiag = sDiag;
+    a.n = (int)n; a.m = (int)m; a.d = d;
+    a.nterms = nterms;
+    a.need_dot = 0;
+    for (int t = 0; t < nterms; ++t) {
+        if (kinds[t] < GPK_K_EQ || kinds[t] > GPK_K_CONST) return GPK_ERR_ARG(1);
+        a.terms[t].kind = kinds[t];
+        a.terms[t].variance = (T)variances[t];
+        a.terms[t].ils2 = (T)(inv_ls[t] * inv_ls[t]);
+        if (kinds[t] == GPK_K_LINEAR) a.need_dot = 1;
+    }
+    a.diag_add = (T)diag_add;
+    a.symmetric = symmetric; a.lower_only = lower_only; a.accumulate = accumulate;
+    a.vec_ok = ((uintptr_t)out % 16 == 0) && (ld % VEC == 0) && (sO % VEC == 0);
+    const int64_t gy = gpk_cdiv(n, TM);
+    if (gy > 65535) return GPK_ERR_ARG(6);
+    dim3 grid((unsigned)gpk_cdiv(m, 64 * VEC), (unsigned)gy, (unsigned)batch);
+    if (a.need_dot)
+        hipLaunchKernelGGL((kmat_kernel<T, true>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((kmat_kernel<T, false>), grid, dim3(256), 0, stream, a);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_kdiag_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                     const T* X, int64_t n, int64_t ldx, int64_t sX, int d, T* out, int64_t sO,
+                     int64_t batch, hipStream_t stream) {
+    if (n <= 0 || batch <= 0) return GPK_OK;
+    if (nterms < 0 || nterms > GPK_MAX_TERMS) return GPK_ERR_ARG(4);
+    KdiagArgs<T> a;
+    a.X = X; a.out = out; a.ldx = ldx; a.sX = sX; a.sO = sO;
+    a.n = (int)n; a.d = d; a.nterms = nterms;
+    for (int t = 0; t < nterms; ++t) {
+        a.terms[t].kind = kinds[t];
+        a.terms[t].variance = (T)variances[t];
+        a.terms[t].ils2 = (T)(inv_ls[t] * inv_ls[t]);
+    }
+    dim3 grid((unsigned)gpk_cdiv(n, 256), (unsigned)batch);
+    hipLaunchKernelGGL((kdiag_kernel<T>), grid, dim3(256), 0, stream, a);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+#define GPK_INST(T)                                                                                   \
+    template int gpk_kmat_launch<T>(const int*, const double*, const double*, int, const T*, int64_t, \
+                                    int64_t, int64_t, const T*, int64_t, int64_t, int64_t, int, T*,   \
+                                    int64_t, int64_t, int64_t, int, int, double, const T*, int64_t,   \
+                                    int, hipStream_t);                                                \
+    template int gpk_kdiag_launch<T>(const int*, const double*, const double*, int, const T*, int64_t, \
+                                     int64_t, int64_t, int, T*, int64_t, int64_t, hipStream_t);
+GPK_INST(double)
+GPK_INST(float)

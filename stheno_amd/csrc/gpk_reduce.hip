@@ -1,0 +1,244 @@
+// gpk_reduce.hip -- the HBM-bound odds and ends of the GP path: log-determinant
+// from the Cholesky diagonal, fused column reductions over V = L^{-1} K(x, x*),
+// triangle clean-up, diagonal updates, strided copies.
+//
+// Replaces (reference call sites): `B.logdet` stheno/random.py:274,
+// observations.py:334; `B.iqf_diag` / `B.matmul_diag` column sums-of-squares
+// random.py:276, observations.py:305; the `(L^{-1}K)^T (L^{-1}y)` contraction
+// inside mlkernels.PosteriorMean (observations.py:161-168).
+#include "gpk_common.hpp"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T gpk_log(T x);
+template <>
+__device__ __forceinline__ double gpk_log<double>(double x) { return log(x); }
+template <>
+__device__ __forceinline__ float gpk_log<float>(float x) { return logf(x); }
+
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    T s = T(0);
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+
+// out[b] = 2 * sum_i log L[i][i]
+template <typename T>
+__global__ __launch_bounds__(256) void logdet_kernel(const T* __restrict__ L, int64_t n, int64_t ld,
+                                                     int64_t sL, T* __restrict__ out) {
+    __shared__ T red[4];
+    const int64_t b = blockIdx.x;
+    const T* Lb = L + b * sL;
+    T acc = T(0);
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc += gpk_log<T>(Lb[i * (ld + 1)]);
+    const T s = block_sum<T>(acc, red);
+    if (threadIdx.x == 0) out[b] = T(2) * s;
+}
+
+// Column reductions of V (rows x cols): partial sums over row chunks.
+//   pdot[chunk][col] = sum_{r in chunk} V[r][col] * w[r]   (if w)
+//   pss [chunk][col] = sum_{r in chunk} V[r][col]^2
+template <typename T>
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const T* __restrict__ V, int64_t rows,
+                                                                int64_t cols, int64_t ld, int64_t sV,
+                                                                const T* __restrict__ w, int64_t sw,
+                                                                T* __restrict__ pdot, T* __restrict__ pss,
+                                                                int rch, int nchunk) {
+    const int64_t b = blockIdx.z;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    if (col >= cols) return;
+    const T* Vb = V + b * sV;
+    const int64_t r0 = (int64_t)chunk * rch;
+    const int64_t r1 = (r0 + rch < rows) ? r0 + rch : rows;
+    T d = T(0), s = T(0);
+    if (w != nullptr) {
+        const T* wb = w + b * sw;
+        for (int64_t r = r0; r < r1; ++r) {
+            const T v = Vb[r * ld + col];
+            d += v * wb[r];
+            s += v * v;
+        }
+        pdot[(b * nchunk + chunk) * cols + col] = d;
+    } else {
+        for (int64_t r = r0; r < r1; ++r) {
+            const T v = Vb[r * ld + col];
+            s += v * v;
+        }
+    }
+    if (pss != nullptr) pss[(b * nchunk + chunk) * cols + col] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const T* __restrict__ pdot,
+                                                              const T* __restrict__ pss, int64_t cols,
+                                                              int nchunk, T* __restrict__ odot,
+                                                              T* __restrict__ oss) {
+    const int64_t b = blockIdx.y;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    if (odot != nullptr) {
+        T d = T(0);
+        for (int c = 0; c < nchunk; ++c) d += pdot[(b * nchunk + c) * cols + col];
+        odot[b * cols + col] = d;
+    }
+    if (oss != nullptr) {
+        T s = T(0);
+        for (int c = 0; c < nchunk; ++c) s += pss[(b * nchunk + c) * cols + col];
+        oss[b * cols + col] = s;
+    }
+}
+
+// zero the strict upper triangle
+template <typename T>
+__global__ __launch_bounds__(256) void tril_kernel(T* __restrict__ A, int64_t n, int64_t ld, int64_t sA) {
+    const int64_t b = blockIdx.z;
+    const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * 256;
+    if (c0 + 255 <= r0) return;   // tile entirely on/below the diagonal
+    const int64_t c = c0 + threadIdx.x;
+    if (c >= n) return;
+    T* Ab = A + b * sA;
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = r0 + i;
+        if (r < n && c > r) Ab[r * ld + c] = T(0);
+    }
+}
+
+// A[i][i] += s + (v ? v[i] : 0)
+template <typename T>
+__global__ void add_diag_kernel(T* __restrict__ A, int64_t n, int64_t ld, int64_t sA, T s,
+                                const T* __restrict__ v, int64_t sv) {
+    const int64_t b = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T add = s;
+    if (v != nullptr) add += v[b * sv + i];
+    A[b * sA + i * (ld + 1)] += add;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy2d_kernel(const T* __restrict__ src, int64_t lds, int64_t ss,
+                                                     T* __restrict__ dst, int64_t ldd, int64_t sd,
+                                                     int64_t rows, int64_t cols) {
+    const int64_t b = blockIdx.z;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 8;
+    for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + i;
+        if (r < rows) dst[b * sd + r * ldd + c] = src[b * ss + r * lds + c];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void set_identity_kernel(T* __restrict__ dst, int64_t n, int64_t ld,
+                                                           int64_t sd) {
+    const int64_t b = blockIdx.z;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 8;
+    for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + i;
+        if (r < n) dst[b * sd + r * ld + c] = (r == c) ? T(1) : T(0);
+    }
+}
+
+}  // namespace
+
+template <typename T>
+int gpk_logdet_launch(const T* L, int64_t n, int64_t ld, int64_t sL, int64_t batch, T* out,
+                      hipStream_t stream) {
+    if (batch <= 0) return GPK_OK;
+    hipLaunchKernelGGL((logdet_kernel<T>), dim3((unsigned)batch), dim3(256), 0, stream, L, n, ld, sL, out);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+int64_t gpk_colreduce_nchunks_impl(int64_t rows) {
+    // 128-row chunks, but never more than 1024 chunks
+    int64_t rch = 128;
+    while (gpk_cdiv(rows, rch) > 1024) rch *= 2;
+    return gpk_cdiv(rows > 0 ? rows : 1, rch);
+}
+
+// ws: 2 * batch * nchunk * cols elements
+template <typename T>
+int gpk_colreduce_launch(const T* V, int64_t rows, int64_t cols, int64_t ld, int64_t sV, const T* w,
+                         int64_t sw, T* odot, T* oss, T* ws, int64_t batch, hipStream_t stream) {
+    if (cols <= 0 || batch <= 0) return GPK_OK;
+    if (batch > 65535) return GPK_ERR_ARG(11);
+    const int nchunk = (int)gpk_colreduce_nchunks_impl(rows);
+    const int rch = (int)gpk_cdiv(rows > 0 ? rows : 1, nchunk);
+    T* pdot = ws;
+    T* pss = ws + batch * nchunk * cols;
+    dim3 g1((unsigned)gpk_cdiv(cols, 256), (unsigned)nchunk, (unsigned)batch);
+    hipLaunchKernelGGL((colreduce_partial_kernel<T>), g1, dim3(256), 0, stream, V, rows, cols, ld, sV,
+                       (odot != nullptr) ? w : (const T*)nullptr, sw, pdot, (oss != nullptr) ? pss : (T*)nullptr,
+                       rch, nchunk);
+    GPK_CHECK_LAUNCH();
+    dim3 g2((unsigned)gpk_cdiv(cols, 256), (unsigned)batch);
+    hipLaunchKernelGGL((colreduce_final_kernel<T>), g2, dim3(256), 0, stream, pdot, pss, cols, nchunk,
+                       odot, oss);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_tril_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream) {
+    if (n <= 0 || batch <= 0) return GPK_OK;
+    dim3 g((unsigned)gpk_cdiv(n, 256), (unsigned)gpk_cdiv(n, 16), (unsigned)batch);
+    hipLaunchKernelGGL((tril_kernel<T>), g, dim3(256), 0, stream, A, n, ld, sA);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_add_diag_launch(T* A, int64_t n, int64_t ld, int64_t sA, T s, const T* v, int64_t sv,
+                        int64_t batch, hipStream_t stream) {
+    if (n <= 0 || batch <= 0) return GPK_OK;
+    dim3 g((unsigned)gpk_cdiv(n, 256), (unsigned)batch);
+    hipLaunchKernelGGL((add_diag_kernel<T>), g, dim3(256), 0, stream, A, n, ld, sA, s, v, sv);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_copy2d_launch(const T* src, int64_t lds, int64_t ss, T* dst, int64_t ldd, int64_t sd,
+                      int64_t rows, int64_t cols, int64_t batch, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || batch <= 0) return GPK_OK;
+    dim3 g((unsigned)gpk_cdiv(cols, 256), (unsigned)gpk_cdiv(rows, 8), (unsigned)batch);
+    hipLaunchKernelGGL((copy2d_kernel<T>), g, dim3(256), 0, stream, src, lds, ss, dst, ldd, sd, rows, cols);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_set_identity_launch(T* dst, int64_t n, int64_t ld, int64_t sd, int64_t batch,
+                            hipStream_t stream) {
+    if (n <= 0 || batch <= 0) return GPK_OK;
+    dim3 g((unsigned)gpk_cdiv(n, 256), (unsigned)gpk_cdiv(n, 8), (unsigned)batch);
+    hipLaunchKernelGGL((set_identity_kernel<T>), g, dim3(256), 0, stream, dst, n, ld, sd);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+#define GPK_INST(T)                                                                                  \
+    template int gpk_logdet_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, T*, hipStream_t); \
+    template int gpk_colreduce_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,     \
+                                         int64_t, T*, T*, T*, int64_t, hipStream_t);                 \
+    template int gpk_tril_launch<T>(T*, int64_t, int64_t, int64_t, int64_t, hipStream_t);            \
+    template int gpk_add_diag_launch<T>(T*, int64_t, int64_t, int64_t, T, const T*, int64_t, int64_t, \
+                                        hipStream_t);                                                \
+    template int gpk_copy2d_launch<T>(const T*, int64_t, int64_t, T*, int64_t, int64_t, int64_t,     \
+                                      int64_t, int64_t, hipStream_t);                                \
+    template int gpk_set_identity_launch<T>(T*, int64_t, int64_t, int64_t, int64_t, hipStream_t);
+GPK_INST(double)
+GPK_INST(float)

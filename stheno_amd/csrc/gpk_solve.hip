@@ -1,0 +1,312 @@
+// gpk_solve.hip -- lower-triangular solves of the GP path, with no substitution
+// on the critical path: gpk_potrf leaves inv(L_cc) for every 128x128 diagonal
+// block, so   X = L^{-1} B   becomes a right-looking sweep of GEMMs (many
+// right-hand sides: posterior conditioning, inducing-point V = L_z^{-1} K_zx)
+// or GEMVs (few right-hand sides: the logpdf quadratic form).
+//
+// Replaces: `B.iqf_diag` / `B.iqf` / `B.solve` of the reference's dependency
+// stack, i.e. LAPACK dtrsm/dtrsv under stheno/random.py:276 and
+// stheno/model/observations.py:301,322,327,329,335 and inside
+// mlkernels.PosteriorMean / PosteriorKernel (constructed observations.py:148-168).
+//
+// For many right-hand sides the 128-blocks are first merged into inverses of
+// SB x SB diagonal blocks (SB = 256/512, recursive doubling, all GEMMs, batched
+// over the blocks): [A 0; C D]^-1 = [Ai 0; -Di C Ai, Di].  Then per block row q:
+//     T   = inv(L_qq) * B_q                 (GEMM, K = SB)
+//     B_q = T;  B_below -= L[below, q] * T  (GEMM, K = SB)
+// so every update is an MFMA GEMM with K = SB, not a rank-128 one.
+#include "gpk_common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// place the 128-blocks on the diagonal of the SB-blocks, identity-pad, zero rest
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void place_blocks_kernel(const T* __restrict__ d128, int64_t s128, int nblk128,
+                                    T* __restrict__ dsb, int64_t ssb, int sb, int nsb) {
+    const int64_t b = blockIdx.z;
+    const int q = blockIdx.y;
+    const int64_t per = (int64_t)sb * sb;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / sb), c = (int)(idx % sb);
+        const int br = r / GPK_DB, bc = c / GPK_DB;
+        T v = T(0);
+        if (br == bc) {
+            const int g = q * (sb / GPK_DB) + br;
+            if (g < nblk128)
+                v = d128[b * s128 + (int64_t)g * GPK_DB * GPK_DB + (r % GPK_DB) * GPK_DB + (c % GPK_DB)];
+            else
+                v = (r == c) ? T(1) : T(0);
+        }
+        dsb[b * ssb + q * per + idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GEMV with a few right-hand sides:
+//   y[i][c] = beta * y[i][c] + alpha * sum_k A[i][k] x[k][c],   i in [0, M)
+// plus an optional prefix copy  ycopy[i][c] = x[i][c], i in [0, ncopy)  (writes a
+// solved block back while the rows below are updated).
+// One wave per row, lanes stride over K with 16-byte loads, x staged in LDS.
+// ---------------------------------------------------------------------------
+template <typename T>
+struct GemvArgs {
+    const T* A;
+    int64_t lda, sA;
+    const T* x;
+    int64_t ldx, sx;
+    T* y;
+    int64_t ldy, sy;
+    T* ycopy;          // nullable
+    int64_t ncopy;
+    int M, K, nrhs;
+    T alpha, beta;
+    int vec_ok;
+};
+
+constexpr int GEMV_ROWS = 16;    // rows per workgroup
+constexpr int GEMV_MAXK = 512;
+
+template <typename T, int NR>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs<T> p) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    __shared__ T xs[GEMV_MAXK * NR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.y;
+    const T* __restrict__ A = p.A + b * p.sA;
+    const T* __restrict__ x = p.x + b * p.sx;
+    T* __restrict__ y = p.y + b * p.sy;
+
+    for (int idx = tid; idx < p.K * NR; idx += 256) {
+        const int k = idx / NR, c = idx % NR;
+        xs[idx] = (c < p.nrhs) ? x[(int64_t)k * p.ldx + c] : T(0);
+    }
+    __syncthreads();
+
+    // prefix copy (only the first workgroups have such rows)
+    if (p.ycopy != nullptr) {
+        T* __restrict__ yc = p.ycopy + b * p.sy;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + tid; idx < p.ncopy * p.nrhs;
+             idx += (int64_t)gridDim.x * 256) {
+            const int64_t i = idx / p.nrhs;
+            const int c = (int)(idx % p.nrhs);
+            yc[i * p.ldy + c] = xs[i * NR + c];
+        }
+    }
+
+    const int row0 = blockIdx.x * GEMV_ROWS;
+    for (int rr = wave; rr < GEMV_ROWS; rr += 4) {
+        const int row = row0 + rr;
+        if (row >= p.M) break;
+        const T* __restrict__ a = A + (int64_t)row * p.lda;
+        T acc[NR];
+#pragma unroll
+        for (int c = 0; c < NR; ++c) acc[c] = T(0);
+        if (p.vec_ok) {
+            for (int k = lane * VEC; k < p.K; k += 64 * VEC) {
+                const vec_t av = *reinterpret_cast<const vec_t*>(a + k);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) acc[c] += av[v] * xs[(k + v) * NR + c];
+            }
+        } else {
+            for (int k = lane; k < p.K; k += 64) {
+                const T av = a[k];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[c] += av * xs[k * NR + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NR; ++c) {
+            T v = acc[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[c] = v;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                if (c < p.nrhs) {
+                    T* yp = y + (int64_t)row * p.ldy + c;
+                    T r = p.alpha * acc[c];
+                    if (p.beta != T(0)) r += p.beta * (*yp);
+                    *yp = r;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda, int64_t sA,
+                const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy, T* ycopy,
+                int64_t ncopy, int64_t batch, hipStream_t stream) {
+    if (K > GEMV_MAXK || nrhs > 8 || nrhs < 1) return GPK_ERR_ARG(2);
+    if (M <= 0 && ncopy <= 0) return GPK_OK;
+    constexpr int VEC = Traits<T>::VEC;
+    GemvArgs<T> g;
+    g.A = A; g.lda = lda; g.sA = sA;
+    g.x = x; g.ldx = ldx; g.sx = sx;
+    g.y = y; g.ldy = ldy; g.sy = sy;
+    g.ycopy = ycopy; g.ncopy = ncopy;
+    g.M = (int)(M > 0 ? M : 0); g.K = (int)K; g.nrhs = nrhs;
+    g.alpha = alpha; g.beta = beta;
+    g.vec_ok = ((uintptr_t)A % 16 == 0) && (lda % VEC == 0) && (sA % VEC == 0) && (K % VEC == 0);
+    int64_t gx = gpk_cdiv(g.M, GEMV_ROWS);
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)batch);
+    if (nrhs == 1)
+        hipLaunchKernelGGL((gemv_kernel<T, 1>), grid, dim3(256), 0, stream, g);
+    else if (nrhs == 2)
+        hipLaunchKernelGGL((gemv_kernel<T, 2>), grid, dim3(256), 0, stream, g);
+    else if (nrhs <= 4)
+        hipLaunchKernelGGL((gemv_kernel<T, 4>), grid, dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemv_kernel<T, 8>), grid, dim3(256), 0, stream, g);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// merge inv(L_cc) 128-blocks into inverses of SB x SB diagonal blocks
+//   dinv_sb : [batch][nsb][sb][sb], nsb = ceil(n / sb)
+//   tmp     : at least nsb * sb * sb / 4 elements
+// ---------------------------------------------------------------------------
+template <typename T>
+int gpk_trtri_merge_launch(const T* L, int64_t n, int64_t ld, int64_t batch, int64_t bstride,
+                           const T* dinv128, int sb, T* dinv_sb, T* tmp, hipStream_t stream) {
+    if (n <= 0 || batch <= 0) return GPK_OK;
+    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(9);
+    const int nblk128 = (int)gpk_cdiv(n, GPK_DB);
+    const int64_t s128 = (int64_t)nblk128 * GPK_DB * GPK_DB;
+    const int nsb = (int)gpk_cdiv(n, sb);
+    const int64_t per = (int64_t)sb * sb;
+    const int64_t ssb = (int64_t)nsb * per;
+    if (batch > 65535) return GPK_ERR_ARG(4);
+    {
+        dim3 grid((unsigned)gpk_cdiv(per, 256 * 4), (unsigned)nsb, (unsigned)batch);
+        hipLaunchKernelGGL((place_blocks_kernel<T>), grid, dim3(256), 0, stream, dinv128, s128, nblk128,
+                           dinv_sb, ssb, sb, nsb);
+        GPK_CHECK_LAUNCH();
+    }
+    const int nfull = (int)(n / sb);
+    for (int h = GPK_DB; h < sb; h *= 2) {
+        const int ppb = sb / (2 * h);          // pairs per SB-block
+        const int64_t hh = (int64_t)h * h;
+        for (int64_t b = 0; b < batch; ++b) {
+            const T* Lb = L + b * bstride;
+            T* Db = dinv_sb + b * ssb;
+            if (nfull > 0) {
+                // T = L21 * Dinv_lo   (pairs: blockIdx.y, SB-blocks: blockIdx.z)
+                int st = gpk_gemm_launch2<T>(true, false, h, h, h, T(1), Lb + (int64_t)h * ld, ld,
+                                             2 * h * (ld + 1), (int64_t)sb * (ld + 1), Db, sb,
+                                             2 * h * (int64_t)(sb + 1), per, T(0), tmp, h, hh, ppb * hh, ppb,
+                                             nfull, false, stream);
+                if (st) return st;
+                // C' = -Dinv_hi * T
+                st = gpk_gemm_launch2<T>(true, false, h, h, h, T(-1), Db + (int64_t)h * (sb + 1), sb,
+                                         2 * h * (int64_t)(sb + 1), per, tmp, h, hh, ppb * hh, T(0),
+                                         Db + (int64_t)h * sb, sb, 2 * h * (int64_t)(sb + 1), per, ppb, nfull,
+                                         false, stream);
+                if (st) return st;
+            }
+            if (nfull < nsb) {   // ragged last SB-block: pair by pair, rows clipped to n
+                const int q = nfull;
+                T* tq = tmp + (int64_t)nfull * ppb * hh;
+                for (int pr = 0; pr < ppb; ++pr) {
+                    const int64_t o = (int64_t)q * sb + (int64_t)pr * 2 * h;   // global row/col of the pair
+                    const int64_t m = n - (o + h);
+                    if (m <= 0) break;
+                    const int64_t mv = m < h ? m : h;
+                    const int64_t oo = (int64_t)pr * 2 * h;                    // offset inside the SB-block
+                    T* Dq = Db + q * per;
+                    if (hipMemsetAsync(tq, 0, hh * sizeof(T), stream) != hipSuccess) return GPK_ERR_LAUNCH;
+                    int st = gpk_gemm_launch<T>(true, false, mv, h, h, T(1), Lb + (o + h) * ld + o, ld, 0,
+                                                Dq + oo * (sb + 1), sb, 0, T(0), tq, h, 0, 1, false, stream);
+                    if (st) return st;
+                    st = gpk_gemm_launch<T>(true, false, h, h, h, T(-1), Dq + (oo + h) * (sb + 1), sb, 0, tq,
+                                            h, 0, T(0), Dq + (oo + h) * sb + oo, sb, 0, 1, false, stream);
+                    if (st) return st;
+                }
+            }
+        }
+    }
+    return GPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// B <- L^{-1} B, many right-hand sides (GEMM sweep)
+//   dinv_sb: [batch][nsb][sb][sb];  tmp: [batch][sb][nrhs]
+// ---------------------------------------------------------------------------
+template <typename T>
+int gpk_trsm_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
+                    int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream) {
+    if (n <= 0 || nrhs <= 0 || batch <= 0) return GPK_OK;
+    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(6);
+    const int nsb = (int)gpk_cdiv(n, sb);
+    const int64_t per = (int64_t)sb * sb, ssb = (int64_t)nsb * per;
+    const int64_t st_tmp = (int64_t)sb * nrhs;
+    for (int q = 0; q < nsb; ++q) {
+        const int64_t r0 = (int64_t)q * sb;
+        const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
+        int st = gpk_gemm_launch<T>(true, false, rq, nrhs, rq, T(1), dinv_sb + q * per, sb, ssb,
+                                    B + r0 * ldb, ldb, sB, T(0), tmp, nrhs, st_tmp, batch, false, stream);
+        if (st) return st;
+        st = gpk_copy2d_launch<T>(tmp, nrhs, st_tmp, B + r0 * ldb, ldb, sB, rq, nrhs, batch, stream);
+        if (st) return st;
+        const int64_t r1 = r0 + rq;
+        if (r1 < n) {
+            st = gpk_gemm_launch<T>(true, false, n - r1, nrhs, rq, T(-1), L + r1 * ld + r0, ld, sL, tmp,
+                                    nrhs, st_tmp, T(1), B + r1 * ldb, ldb, sB, batch, false, stream);
+            if (st) return st;
+        }
+    }
+    return GPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// B <- L^{-1} B, nrhs <= 8 (GEMV sweep; HBM-bound: reads the lower triangle once)
+//   tmp: [batch][sb][nrhs]
+// ---------------------------------------------------------------------------
+template <typename T>
+int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
+                    int nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream) {
+    if (n <= 0 || nrhs <= 0 || batch <= 0) return GPK_OK;
+    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(6);
+    if (nrhs > 8) return GPK_ERR_ARG(8);
+    if (batch > 65535) return GPK_ERR_ARG(12);
+    const int nsb = (int)gpk_cdiv(n, sb);
+    const int64_t per = (int64_t)sb * sb, ssb = (int64_t)nsb * per;
+    const int64_t st_tmp = (int64_t)sb * nrhs;
+    for (int q = 0; q < nsb; ++q) {
+        const int64_t r0 = (int64_t)q * sb;
+        const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
+        // tmp = inv(L_qq) b_q
+        int st = gemv_launch<T>(rq, rq, nrhs, T(1), dinv_sb + q * per, sb, ssb, B + r0 * ldb, ldb, sB, T(0),
+                                tmp, nrhs, st_tmp, (T*)nullptr, 0, batch, stream);
+        if (st) return st;
+        // b_q = tmp;  b_below -= L[below, q] tmp
+        const int64_t r1 = r0 + rq;
+        st = gemv_launch<T>(n - r1, rq, nrhs, T(-1), L + r1 * ld + r0, ld, sL, tmp, nrhs, st_tmp, T(1),
+                            B + r1 * ldb, ldb, sB, B + r0 * ldb, rq, batch, stream);
+        if (st) return st;
+    }
+    return GPK_OK;
+}
+
+#define GPK_INST(T)                                                                                 \
+    template int gpk_trtri_merge_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,  \
+                                           int, T*, T*, hipStream_t);                               \
+    template int gpk_trsm_launch<T>(const T*, int64_t, int64_t, int64_t, const T*, int, T*, int64_t, \
+                                    int64_t, int64_t, T*, int64_t, hipStream_t);                    \
+    template int gpk_trsv_launch<T>(const T*, int64_t, int64_t, int64_t, const T*, int, T*, int,    \
+                                    int64_t, int64_t, T*, int64_t, hipStream_t);
+GPK_INST(double)
+GPK_INST(float)

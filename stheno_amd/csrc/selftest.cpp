@@ -1,0 +1,542 @@
+// selftest.cpp -- native GPU self-test + micro-benchmarks for libgpk.so.
+// Test infrastructure only (host references are plain C++ loops).  Built by the
+// Makefile into gpk_selftest; run on the MI355X box:
+//     ./gpk_selftest            correctness of every entry point vs host loops
+//     ./gpk_selftest --perf     + timings (HIP events) of the hot kernels
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+#include "../../include/gpk.h"
+
+#define HIPCHK(x)                                                                       \
+    do {                                                                                \
+        hipError_t e = (x);                                                             \
+        if (e != hipSuccess) {                                                          \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(3);                                                                    \
+        }                                                                               \
+    } while (0)
+
+static int g_fail = 0, g_pass = 0;
+static void report(const std::string& name, double err, double tol) {
+    const bool ok = (err <= tol) && std::isfinite(err);
+    printf("%s %-58s err=%.3e tol=%.1e\n", ok ? "PASS" : "FAIL", name.c_str(), err, tol);
+    fflush(stdout);
+    if (ok) ++g_pass; else ++g_fail;
+}
+
+template <typename T> struct DT;
+template <> struct DT<double> { static constexpr int v = GPK_F64; static constexpr double eps = 1e-12; static const char* name() { return "f64"; } };
+template <> struct DT<float> { static constexpr int v = GPK_F32; static constexpr double eps = 2e-4; static const char* name() { return "f32"; } };
+
+template <typename T>
+struct Dev {
+    T* p = nullptr;
+    size_t n = 0;
+    explicit Dev(size_t n_) : n(n_) { HIPCHK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); }
+    ~Dev() { hipFree(p); }
+    void up(const std::vector<T>& h) { HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    std::vector<T> down() const {
+        std::vector<T> h(n);
+        HIPCHK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+        return h;
+    }
+    void zero() { HIPCHK(hipMemset(p, 0, n * sizeof(T))); }
+};
+
+static std::mt19937_64 rng(1234);
+template <typename T>
+static std::vector<T> randv(size_t n, double scale = 1.0) {
+    std::normal_distribution<double> d(0.0, 1.0);
+    std::vector<T> v(n);
+    for (auto& x : v) x = (T)(scale * d(rng));
+    return v;
+}
+
+template <typename T>
+static double relerr(const std::vector<T>& got, const std::vector<double>& ref) {
+    double num = 0, den = 0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        const double d = (double)got[i] - ref[i];
+        if (!std::isfinite((double)got[i])) return INFINITY;
+        num = std::max(num, std::fabs(d));
+        den = std::max(den, std::fabs(ref[i]));
+    }
+    return num / std::max(den, 1e-300);
+}
+
+// ----------------------------------------------------------------------------
+// MFMA layout probe (documents the lane maps the kernels rely on)
+// ----------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__global__ void probe64(const double* A, const double* B, double* C) {   // A 16x4, B 4x16 row-major
+    const int l = threadIdx.x;
+    d4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) C[((l >> 4) + 4 * i) * 16 + (l & 15)] = acc[i];
+}
+__global__ void probe32(const float* A, const float* B, float* C) {
+    const int l = threadIdx.x;
+    f4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) C[((l >> 4) * 4 + i) * 16 + (l & 15)] = acc[i];
+}
+template <typename T>
+static void test_probe() {
+    auto A = randv<T>(64), B = randv<T>(64);
+    Dev<T> dA(64), dB(64), dC(256);
+    dA.up(A); dB.up(B);
+    if (sizeof(T) == 8) hipLaunchKernelGGL(probe64, dim3(1), dim3(64), 0, 0, (double*)dA.p, (double*)dB.p, (double*)dC.p);
+    else hipLaunchKernelGGL(probe32, dim3(1), dim3(64), 0, 0, (float*)dA.p, (float*)dB.p, (float*)dC.p);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> ref(256, 0.0);
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) for (int k = 0; k < 4; ++k) ref[i * 16 + j] += (double)A[i * 4 + k] * (double)B[k * 16 + j];
+    report(std::string("mfma_layout_") + DT<T>::name(), relerr(dC.down(), ref), DT<T>::eps);
+}
+
+// ----------------------------------------------------------------------------
+// GEMM
+// ----------------------------------------------------------------------------
+template <typename T>
+static void test_gemm_case(bool ak, bool bk, int M, int N, int K, double alpha, double beta, int batch, bool lower, int pad) {
+    const int64_t lda = (ak ? K : M) + pad, ldb = (bk ? K : N) + pad, ldc = N + pad;
+    const int64_t ra = ak ? M : K, rb = bk ? N : K;
+    const int64_t sA = ra * lda + 2 * pad, sB = rb * ldb + 2 * pad, sC = M * ldc + 2 * pad;
+    auto A = randv<T>(sA * batch), B = randv<T>(sB * batch), C = randv<T>(sC * batch);
+    Dev<T> dA(A.size()), dB(B.size()), dC(C.size());
+    dA.up(A); dB.up(B); dC.up(C);
+    int st = gpk_gemm(DT<T>::v, ak, bk, M, N, K, alpha, dA.p, lda, sA, dB.p, ldb, sB, beta, dC.p, ldc, sC, batch, lower, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto got = dC.down();
+    std::vector<double> ref(C.begin(), C.end());
+    for (int b = 0; b < batch; ++b)
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                if (lower && (n / 128) > (m / 128)) continue;   // tile not computed
+                double s = 0;
+                for (int k = 0; k < K; ++k) {
+                    const double a = ak ? A[b * sA + m * lda + k] : A[b * sA + k * lda + m];
+                    const double bb = bk ? B[b * sB + n * ldb + k] : B[b * sB + k * ldb + n];
+                    s += a * bb;
+                }
+                const double c0 = (beta != 0.0) ? beta * (double)C[b * sC + m * ldc + n] : 0.0;
+                ref[b * sC + m * ldc + n] = alpha * s + c0;
+            }
+    char nm[160];
+    snprintf(nm, sizeof nm, "gemm_%s %c%c M%d N%d K%d a%.0f b%.0f batch%d low%d pad%d st%d", DT<T>::name(), ak ? 'k' : 'r', bk ? 'k' : 'r', M, N, K, alpha, beta, batch, (int)lower, pad, st);
+    report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * std::sqrt((double)K + 1));
+}
+template <typename T>
+static void test_gemm() {
+    for (int ak = 0; ak < 2; ++ak)
+        for (int bk = 0; bk < 2; ++bk) {
+            test_gemm_case<T>(ak, bk, 128, 128, 128, 1, 0, 1, false, 0);
+            test_gemm_case<T>(ak, bk, 256, 384, 64, -1, 1, 2, false, 0);
+            test_gemm_case<T>(ak, bk, 100, 70, 37, 1, 1, 1, false, 0);
+            test_gemm_case<T>(ak, bk, 300, 200, 150, -1, 0, 3, false, 1);
+        }
+    test_gemm_case<T>(true, true, 512, 512, 256, -1, 1, 1, true, 0);
+    test_gemm_case<T>(true, true, 5 * 128 + 17, 5 * 128 + 17, 128, -1, 1, 2, true, 0);
+    test_gemm_case<T>(true, true, 4352, 4352, 32, -1, 1, 1, true, 0);    // 34x34 tiles -> XCD super-tile path
+    test_gemm_case<T>(true, false, 4224, 4224, 32, 1, 0, 1, false, 0);   // 33x33 tiles, rectangular super-tiles
+}
+
+// ----------------------------------------------------------------------------
+// kernel matrix
+// ----------------------------------------------------------------------------
+static double kappa(int kind, double r2, double dot, double il) {
+    const double q = r2 * il * il;
+    switch (kind) {
+        case GPK_K_EQ: return std::exp(-0.5 * q);
+        case GPK_K_MATERN12: return std::exp(-std::sqrt(q));
+        case GPK_K_MATERN32: { double s = std::sqrt(3 * q); return (1 + s) * std::exp(-s); }
+        case GPK_K_MATERN52: { double s = std::sqrt(5 * q); return (1 + s + s * s / 3) * std::exp(-s); }
+        case GPK_K_LINEAR: return dot * il * il;
+        default: return 1.0;
+    }
+}
+template <typename T>
+static void test_kmat_case(std::vector<int> kinds, int n, int m, int d, int batch, bool sym, bool lower, bool acc, bool dvec) {
+    const int nt = (int)kinds.size();
+    std::vector<double> var(nt), il(nt);
+    for (int t = 0; t < nt; ++t) { var[t] = 0.5 + 0.3 * t; il[t] = 1.0 / (0.7 + 0.2 * t); }
+    if (sym) m = n;
+    auto X = randv<T>((size_t)batch * n * d), Y = sym ? X : randv<T>((size_t)batch * m * d);
+    const int64_t ld = m + 3;
+    auto O = randv<T>((size_t)batch * n * ld);
+    auto dv = randv<T>((size_t)batch * n);
+    Dev<T> dX(X.size()), dY(Y.size()), dO(O.size()), dD(dv.size());
+    dX.up(X); dY.up(Y); dO.up(O); dD.up(dv);
+    int st = gpk_kmat(DT<T>::v, kinds.data(), var.data(), il.data(), nt, dX.p, n, d, (int64_t)n * d, sym ? dX.p : dY.p, m, d, (int64_t)m * d, d,
+                      dO.p, ld, (int64_t)n * ld, batch, lower, sym, sym ? 0.25 : 0.0, dvec ? dD.p : nullptr, n, acc, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto got = dO.down();
+    std::vector<double> ref(O.begin(), O.end());
+    const int TN = 64 * (16 / (int)sizeof(T));
+    for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < m; ++j) {
+                if (lower && (j / TN) * TN > (i / 32) * 32 + 31) continue;
+                double r2 = 0, dot = 0;
+                for (int k = 0; k < d; ++k) {
+                    const double a = X[((size_t)b * n + i) * d + k], c = Y[((size_t)b * m + j) * d + k];
+                    r2 += (a - c) * (a - c);
+                    dot += a * c;
+                }
+                double v = 0;
+                for (int t = 0; t < nt; ++t) v += var[t] * kappa(kinds[t], r2, dot, il[t]);
+                if (sym && i == j) v += 0.25 + (dvec ? (double)dv[(size_t)b * n + i] : 0.0);
+                const size_t o = (size_t)b * n * ld + (size_t)i * ld + j;
+                ref[o] = acc ? (double)O[o] + v : v;
+            }
+    char nm[160];
+    snprintf(nm, sizeof nm, "kmat_%s k%d.. nt%d n%d m%d d%d b%d sym%d low%d acc%d dv%d st%d", DT<T>::name(), kinds[0], nt, n, m, d, batch, sym, lower, acc, dvec, st);
+    report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * 50);
+}
+template <typename T>
+static void test_kmat() {
+    for (int k = 0; k <= 5; ++k) test_kmat_case<T>({k}, 70, 45, 3, 1, false, false, false, false);
+    test_kmat_case<T>({GPK_K_EQ}, 300, 300, 8, 2, true, false, false, true);
+    test_kmat_case<T>({GPK_K_EQ}, 700, 700, 8, 1, true, true, false, false);
+    test_kmat_case<T>({GPK_K_EQ, GPK_K_LINEAR}, 257, 129, 4, 1, false, false, true, false);
+    test_kmat_case<T>({GPK_K_MATERN52, GPK_K_MATERN32, GPK_K_CONST}, 64, 512, 20, 1, false, false, false, false);
+    test_kmat_case<T>({GPK_K_EQ}, 33, 33, 1, 3, true, false, false, false);
+    // kdiag
+    {
+        const int n = 100, d = 5;
+        std::vector<int> kinds = {GPK_K_EQ, GPK_K_LINEAR};
+        std::vector<double> var = {0.7, 1.3}, il = {1.0, 0.5};
+        auto X = randv<T>(n * d);
+        Dev<T> dX(X.size()), dO(n);
+        dX.up(X);
+        int st = gpk_kdiag(DT<T>::v, kinds.data(), var.data(), il.data(), 2, dX.p, n, d, n * d, d, dO.p, n, 1, nullptr);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<double> ref(n);
+        for (int i = 0; i < n; ++i) { double nr = 0; for (int k = 0; k < d; ++k) nr += (double)X[i * d + k] * X[i * d + k]; ref[i] = 0.7 + 1.3 * 0.25 * nr; }
+        report(std::string("kdiag_") + DT<T>::name(), st ? INFINITY : relerr(dO.down(), ref), DT<T>::eps * 50);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Cholesky + solves
+// ----------------------------------------------------------------------------
+template <typename T>
+static std::vector<T> make_spd(int n, int batch, int64_t ld) {
+    // EQ kernel on random 3-d points + 0.5 I  (condition number modest)
+    std::vector<T> A((size_t)batch * n * ld, (T)0);
+    for (int b = 0; b < batch; ++b) {
+        auto X = randv<double>((size_t)n * 3);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double r2 = 0;
+                for (int k = 0; k < 3; ++k) { double df = X[i * 3 + k] - X[j * 3 + k]; r2 += df * df; }
+                double v = std::exp(-0.5 * r2) + (i == j ? 0.5 : 0.0);
+                A[(size_t)b * n * ld + (size_t)i * ld + j] = (T)v;
+                A[(size_t)b * n * ld + (size_t)j * ld + i] = (T)v;
+            }
+    }
+    return A;
+}
+static void host_chol(std::vector<double>& A, int n, int64_t ld) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[j * ld + j];
+        for (int k = 0; k < j; ++k) d -= A[j * ld + k] * A[j * ld + k];
+        d = std::sqrt(d);
+        A[j * ld + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[i * ld + j];
+            for (int k = 0; k < j; ++k) s -= A[i * ld + k] * A[j * ld + k];
+            A[i * ld + j] = s / d;
+        }
+    }
+}
+template <typename T>
+static void test_potrf_case(int n, int batch, int nbo, int nrhs_small, int nrhs_big, int sb) {
+    const int64_t ld = n + (n % 2);   // keep rows 16-byte aligned for f64, exercise ld != n
+    auto A = make_spd<T>(n, batch, ld);
+    const int64_t sA = (int64_t)n * ld;
+    const int64_t de = gpk_dinv_elems(n);
+    Dev<T> dA(A.size()), dinv((size_t)de * batch);
+    Dev<int> info(batch);
+    dA.up(A); info.zero();
+    int st = gpk_potrf(DT<T>::v, dA.p, n, ld, sA, batch, dinv.p, info.p, nbo, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto L = dA.down();
+    auto inf = info.down();
+    // host reference factor
+    std::vector<double> Lref(A.begin(), A.end());
+    for (int b = 0; b < batch; ++b) {
+        std::vector<double> sub(Lref.begin() + b * sA, Lref.begin() + (b + 1) * sA);
+        host_chol(sub, n, ld);
+        std::copy(sub.begin(), sub.end(), Lref.begin() + b * sA);
+    }
+    double num = 0, den = 0;
+    bool finite = true;
+    for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) {
+                const double g = L[b * sA + i * ld + j], r = Lref[b * sA + i * ld + j];
+                if (!std::isfinite(g)) finite = false;
+                num = std::max(num, std::fabs(g - r));
+                den = std::max(den, std::fabs(r));
+            }
+    char nm[160];
+    snprintf(nm, sizeof nm, "potrf_%s n%d batch%d nbo%d st%d info%d", DT<T>::name(), n, batch, nbo, st, inf[0]);
+    report(nm, (st || !finite || inf[0]) ? INFINITY : num / den, DT<T>::eps * 100);
+
+    // dinv check: inv(L_cc) * L_cc = I on the first and last diagonal block of batch 0
+    {
+        auto W = dinv.down();
+        const int nblk = (n + 127) / 128;
+        double worst = 0;
+        for (int blk : {0, nblk - 1}) {
+            const int o = blk * 128, nv = std::min(128, n - o);
+            for (int i = 0; i < nv; ++i)
+                for (int j = 0; j < nv; ++j) {
+                    double s = 0;
+                    for (int k = 0; k < nv; ++k) s += (double)W[(size_t)blk * 16384 + i * 128 + k] * Lref[(o + k) * ld + o + j] * (k >= j ? 1.0 : 0.0);
+                    worst = std::max(worst, std::fabs(s - (i == j ? 1.0 : 0.0)));
+                }
+        }
+        snprintf(nm, sizeof nm, "dinv128_%s n%d", DT<T>::name(), n);
+        report(nm, worst, DT<T>::eps * 1000);
+    }
+
+    // logdet
+    {
+        Dev<T> out(batch);
+        int s2 = gpk_logdet_chol(DT<T>::v, dA.p, n, ld, sA, batch, out.p, nullptr);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<double> ref(batch, 0.0);
+        for (int b = 0; b < batch; ++b) for (int i = 0; i < n; ++i) ref[b] += 2 * std::log(Lref[b * sA + i * ld + i]);
+        snprintf(nm, sizeof nm, "logdet_%s n%d st%d", DT<T>::name(), n, s2);
+        report(nm, s2 ? INFINITY : relerr(out.down(), ref), DT<T>::eps * 100);
+    }
+
+    // merged inverses + solves
+    Dev<T> dsb((size_t)batch * ((n + sb - 1) / sb) * sb * sb), tmpm((size_t)((n + sb - 1) / sb) * sb * sb / 4 + 16);
+    int s3 = gpk_trtri_merge(DT<T>::v, dA.p, n, ld, sA, batch, dinv.p, sb, dsb.p, tmpm.p, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    for (int pass = 0; pass < 2; ++pass) {
+        const int nrhs = pass == 0 ? nrhs_small : nrhs_big;
+        if (nrhs <= 0) continue;
+        const int64_t ldb = nrhs + (pass == 0 ? 0 : 2);
+        auto Bm = randv<T>((size_t)batch * n * ldb);
+        Dev<T> dB(Bm.size()), tmp((size_t)batch * sb * nrhs);
+        dB.up(Bm);
+        int s4 = pass == 0 ? gpk_trsv_lower(DT<T>::v, dA.p, n, ld, sA, dsb.p, sb, dB.p, nrhs, ldb, (int64_t)n * ldb, tmp.p, batch, nullptr)
+                           : gpk_trsm_lower(DT<T>::v, dA.p, n, ld, sA, dsb.p, sb, dB.p, nrhs, ldb, (int64_t)n * ldb, tmp.p, batch, nullptr);
+        HIPCHK(hipDeviceSynchronize());
+        std::vector<double> ref(Bm.begin(), Bm.end());
+        for (int b = 0; b < batch; ++b)
+            for (int c = 0; c < nrhs; ++c)
+                for (int i = 0; i < n; ++i) {
+                    double s = ref[((size_t)b * n + i) * ldb + c];
+                    for (int k = 0; k < i; ++k) s -= Lref[b * sA + i * ld + k] * ref[((size_t)b * n + k) * ldb + c];
+                    ref[((size_t)b * n + i) * ldb + c] = s / Lref[b * sA + i * ld + i];
+                }
+        // compare only the nrhs columns
+        auto got = dB.down();
+        double nu = 0, de2 = 0;
+        for (int b = 0; b < batch; ++b) for (int i = 0; i < n; ++i) for (int c = 0; c < nrhs; ++c) {
+            const size_t o = ((size_t)b * n + i) * ldb + c;
+            if (!std::isfinite((double)got[o])) nu = INFINITY;
+            nu = std::max(nu, std::fabs((double)got[o] - ref[o]));
+            de2 = std::max(de2, std::fabs(ref[o]));
+        }
+        snprintf(nm, sizeof nm, "%s_%s n%d nrhs%d sb%d batch%d st%d/%d", pass == 0 ? "trsv" : "trsm", DT<T>::name(), n, nrhs, sb, batch, s3, s4);
+        report(nm, (s3 || s4) ? INFINITY : nu / de2, DT<T>::eps * 1000);
+    }
+}
+template <typename T>
+static void test_potrf() {
+    test_potrf_case<T>(10, 1, 0, 1, 3, 128);
+    test_potrf_case<T>(100, 3, 0, 2, 0, 128);
+    test_potrf_case<T>(128, 1, 0, 1, 130, 128);
+    test_potrf_case<T>(200, 2, 0, 3, 64, 128);
+    test_potrf_case<T>(256, 1, 128, 1, 0, 256);
+    test_potrf_case<T>(384, 1, 256, 8, 200, 256);
+    test_potrf_case<T>(500, 2, 256, 1, 129, 512);
+    test_potrf_case<T>(1024, 1, 256, 1, 256, 512);
+    test_potrf_case<T>(1200, 1, 512, 4, 100, 512);
+    test_potrf_case<T>(1664, 1, 256, 1, 300, 256);
+}
+
+// ----------------------------------------------------------------------------
+// reductions / misc
+// ----------------------------------------------------------------------------
+template <typename T>
+static void test_misc() {
+    const int rows = 1000, cols = 300, batch = 2;
+    const int64_t ld = cols + 4;
+    auto V = randv<T>((size_t)batch * rows * ld), w = randv<T>((size_t)batch * rows);
+    Dev<T> dV(V.size()), dw(w.size()), od((size_t)batch * cols), os((size_t)batch * cols), ws(2 * (size_t)batch * gpk_colreduce_chunks(rows) * cols);
+    dV.up(V); dw.up(w);
+    int st = gpk_colreduce(DT<T>::v, dV.p, rows, cols, ld, (int64_t)rows * ld, dw.p, rows, od.p, os.p, ws.p, batch, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> rd((size_t)batch * cols, 0), rs((size_t)batch * cols, 0);
+    for (int b = 0; b < batch; ++b) for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) {
+        const double v = V[((size_t)b * rows + r) * ld + c];
+        rd[b * cols + c] += v * w[b * rows + r];
+        rs[b * cols + c] += v * v;
+    }
+    report(std::string("colreduce_dot_") + DT<T>::name(), st ? INFINITY : relerr(od.down(), rd), DT<T>::eps * 100);
+    report(std::string("colreduce_ss_") + DT<T>::name(), st ? INFINITY : relerr(os.down(), rs), DT<T>::eps * 100);
+    // tril + add_diag + copy2d
+    const int n = 300;
+    auto A = randv<T>((size_t)n * n), dv = randv<T>(n);
+    Dev<T> dA(A.size()), dd(n), dC(A.size());
+    dA.up(A); dd.up(dv);
+    gpk_add_diag(DT<T>::v, dA.p, n, n, (int64_t)n * n, 0.5, dd.p, n, 1, nullptr);
+    gpk_tril(DT<T>::v, dA.p, n, n, (int64_t)n * n, 1, nullptr);
+    gpk_copy2d(DT<T>::v, dA.p, n, 0, dC.p, n, 0, n, n, 1, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> ref((size_t)n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) ref[i * n + j] = j > i ? 0.0 : (double)A[i * n + j] + (i == j ? 0.5 + (double)dv[i] : 0.0);
+    report(std::string("add_diag_tril_copy_") + DT<T>::name(), relerr(dC.down(), ref), DT<T>::eps);
+}
+
+// ----------------------------------------------------------------------------
+// perf
+// ----------------------------------------------------------------------------
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { hipEventCreate(&a); hipEventCreate(&b); }
+    void start() { hipEventRecord(a, 0); }
+    float stop() { hipEventRecord(b, 0); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b); return ms; }
+};
+template <typename T>
+static void perf() {
+    Timer tm;
+    const double peak = sizeof(T) == 8 ? 78.6 : 157.3;
+    // GEMM NT
+    for (int n : {4096, 8192}) {
+        Dev<T> A((size_t)n * n), B((size_t)n * n), C((size_t)n * n);
+        auto h = randv<T>((size_t)n * n);
+        A.up(h); B.up(h); C.zero();
+        for (int rep = 0; rep < 2; ++rep) {
+            tm.start();
+            gpk_gemm(DT<T>::v, 1, 1, n, n, n, -1.0, A.p, n, 0, B.p, n, 0, 1.0, C.p, n, 0, 1, 0, nullptr);
+            const float ms = tm.stop();
+            const double tf = 2.0 * n * n * (double)n / ms * 1e-9;
+            printf("PERF gemm_nt_%s n=%d  %.3f ms  %.2f TFLOP/s  (%.1f%% of %.1f)\n", DT<T>::name(), n, ms, tf, 100 * tf / peak, peak);
+        }
+    }
+    // SYRK-like trailing update: M=N=16384-ish, K=256, lower
+    for (int k : {128, 256, 512}) {
+        const int n = 12288;
+        Dev<T> P((size_t)n * k), C((size_t)n * n);
+        auto h = randv<T>((size_t)n * k);
+        P.up(h); C.zero();
+        for (int rep = 0; rep < 2; ++rep) {
+            tm.start();
+            gpk_gemm(DT<T>::v, 1, 1, n, n, k, -1.0, P.p, k, 0, P.p, k, 0, 1.0, C.p, n, 0, 1, 1, nullptr);
+            const float ms = tm.stop();
+            const double tf = 1.0 * n * (double)n * k / ms * 1e-9;
+            printf("PERF syrk_lower_%s n=%d k=%d  %.3f ms  %.2f TFLOP/s (sym count) (%.1f%%)\n", DT<T>::name(), n, k, ms, tf, 100 * tf / peak);
+        }
+    }
+    // kmat + potrf + trsv + trsm at growing N
+    for (int n : {2048, 4096, 8192, 16384}) {
+        const int d = 8;
+        auto hx = randv<T>((size_t)n * d);
+        Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n));
+        Dev<int> info(1);
+        X.up(hx);
+        int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+        float ms_k = 0, ms_p = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            info.zero();
+            tm.start();
+            gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+            ms_k = tm.stop();
+            tm.start();
+            gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, 0, nullptr);
+            ms_p = tm.stop();
+        }
+        const double tf = (double)n * n * n / 3.0 / ms_p * 1e-9;
+        printf("PERF kmat_lower_%s n=%d d=%d  %.3f ms  %.1f GB/s (lower bytes)\n", DT<T>::name(), n, d, ms_k, 0.5 * n * (double)n * sizeof(T) / ms_k * 1e-6);
+        printf("PERF potrf_%s n=%d  %.3f ms  %.2f TFLOP/s (%.1f%% of %.1f) info=%d\n", DT<T>::name(), n, ms_p, tf, 100 * tf / peak, peak, info.down()[0]);
+        for (int nbo : {128, 512}) {
+            info.zero();
+            gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+            tm.start();
+            gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, nbo, nullptr);
+            const float ms = tm.stop();
+            printf("PERF potrf_%s n=%d nbo=%d  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), n, nbo, ms, (double)n * n * n / 3.0 / ms * 1e-9);
+        }
+        // trsv (nrhs = 1), sb = 128
+        {
+            Dev<T> y(n), tmp(512);
+            auto hy = randv<T>(n);
+            for (int rep = 0; rep < 2; ++rep) {
+                y.up(hy);
+                tm.start();
+                gpk_trsv_lower(DT<T>::v, K.p, n, n, 0, dinv.p, 128, y.p, 1, 1, 0, tmp.p, 1, nullptr);
+                const float ms = tm.stop();
+                if (rep) printf("PERF trsv_%s n=%d sb=128  %.3f ms  %.1f GB/s\n", DT<T>::name(), n, ms, 0.5 * n * (double)n * sizeof(T) / ms * 1e-6);
+            }
+        }
+        // merge + trsm (nrhs = 2048)
+        for (int sb : {128, 512}) {
+            const int nrhs = 2048;
+            Dev<T> dsb((size_t)((n + sb - 1) / sb) * sb * sb), tmpm((size_t)((n + sb - 1) / sb) * sb * sb / 4 + 16), Bm((size_t)n * nrhs), tmp((size_t)sb * nrhs);
+            auto hb = randv<T>((size_t)n * nrhs);
+            Bm.up(hb);
+            tm.start();
+            gpk_trtri_merge(DT<T>::v, K.p, n, n, 0, 1, dinv.p, sb, dsb.p, tmpm.p, nullptr);
+            const float ms_m = tm.stop();
+            tm.start();
+            gpk_trsm_lower(DT<T>::v, K.p, n, n, 0, dsb.p, sb, Bm.p, nrhs, nrhs, 0, tmp.p, 1, nullptr);
+            const float ms = tm.stop();
+            printf("PERF trsm_%s n=%d nrhs=%d sb=%d  merge %.3f ms  solve %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), n, nrhs, sb, ms_m, ms, (double)n * n * nrhs / ms * 1e-9);
+        }
+    }
+    // batched: 512 x 2048 (f32 config 4) -- only for float to bound memory/time
+    if (sizeof(T) == 4) {
+        const int n = 2048, d = 3, batch = 512;
+        auto hx = randv<T>((size_t)batch * n * d);
+        Dev<T> X(hx.size()), K((size_t)batch * n * n), dinv((size_t)batch * gpk_dinv_elems(n));
+        Dev<int> info(batch);
+        X.up(hx);
+        int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+        for (int rep = 0; rep < 2; ++rep) {
+            info.zero();
+            tm.start();
+            gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, X.p, n, d, (int64_t)n * d, d, K.p, n, (int64_t)n * n, batch, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+            const float ms_k = tm.stop();
+            tm.start();
+            gpk_potrf(DT<T>::v, K.p, n, n, (int64_t)n * n, batch, dinv.p, info.p, 0, nullptr);
+            const float ms_p = tm.stop();
+            printf("PERF batched_%s 512x2048: kmat %.3f ms, potrf %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), ms_k, ms_p, batch * (double)n * n * n / 3.0 / ms_p * 1e-9);
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    bool do_perf = false, only_perf = false;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--perf")) do_perf = true;
+        if (!strcmp(argv[i], "--only-perf")) do_perf = only_perf = true;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  arch=%s  CUs=%d  clock=%d MHz  gpk_version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, gpk_version());
+    if (!only_perf) {
+        test_probe<double>(); test_probe<float>();
+        test_gemm<double>(); test_gemm<float>();
+        test_kmat<double>(); test_kmat<float>();
+        test_potrf<double>(); test_potrf<float>();
+        test_misc<double>(); test_misc<float>();
+        printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
+    }
+    if (do_perf) { perf<double>(); perf<float>(); }
+    return g_fail ? 1 : 0;
+}
