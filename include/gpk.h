@@ -137,6 +137,20 @@ int gpk_tril(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batc
 int gpk_add_diag(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, double s, const void* v,
                  int64_t sv, int64_t batch, void* stream);
 
+/* V[i][j] *= s[j]  (column scaling by K_n^{-1/2} in the pseudo-point ELBO: the
+ * `B.iqf(K_n, .)` with diagonal K_n of stheno/model/observations.py:322,327). */
+int gpk_scale_cols(int dtype, void* v, int64_t rows, int64_t cols, int64_t ld, int64_t sv, const void* s,
+                   int64_t ss, int64_t batch, void* stream);
+
+/* Mirror the lower triangle into the upper one (full symmetric matrix after a lower-only SYRK/kmat). */
+int gpk_symmetrize(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* stream);
+
+/* y[m x nrhs] = alpha * A[m x k] x[k x nrhs] + beta * y, nrhs <= 8, A row-major; trans must be 0.
+ * HBM-bound matrix-vector products of the path (e.g. `B.iqf(K_n, V^T, y)`: observations.py:327). */
+int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha, const void* a, int64_t lda,
+             int64_t sa, const void* x, int64_t ldx, int64_t sx, double beta, void* y, int64_t ldy, int64_t sy,
+             int64_t batch, void* stream);
+
 /* Strided 2-D copy (rows x cols). */
 int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, int64_t ldd, int64_t sd,
                int64_t rows, int64_t cols, int64_t batch, void* stream);

@@ -1,0 +1,102 @@
+"""ctypes binding of ``libgpk.so`` (the C ABI declared in ``include/gpk.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C stheno_amd/csrc``).
+There is NO fallback: if the shared object is missing, loading raises.
+"""
+import ctypes
+import os
+
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_dbl = ctypes.c_double
+_c_ptr = ctypes.c_void_p
+_p_int = ctypes.POINTER(ctypes.c_int)
+_p_dbl = ctypes.POINTER(ctypes.c_double)
+
+GPK_F32 = 0
+GPK_F64 = 1
+
+K_EQ, K_MATERN12, K_MATERN32, K_MATERN52, K_LINEAR, K_CONST = range(6)
+MAX_TERMS = 8
+DIAG_BLOCK = 128
+
+#: name -> (restype, argtypes); mirrors include/gpk.h declaration by declaration.
+SIGNATURES = {
+    "gpk_version": (_c_int, []),
+    "gpk_dinv_elems": (_c_i64, [_c_i64]),
+    "gpk_colreduce_chunks": (_c_i64, [_c_i64]),
+    "gpk_kmat": (
+        _c_int,
+        [_c_int, _p_int, _p_dbl, _p_dbl, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
+         _c_i64, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_dbl, _c_ptr, _c_i64, _c_int,
+         _c_ptr],
+    ),
+    "gpk_kdiag": (
+        _c_int,
+        [_c_int, _p_int, _p_dbl, _p_dbl, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64,
+         _c_i64, _c_ptr],
+    ),
+    "gpk_potrf": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr]),
+    "gpk_trtri_merge": (
+        _c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]
+    ),
+    "gpk_trsm_lower": (
+        _c_int,
+        [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr,
+         _c_i64, _c_ptr],
+    ),
+    "gpk_trsv_lower": (
+        _c_int,
+        [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_int, _c_i64, _c_i64, _c_ptr,
+         _c_i64, _c_ptr],
+    ),
+    "gpk_gemm": (
+        _c_int,
+        [_c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_dbl, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64,
+         _c_i64, _c_dbl, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr],
+    ),
+    "gpk_logdet_chol": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr]),
+    "gpk_colreduce": (
+        _c_int,
+        [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_i64,
+         _c_ptr],
+    ),
+    "gpk_tril": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    "gpk_add_diag": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    "gpk_scale_cols": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_ptr]),
+    "gpk_symmetrize": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr]),
+    "gpk_gemv": (
+        _c_int,
+        [_c_int, _c_int, _c_i64, _c_i64, _c_int, _c_dbl, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
+         _c_dbl, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
+    ),
+    "gpk_copy2d": (
+        _c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr]
+    ),
+}
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgpk.so")
+
+
+def load():
+    """Load ``libgpk.so`` and attach the prototypes.  Raises if it was not built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C stheno_amd/csrc`). "
+                "stheno_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(path)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB

@@ -102,4 +102,21 @@ int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, i
                                    (hipStream_t)stream));
 }
 
+int gpk_scale_cols(int dtype, void* v, int64_t rows, int64_t cols, int64_t ld, int64_t sv, const void* s,
+                   int64_t ss, int64_t batch, void* stream) {
+    D1(dtype, gpk_scale_cols_launch<T>((T*)v, rows, cols, ld, sv, (const T*)s, ss, batch, (hipStream_t)stream));
+}
+
+int gpk_symmetrize(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* stream) {
+    D1(dtype, gpk_symmetrize_launch<T>((T*)a, n, ld, sa, batch, (hipStream_t)stream));
+}
+
+int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha, const void* a, int64_t lda,
+             int64_t sa, const void* x, int64_t ldx, int64_t sx, double beta, void* y, int64_t ldy, int64_t sy,
+             int64_t batch, void* stream) {
+    if (trans != 0) return -2;   // A^T x is gpk_colreduce (nrhs = 1) or gpk_gemm
+    D1(dtype, gpk_gemv_launch<T>(m, k, nrhs, (T)alpha, (const T*)a, lda, sa, (const T*)x, ldx, sx, (T)beta,
+                                 (T*)y, ldy, sy, batch, (hipStream_t)stream));
+}
+
 }  // extern "C"

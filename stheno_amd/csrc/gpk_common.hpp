@@ -133,3 +133,12 @@ template <typename T>
 int gpk_kdiag_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms,
                      const T* X, int64_t n, int64_t ldx, int64_t sX, int d, T* out, int64_t sO,
                      int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_scale_cols_launch(T* V, int64_t rows, int64_t cols, int64_t ld, int64_t sV, const T* s, int64_t ss,
+                          int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_symmetrize_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda, int64_t sA,
+                    const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy,
+                    int64_t batch, hipStream_t stream);

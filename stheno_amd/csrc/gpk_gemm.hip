@@ -64,20 +64,21 @@ __device__ __forceinline__ void tri_decode(int s, int& I, int& J) {
 
 template <typename T>
 __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& ti, int& tj) {
+    const bool tri = p.lower_only && p.tiles_m == p.tiles_n;   // square: triangular enumeration
     if (!p.swizzle) {
-        if (p.lower_only) {
+        if (tri) {
             tri_decode(bid, ti, tj);
             return ti < p.tiles_m;
         }
         ti = bid / p.tiles_n;
         tj = bid - ti * p.tiles_n;
-        return ti < p.tiles_m;
+        return ti < p.tiles_m && (!p.lower_only || tj <= ti);
     }
     const int xcd = bid & 7, local = bid >> 3;
     const int s = (local >> 6) * 8 + xcd, w = local & 63;
     if (s >= p.n_super) return false;
     int I, J;
-    if (p.lower_only) {
+    if (tri) {
         tri_decode(s, I, J);
     } else {
         I = s / p.SN;
@@ -307,7 +308,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.tiles_n = (int)gpk_cdiv(N, GPK_TILE);
     g.lower_only = lower_only ? 1 : 0;
 
-    const int64_t total = lower_only ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
+    const bool tri = lower_only && g.tiles_m == g.tiles_n;
+    const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
                                      : (int64_t)g.tiles_m * g.tiles_n;
     int64_t gridx;
     g.swizzle = (total >= 1024) ? 1 : 0;
@@ -316,7 +318,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     if (g.swizzle) {
         const int SM = (g.tiles_m + 7) / 8;
         g.SN = (g.tiles_n + 7) / 8;
-        g.n_super = lower_only ? SM * (SM + 1) / 2 : SM * g.SN;
+        g.n_super = tri ? SM * (SM + 1) / 2 : SM * g.SN;
         gridx = gpk_cdiv(g.n_super, 8) * 8 * 64;
     } else {
         gridx = total;

@@ -151,7 +151,67 @@ __global__ __launch_bounds__(256) void set_identity_kernel(T* __restrict__ dst, 
     }
 }
 
+// V[i][j] *= s[j]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_cols_kernel(T* __restrict__ V, int64_t rows, int64_t cols,
+                                                         int64_t ld, int64_t sV, const T* __restrict__ s,
+                                                         int64_t ss) {
+    const int64_t b = blockIdx.z;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const T f = s[b * ss + c];
+    const int64_t r0 = (int64_t)blockIdx.y * 8;
+    for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + i;
+        if (r < rows) V[b * sV + r * ld + c] *= f;
+    }
+}
+
+// A[i][j] = A[j][i] for j > i (mirror the lower triangle), 32x32 LDS transposes
+template <typename T>
+__global__ __launch_bounds__(256) void symmetrize_kernel(T* __restrict__ A, int64_t n, int64_t ld,
+                                                         int64_t sA) {
+    __shared__ T tile[32][33];
+    const int64_t b = blockIdx.z;
+    const int bi = blockIdx.y, bj = blockIdx.x;   // source tile (rows bi, cols bj), need bj <= bi
+    if (bj > bi) return;
+    T* Ab = A + b * sA;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t r = (int64_t)bi * 32 + i, c = (int64_t)bj * 32 + tx;
+        tile[i][tx] = (r < n && c < n) ? Ab[r * ld + c] : T(0);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t r = (int64_t)bj * 32 + i, c = (int64_t)bi * 32 + tx;   // destination (transposed tile)
+        if (r < n && c < n && c > r) Ab[r * ld + c] = tile[tx][i];
+    }
+}
+
 }  // namespace
+
+template <typename T>
+int gpk_scale_cols_launch(T* V, int64_t rows, int64_t cols, int64_t ld, int64_t sV, const T* s, int64_t ss,
+                          int64_t batch, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || batch <= 0) return GPK_OK;
+    const int64_t gy = gpk_cdiv(rows, 8);
+    if (gy > 65535 || batch > 65535) return GPK_ERR_ARG(3);
+    dim3 g((unsigned)gpk_cdiv(cols, 256), (unsigned)gy, (unsigned)batch);
+    hipLaunchKernelGGL((scale_cols_kernel<T>), g, dim3(256), 0, stream, V, rows, cols, ld, sV, s, ss);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
+int gpk_symmetrize_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream) {
+    if (n <= 0 || batch <= 0) return GPK_OK;
+    const int64_t t = gpk_cdiv(n, 32);
+    if (t > 65535 || batch > 65535) return GPK_ERR_ARG(3);
+    dim3 g((unsigned)t, (unsigned)t, (unsigned)batch);
+    hipLaunchKernelGGL((symmetrize_kernel<T>), g, dim3(256), 0, stream, A, n, ld, sA);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
 
 template <typename T>
 int gpk_logdet_launch(const T* L, int64_t n, int64_t ld, int64_t sL, int64_t batch, T* out,
@@ -231,6 +291,9 @@ int gpk_set_identity_launch(T* dst, int64_t n, int64_t ld, int64_t sd, int64_t b
 }
 
 #define GPK_INST(T)                                                                                  \
+    template int gpk_scale_cols_launch<T>(T*, int64_t, int64_t, int64_t, int64_t, const T*, int64_t, \
+                                          int64_t, hipStream_t);                                     \
+    template int gpk_symmetrize_launch<T>(T*, int64_t, int64_t, int64_t, int64_t, hipStream_t);      \
     template int gpk_logdet_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, T*, hipStream_t); \
     template int gpk_colreduce_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,     \
                                          int64_t, T*, T*, T*, int64_t, hipStream_t);                 \

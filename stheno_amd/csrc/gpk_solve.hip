@@ -81,59 +81,76 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs<T> p) {
     const T* __restrict__ x = p.x + b * p.sx;
     T* __restrict__ y = p.y + b * p.sy;
 
-    for (int idx = tid; idx < p.K * NR; idx += 256) {
-        const int k = idx / NR, c = idx % NR;
-        xs[idx] = (c < p.nrhs) ? x[(int64_t)k * p.ldx + c] : T(0);
-    }
-    __syncthreads();
-
-    // prefix copy (only the first workgroups have such rows)
-    if (p.ycopy != nullptr) {
-        T* __restrict__ yc = p.ycopy + b * p.sy;
-        for (int64_t idx = (int64_t)blockIdx.x * 256 + tid; idx < p.ncopy * p.nrhs;
-             idx += (int64_t)gridDim.x * 256) {
-            const int64_t i = idx / p.nrhs;
-            const int c = (int)(idx % p.nrhs);
-            yc[i * p.ldy + c] = xs[i * NR + c];
-        }
-    }
-
     const int row0 = blockIdx.x * GEMV_ROWS;
-    for (int rr = wave; rr < GEMV_ROWS; rr += 4) {
-        const int row = row0 + rr;
-        if (row >= p.M) break;
-        const T* __restrict__ a = A + (int64_t)row * p.lda;
-        T acc[NR];
+    constexpr int RPW = GEMV_ROWS / 4;   // rows per wave: wave, wave + 4, ...
+    T acc[RPW][NR];
 #pragma unroll
-        for (int c = 0; c < NR; ++c) acc[c] = T(0);
-        if (p.vec_ok) {
-            for (int k = lane * VEC; k < p.K; k += 64 * VEC) {
-                const vec_t av = *reinterpret_cast<const vec_t*>(a + k);
+    for (int q = 0; q < RPW; ++q)
 #pragma unroll
-                for (int v = 0; v < VEC; ++v)
-#pragma unroll
-                    for (int c = 0; c < NR; ++c) acc[c] += av[v] * xs[(k + v) * NR + c];
-            }
-        } else {
-            for (int k = lane; k < p.K; k += 64) {
-                const T av = a[k];
-#pragma unroll
-                for (int c = 0; c < NR; ++c) acc[c] += av * xs[k * NR + c];
+        for (int c = 0; c < NR; ++c) acc[q][c] = T(0);
+
+    for (int kc = 0; kc < p.K || kc == 0; kc += GEMV_MAXK) {
+        const int kb = (p.K - kc < GEMV_MAXK) ? p.K - kc : GEMV_MAXK;
+        __syncthreads();
+        for (int idx = tid; idx < kb * NR; idx += 256) {
+            const int k = idx / NR, c = idx % NR;
+            xs[idx] = (c < p.nrhs) ? x[(int64_t)(kc + k) * p.ldx + c] : T(0);
+        }
+        __syncthreads();
+
+        // prefix copy (rows of x written back to ycopy; x must fit one chunk)
+        if (p.ycopy != nullptr && kc == 0) {
+            T* __restrict__ yc = p.ycopy + b * p.sy;
+            for (int64_t idx = (int64_t)blockIdx.x * 256 + tid; idx < p.ncopy * p.nrhs;
+                 idx += (int64_t)gridDim.x * 256) {
+                const int64_t i = idx / p.nrhs;
+                const int c = (int)(idx % p.nrhs);
+                yc[i * p.ldy + c] = xs[i * NR + c];
             }
         }
+
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int row = row0 + wave + 4 * q;
+            if (row < p.M) {
+                const T* __restrict__ a = A + (int64_t)row * p.lda + kc;
+                if (p.vec_ok) {
+                    for (int k = lane * VEC; k < kb; k += 64 * VEC) {
+                        const vec_t av = *reinterpret_cast<const vec_t*>(a + k);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) acc[q][c] += av[v] * xs[(k + v) * NR + c];
+                    }
+                } else {
+                    for (int k = lane; k < kb; k += 64) {
+                        const T av = a[k];
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) acc[q][c] += av * xs[k * NR + c];
+                    }
+                }
+            }
+        }
+        if (p.K == 0) break;
+    }
+
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int row = row0 + wave + 4 * q;
+        if (row >= p.M) continue;
 #pragma unroll
         for (int c = 0; c < NR; ++c) {
-            T v = acc[c];
+            T v = acc[q][c];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            acc[c] = v;
+            acc[q][c] = v;
         }
         if (lane == 0) {
 #pragma unroll
             for (int c = 0; c < NR; ++c) {
                 if (c < p.nrhs) {
                     T* yp = y + (int64_t)row * p.ldy + c;
-                    T r = p.alpha * acc[c];
+                    T r = p.alpha * acc[q][c];
                     if (p.beta != T(0)) r += p.beta * (*yp);
                     *yp = r;
                 }
@@ -146,8 +163,10 @@ template <typename T>
 int gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda, int64_t sA,
                 const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy, T* ycopy,
                 int64_t ncopy, int64_t batch, hipStream_t stream) {
-    if (K > GEMV_MAXK || nrhs > 8 || nrhs < 1) return GPK_ERR_ARG(2);
+    if (nrhs > 8 || nrhs < 1) return GPK_ERR_ARG(3);
+    if (ycopy != nullptr && K > GEMV_MAXK) return GPK_ERR_ARG(2);
     if (M <= 0 && ncopy <= 0) return GPK_OK;
+    if (batch > 65535) return GPK_ERR_ARG(17);
     constexpr int VEC = Traits<T>::VEC;
     GemvArgs<T> g;
     g.A = A; g.lda = lda; g.sA = sA;
@@ -173,6 +192,16 @@ int gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda
 }
 
 }  // namespace
+
+// y[M x nrhs] = alpha * A[M x K] x[K x nrhs] + beta * y, nrhs <= 8, A row-major (k contiguous)
+template <typename T>
+int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda, int64_t sA,
+                    const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy,
+                    int64_t batch, hipStream_t stream) {
+    if (M > INT32_MAX || K > INT32_MAX) return GPK_ERR_ARG(1);
+    return gemv_launch<T>(M, K, nrhs, alpha, A, lda, sA, x, ldx, sx, beta, y, ldy, sy, (T*)nullptr, 0, batch,
+                          stream);
+}
 
 // ---------------------------------------------------------------------------
 // merge inv(L_cc) 128-blocks into inverses of SB x SB diagonal blocks
@@ -302,6 +331,8 @@ int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv
 }
 
 #define GPK_INST(T)                                                                                 \
+    template int gpk_gemv_launch<T>(int64_t, int64_t, int, T, const T*, int64_t, int64_t, const T*,  \
+                                    int64_t, int64_t, T, T*, int64_t, int64_t, int64_t, hipStream_t); \
     template int gpk_trtri_merge_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,  \
                                            int, T*, T*, hipStream_t);                               \
     template int gpk_trsm_launch<T>(const T*, int64_t, int64_t, int64_t, const T*, int, T*, int64_t, \

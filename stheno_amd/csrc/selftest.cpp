@@ -520,9 +520,63 @@ static void perf() {
     }
 }
 
+// one problem, for rocprofv3: kmat + potrf (+ trsv, merge, trsm) at order n
+template <typename T>
+static void profile_one(int n, int nbo, int reps) {
+    const int d = 8, nrhs = 2048, sb = 512;
+    auto hx = randv<T>((size_t)n * d);
+    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n)), y(n), tmp((size_t)sb * nrhs);
+    Dev<T> dsb((size_t)((n + sb - 1) / sb) * sb * sb), tmpm((size_t)((n + sb - 1) / sb) * sb * sb / 4 + 16), Bm((size_t)n * nrhs);
+    Dev<int> info(1);
+    X.up(hx);
+    y.up(randv<T>(n));
+    Bm.up(randv<T>((size_t)n * nrhs));
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    Timer tm;
+    for (int rep = 0; rep < reps; ++rep) {
+        info.zero();
+        gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+        tm.start();
+        gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, nbo, nullptr);
+        const float ms = tm.stop();
+        printf("PROFILE potrf_%s n=%d nbo=%d %.3f ms %.2f TFLOP/s\n", DT<T>::name(), n, nbo, ms, (double)n * n * n / 3.0 / ms * 1e-9);
+        gpk_trsv_lower(DT<T>::v, K.p, n, n, 0, dinv.p, 128, y.p, 1, 1, 0, tmp.p, 1, nullptr);
+        gpk_trtri_merge(DT<T>::v, K.p, n, n, 0, 1, dinv.p, sb, dsb.p, tmpm.p, nullptr);
+        gpk_trsm_lower(DT<T>::v, K.p, n, n, 0, dsb.p, sb, Bm.p, nrhs, nrhs, 0, tmp.p, 1, nullptr);
+        HIPCHK(hipDeviceSynchronize());
+    }
+}
+
+extern "C" void gpk_debug_diag_prof(long long* dev_buf);
+template <typename T>
+static void diag_phase_profile(int n) {
+    const int nblk = (n + 127) / 128;
+    Dev<long long> prof((size_t)nblk * 8);
+    prof.zero();
+    gpk_debug_diag_prof(prof.p);
+    profile_one<T>(n, 0, 1);
+    gpk_debug_diag_prof(nullptr);
+    auto h = prof.down();
+    for (int blk : {0, nblk / 2, nblk - 1}) {
+        printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld  storeL %lld  invert %lld  storeW %lld  total %lld\n", DT<T>::name(), blk,
+               h[blk * 8 + 1] - h[blk * 8 + 0], h[blk * 8 + 2] - h[blk * 8 + 1], h[blk * 8 + 3] - h[blk * 8 + 2],
+               h[blk * 8 + 4] - h[blk * 8 + 3], h[blk * 8 + 5] - h[blk * 8 + 4], h[blk * 8 + 5] - h[blk * 8 + 0]);
+    }
+}
+
 int main(int argc, char** argv) {
     bool do_perf = false, only_perf = false;
     for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
+            diag_phase_profile<double>(atoi(argv[i + 1]));
+            diag_phase_profile<float>(atoi(argv[i + 1]));
+            return 0;
+        }
+        if (!strcmp(argv[i], "--profile") && i + 3 < argc) {   // --profile f64|f32 N NBO
+            const int n = atoi(argv[i + 2]), nbo = atoi(argv[i + 3]);
+            if (!strcmp(argv[i + 1], "f64")) profile_one<double>(n, nbo, 2); else profile_one<float>(n, nbo, 2);
+            return 0;
+        }
         if (!strcmp(argv[i], "--perf")) do_perf = true;
         if (!strcmp(argv[i], "--only-perf")) do_perf = only_perf = true;
     }

@@ -1,0 +1,353 @@
+"""Tensor-level ops of the GP hot path, backed by ``libgpk.so`` (HIP, gfx950).
+
+Every function takes/returns ``torch.Tensor`` objects that live on a HIP device; the
+tensors provide memory and the stream, ``libgpk.so`` does the arithmetic.  There is
+no CPU implementation in this package: calling an op with a CPU tensor, or without
+the built extension, raises.
+
+``set_backend`` exists so that the host-side model logic can be unit-tested on a
+machine without a GPU by injecting a checker backend from ``tests/`` (see
+``tests/conftest.py``); nothing in the package ever installs another backend.
+"""
+import ctypes
+
+import torch
+
+from . import _native
+
+__all__ = ["get_backend", "set_backend", "HipBackend", "KTerms"]
+
+_KIND_IDS = {
+    "eq": _native.K_EQ,
+    "matern12": _native.K_MATERN12,
+    "matern32": _native.K_MATERN32,
+    "matern52": _native.K_MATERN52,
+    "linear": _native.K_LINEAR,
+    "const": _native.K_CONST,
+}
+
+
+class KTerms:
+    """A kernel as a sum of ``variance * kind(. / scale)`` terms (host-side descriptor)."""
+
+    def __init__(self, terms):
+        terms = list(terms)
+        if len(terms) > _native.MAX_TERMS:
+            raise ValueError(f"at most {_native.MAX_TERMS} kernel terms are supported")
+        self.terms = [(str(k), float(v), float(s)) for k, v, s in terms]
+        for k, _, s in self.terms:
+            if k not in _KIND_IDS:
+                raise ValueError(f"unknown kernel kind {k!r}")
+            if not s > 0:
+                raise ValueError("length scales must be positive")
+
+    def __len__(self):
+        return len(self.terms)
+
+    def c_arrays(self):
+        n = len(self.terms)
+        kinds = (ctypes.c_int * max(n, 1))(*[_KIND_IDS[k] for k, _, _ in self.terms])
+        var = (ctypes.c_double * max(n, 1))(*[v for _, v, _ in self.terms])
+        ils = (ctypes.c_double * max(n, 1))(*[1.0 / s for _, _, s in self.terms])
+        return kinds, var, ils, n
+
+
+def _dtype_id(t):
+    if t.dtype == torch.float64:
+        return _native.GPK_F64
+    if t.dtype == torch.float32:
+        return _native.GPK_F32
+    raise TypeError(f"stheno_amd supports float32/float64 tensors, got {t.dtype}")
+
+
+def _as3(t):
+    """View a (..., R, C) tensor as (B, R, C) with unit inner stride; returns (t3, batch_shape)."""
+    if t.dim() < 2:
+        raise ValueError("expected a matrix")
+    bshape = tuple(t.shape[:-2])
+    if t.stride(-1) != 1 and t.shape[-1] > 1:
+        t = t.contiguous()
+    if t.dim() == 2:
+        return t.unsqueeze(0), bshape
+    if t.dim() > 3:
+        t = t.reshape(-1, t.shape[-2], t.shape[-1])
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(-1) != 1:
+        t = t.contiguous()
+    return t, bshape
+
+
+def _ld(t3):
+    # leading dimension of the (R, C) slices of a (B, R, C) tensor
+    return t3.stride(1) if t3.shape[1] > 1 else max(t3.shape[2], 1)
+
+
+def _bs(t3):
+    return t3.stride(0) if t3.shape[0] > 1 else 0
+
+
+class HipBackend:
+    """ctypes calls into ``libgpk.so`` on the current torch HIP stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _native.load()
+
+    # -- helpers -------------------------------------------------------------
+    @staticmethod
+    def _check(*tensors):
+        for t in tensors:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise RuntimeError(
+                    "stheno_amd ops run on a HIP device only (got a CPU tensor); "
+                    "there is no CPU fallback in this package"
+                )
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _ptr(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+    @staticmethod
+    def _st(code, what):
+        if code != 0:
+            raise RuntimeError(f"libgpk {what} failed with status {code}")
+
+    # -- kernel matrices -----------------------------------------------------
+    def kmat(self, terms, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, out=None, accumulate=False):
+        """``out[b, i, j] (+)= k(x[b, i], y[b, j])``; ``y is None`` means the symmetric case
+        (then ``diag_add`` / ``diag_vec`` go on the diagonal)."""
+        symmetric = y is None
+        x3, bshape = _as3(x)
+        y3 = x3 if symmetric else _as3(y)[0]
+        self._check(x3, y3, diag_vec, out)
+        B, n, d = x3.shape
+        m = y3.shape[1]
+        if y3.shape[0] != B or y3.shape[2] != d:
+            raise ValueError("x and y must agree in batch size and input dimension")
+        if out is None:
+            out = torch.empty(bshape + (n, m), dtype=x.dtype, device=x.device)
+        o3, _ = _as3(out)
+        dv = None
+        if diag_vec is not None:
+            dv = diag_vec.reshape(B, n).contiguous()
+        kinds, var, ils, nt = terms.c_arrays()
+        code = self.lib.gpk_kmat(
+            _dtype_id(x3), kinds, var, ils, nt, self._ptr(x3), n, _ld(x3), _bs(x3), self._ptr(y3), m, _ld(y3),
+            _bs(y3), d, self._ptr(o3), _ld(o3), _bs(o3), B, int(lower), int(symmetric), float(diag_add),
+            self._ptr(dv), n if dv is not None else 0, int(accumulate), self._stream(),
+        )
+        self._st(code, "gpk_kmat")
+        return out
+
+    def kdiag(self, terms, x):
+        x3, bshape = _as3(x)
+        self._check(x3)
+        B, n, d = x3.shape
+        out = torch.empty(bshape + (n,), dtype=x.dtype, device=x.device)
+        kinds, var, ils, nt = terms.c_arrays()
+        code = self.lib.gpk_kdiag(_dtype_id(x3), kinds, var, ils, nt, self._ptr(x3), n, _ld(x3), _bs(x3), d,
+                                  self._ptr(out), n, B, self._stream())
+        self._st(code, "gpk_kdiag")
+        return out
+
+    # -- factorisation -------------------------------------------------------
+    def potrf_(self, a, nbo=0):
+        """In-place lower Cholesky of ``a`` (..., n, n).  Returns ``(dinv, info)``."""
+        a3, _ = _as3(a)
+        if a3.data_ptr() != a.data_ptr():
+            raise ValueError("potrf_ needs a tensor with unit inner stride (it factorises in place)")
+        self._check(a3)
+        B, n, _ = a3.shape
+        nblk = (max(n, 1) + 127) // 128
+        dinv = torch.empty((B, nblk, 128, 128), dtype=a.dtype, device=a.device)
+        info = torch.zeros((B,), dtype=torch.int32, device=a.device)
+        code = self.lib.gpk_potrf(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._ptr(dinv),
+                                  self._ptr(info), int(nbo), self._stream())
+        self._st(code, "gpk_potrf")
+        return dinv, info
+
+    def trtri_merge(self, l, dinv, sb):
+        l3, _ = _as3(l)
+        self._check(l3, dinv)
+        B, n, _ = l3.shape
+        nsb = (n + sb - 1) // sb
+        dsb = torch.empty((B, nsb, sb, sb), dtype=l.dtype, device=l.device)
+        tmp = torch.empty((nsb * sb * sb // 4 + 16,), dtype=l.dtype, device=l.device)
+        code = self.lib.gpk_trtri_merge(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), B, self._ptr(dinv), sb,
+                                        self._ptr(dsb), self._ptr(tmp), self._stream())
+        self._st(code, "gpk_trtri_merge")
+        return dsb
+
+    def tri_solve_(self, l, dinv_sb, sb, b):
+        """``b <- L^{-1} b`` in place; ``b`` is (..., n, nrhs) with unit inner stride."""
+        l3, _ = _as3(l)
+        b3, _ = _as3(b)
+        if b3.data_ptr() != b.data_ptr():
+            raise ValueError("tri_solve_ needs a right-hand side with unit inner stride")
+        self._check(l3, b3, dinv_sb)
+        B, n, _ = l3.shape
+        nrhs = b3.shape[2]
+        if b3.shape[0] != B or b3.shape[1] != n:
+            raise ValueError("right-hand side does not match the factor")
+        if n == 0 or nrhs == 0:
+            return b
+        tmp = torch.empty((B, sb, nrhs), dtype=b.dtype, device=b.device)
+        if nrhs <= 8:
+            code = self.lib.gpk_trsv_lower(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), self._ptr(dinv_sb), sb,
+                                           self._ptr(b3), nrhs, _ld(b3), _bs(b3), self._ptr(tmp), B, self._stream())
+            self._st(code, "gpk_trsv_lower")
+        else:
+            code = self.lib.gpk_trsm_lower(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), self._ptr(dinv_sb), sb,
+                                           self._ptr(b3), nrhs, _ld(b3), _bs(b3), self._ptr(tmp), B, self._stream())
+            self._st(code, "gpk_trsm_lower")
+        return b
+
+    # -- products ------------------------------------------------------------
+    def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False):
+        """``out[m, n] = alpha * sum_k a(m, k) b(n, k) + beta * out``.
+
+        ``a_kmajor``: ``a`` is stored (M, K); otherwise (K, M).  ``b_kmajor``: ``b`` is stored
+        (N, K); otherwise (K, N)."""
+        a3, bshape = _as3(a)
+        b3, _ = _as3(b)
+        self._check(a3, b3, out)
+        B = max(a3.shape[0], b3.shape[0])
+        M, K = (a3.shape[1], a3.shape[2]) if a_kmajor else (a3.shape[2], a3.shape[1])
+        N, K2 = (b3.shape[1], b3.shape[2]) if b_kmajor else (b3.shape[2], b3.shape[1])
+        if K != K2:
+            raise ValueError("inner dimensions do not match")
+        if out is None:
+            if beta != 0.0:
+                raise ValueError("beta != 0 requires `out`")
+            shape = (bshape if a3.shape[0] >= b3.shape[0] else tuple(b.shape[:-2])) + (M, N)
+            out = torch.empty(shape, dtype=a.dtype, device=a.device)
+        o3, _ = _as3(out)
+        code = self.lib.gpk_gemm(_dtype_id(a3), int(a_kmajor), int(b_kmajor), M, N, K, float(alpha), self._ptr(a3),
+                                 _ld(a3), _bs(a3), self._ptr(b3), _ld(b3), _bs(b3), float(beta), self._ptr(o3),
+                                 _ld(o3), _bs(o3), B, int(lower_only), self._stream())
+        self._st(code, "gpk_gemm")
+        return out
+
+    def gemv(self, a, x, *, alpha=1.0, beta=0.0, out=None):
+        """``out = alpha * a @ x + beta * out`` for (..., M, K) @ (..., K, nrhs <= 8)."""
+        a3, bshape = _as3(a)
+        x3, _ = _as3(x)
+        self._check(a3, x3, out)
+        B, M, K = a3.shape
+        nrhs = x3.shape[2]
+        if out is None:
+            out = torch.empty(bshape + (M, nrhs), dtype=a.dtype, device=a.device)
+        o3, _ = _as3(out)
+        code = self.lib.gpk_gemv(_dtype_id(a3), 0, M, K, nrhs, float(alpha), self._ptr(a3), _ld(a3), _bs(a3),
+                                 self._ptr(x3), _ld(x3), _bs(x3), float(beta), self._ptr(o3), _ld(o3), _bs(o3), B,
+                                 self._stream())
+        self._st(code, "gpk_gemv")
+        return out
+
+    # -- reductions ----------------------------------------------------------
+    def logdet_chol(self, l):
+        l3, bshape = _as3(l)
+        self._check(l3)
+        B, n, _ = l3.shape
+        out = torch.empty((B,), dtype=l.dtype, device=l.device)
+        code = self.lib.gpk_logdet_chol(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), B, self._ptr(out),
+                                        self._stream())
+        self._st(code, "gpk_logdet_chol")
+        return out.reshape(bshape)
+
+    def colreduce(self, v, w=None, *, want_dot=False, want_ss=True):
+        """Column reductions of ``v`` (..., R, C): ``(v^T w, colsumsq(v))`` (``None`` for the
+        one not requested).  ``w``: (..., R) or (..., R, 1)."""
+        v3, bshape = _as3(v)
+        self._check(v3, w)
+        B, R, C = v3.shape
+        dot = ss = None
+        w2 = None
+        if want_dot:
+            if w is None:
+                raise ValueError("want_dot needs w")
+            w2 = w.reshape(B, R).contiguous()
+            dot = torch.empty((B, C), dtype=v.dtype, device=v.device)
+        if want_ss:
+            ss = torch.empty((B, C), dtype=v.dtype, device=v.device)
+        nchunk = int(self.lib.gpk_colreduce_chunks(R))
+        ws = torch.empty((2 * B * nchunk * max(C, 1),), dtype=v.dtype, device=v.device)
+        code = self.lib.gpk_colreduce(_dtype_id(v3), self._ptr(v3), R, C, _ld(v3), _bs(v3), self._ptr(w2), R,
+                                      self._ptr(dot), self._ptr(ss), self._ptr(ws), B, self._stream())
+        self._st(code, "gpk_colreduce")
+        if dot is not None:
+            dot = dot.reshape(bshape + (C,))
+        if ss is not None:
+            ss = ss.reshape(bshape + (C,))
+        return dot, ss
+
+    # -- in-place odds and ends ------------------------------------------------
+    def tril_(self, a):
+        a3, _ = _as3(a)
+        self._check(a3)
+        B, n, _ = a3.shape
+        self._st(self.lib.gpk_tril(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._stream()), "gpk_tril")
+        return a
+
+    def symmetrize_(self, a):
+        a3, _ = _as3(a)
+        self._check(a3)
+        B, n, _ = a3.shape
+        self._st(self.lib.gpk_symmetrize(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._stream()),
+                 "gpk_symmetrize")
+        return a
+
+    def add_diag_(self, a, s=0.0, v=None):
+        a3, _ = _as3(a)
+        self._check(a3, v)
+        B, n, _ = a3.shape
+        v2 = v.reshape(B, n).contiguous() if v is not None else None
+        self._st(self.lib.gpk_add_diag(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), float(s), self._ptr(v2),
+                                       n if v2 is not None else 0, B, self._stream()), "gpk_add_diag")
+        return a
+
+    def scale_cols_(self, v, s):
+        v3, _ = _as3(v)
+        self._check(v3, s)
+        B, R, C = v3.shape
+        s2 = s.reshape(B, C).contiguous()
+        self._st(self.lib.gpk_scale_cols(_dtype_id(v3), self._ptr(v3), R, C, _ld(v3), _bs(v3), self._ptr(s2), C, B,
+                                         self._stream()), "gpk_scale_cols")
+        return v
+
+    def copy(self, src):
+        """Fresh contiguous copy of a (..., R, C) tensor (strided 2-D copy kernel)."""
+        s3, bshape = _as3(src)
+        self._check(s3)
+        B, R, C = s3.shape
+        out = torch.empty(bshape + (R, C), dtype=src.dtype, device=src.device)
+        o3, _ = _as3(out)
+        self._st(self.lib.gpk_copy2d(_dtype_id(s3), self._ptr(s3), _ld(s3), _bs(s3), self._ptr(o3), _ld(o3), _bs(o3),
+                                     R, C, B, self._stream()), "gpk_copy2d")
+        return out
+
+
+_backend = None
+
+
+def get_backend():
+    """The op backend; instantiates :class:`HipBackend` on first use (raises if
+    ``libgpk.so`` is not built)."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(backend):
+    """Install an op backend.  TEST HOOK ONLY (host-logic unit tests without a GPU);
+    returns the previous backend."""
+    global _backend
+    prev, _backend = _backend, backend
+    return prev
