@@ -151,6 +151,15 @@ int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha,
              int64_t sa, const void* x, int64_t ldx, int64_t sx, double beta, void* y, int64_t ldy, int64_t sy,
              int64_t batch, void* stream);
 
+/* Measurement hooks (bench.py's live roofline figure).  Between gpk_prof_start and
+ * gpk_prof_stop every MFMA GEMM launch of this process is bracketed by HIP events on its
+ * launch stream; gpk_prof_stop synchronises those events and returns the summed duration,
+ * launch count and ALGORITHMIC flops (2mnk; mnk for a lower-only symmetric update) of the
+ * launches of one kernel variant: 8*(f64) + 4*(a_kmajor) + 2*(b_kmajor) + 1*(bounds-checked
+ * kernel), or -1 for all.  Not thread-safe; off by default; not used by the product path. */
+int gpk_prof_start(void);
+int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops);
+
 /* Strided 2-D copy (rows x cols). */
 int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, int64_t ldd, int64_t sd,
                int64_t rows, int64_t cols, int64_t batch, void* stream);

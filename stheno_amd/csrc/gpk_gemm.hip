@@ -30,6 +30,7 @@
 //  * accumulators are initialised with C * (beta / alpha) so the epilogue is a
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
+#include <vector>
 
 namespace {
 
@@ -281,7 +282,61 @@ void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, cons
         hipLaunchKernelGGL((gemm_kernel<T, false, false, EDGE>), grid, dim3(256), 0, stream, args);
 }
 
+// ---- measurement hook: HIP events around every GEMM launch (opt-in, see gpk.h) ----
+struct ProfSlot {
+    hipEvent_t a, b;
+    int variant;
+    double flops;
+};
+struct Prof {
+    bool on = false;
+    std::vector<ProfSlot> used, pool;
+    ProfSlot* begin(int variant, double flops, hipStream_t stream) {
+        ProfSlot s;
+        if (!pool.empty()) {
+            s = pool.back();
+            pool.pop_back();
+        } else {
+            if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return nullptr;
+        }
+        s.variant = variant;
+        s.flops = flops;
+        (void)hipEventRecord(s.a, stream);
+        used.push_back(s);
+        return &used.back();
+    }
+    void end(ProfSlot* s, hipStream_t stream) { (void)hipEventRecord(s->b, stream); }
+};
+Prof g_prof;
+
 }  // namespace
+
+extern "C" int gpk_prof_start(void) {
+    for (auto& s : g_prof.used) g_prof.pool.push_back(s);
+    g_prof.used.clear();
+    g_prof.on = true;
+    return GPK_OK;
+}
+
+// variant: 8*(f64) + 4*(A k-major) + 2*(B k-major) + 1*(edge-checked kernel), or -1 for all
+extern "C" int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops) {
+    g_prof.on = false;
+    double ms = 0, fl = 0;
+    int64_t n = 0;
+    for (auto& s : g_prof.used) {
+        if (hipEventSynchronize(s.b) != hipSuccess) return GPK_ERR_LAUNCH;
+        if (variant >= 0 && s.variant != variant) continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) return GPK_ERR_LAUNCH;
+        ms += t;
+        fl += s.flops;
+        ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (useful_flops) *useful_flops = fl;
+    return GPK_OK;
+}
 
 template <typename T>
 int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
@@ -330,10 +385,17 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool edge = !aligned || (M % GPK_TILE) || (N % GPK_TILE) || (K % BK);
 
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
+    ProfSlot* slot = nullptr;
+    if (g_prof.on) {
+        // useful (algorithmic) flops: a lower-only update counts the symmetric half
+        const double fl = (lower_only ? 1.0 : 2.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
+        slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0), fl, stream);
+    }
     if (edge)
         launch_layout<T, true>(a_kmaj, b_kmaj, grid, stream, g);
     else
         launch_layout<T, false>(a_kmaj, b_kmaj, grid, stream, g);
+    if (slot) g_prof.end(slot, stream);
     GPK_CHECK_LAUNCH();
     return GPK_OK;
 }

@@ -1,0 +1,498 @@
+"""Kernels and means on the GP hot path -- the slice of the reference's ``mlkernels``
+dependency that ``stheno/model/*.py`` uses:
+
+* primitives ``EQ``, ``Exp``/``Matern12``, ``Matern32``, ``Matern52``, ``Linear``,
+  ``OneKernel``, ``ZeroKernel`` with the ``v * k``, ``k1 + k2``, ``k.stretch(l)`` algebra
+  (usage: ``readme_example13_optimisation_torch.py:34``, ``tests/model/test_cases.py:138``);
+* ``pairwise`` (``k(x, y)``) and ``elwise`` (``k.elwise(x)``) evaluation -- one fused HIP
+  kernel launch per call for any sum of primitives (``gpk_kmat`` / ``gpk_kdiag``);
+* ``PosteriorKernel``, ``PosteriorMean``, ``SubspaceKernel`` (constructed at
+  ``stheno/model/observations.py:148-168,256-277``) and ``mean_var`` / ``mean_var_diag``
+  (``stheno/model/fdd.py:69,73``), which share one ``L^{-1} k(z, x)`` between the mean and
+  the variance and never form the N* x N* covariance for marginals.
+
+Inputs follow the reference's conventions: ``(N,)`` -> ``(N, 1)``; ``(N, D)``;
+``(B, N, D)`` batched.
+"""
+import torch
+
+from . import ops
+from .matrix import Chol, Dense, KernelDense
+
+__all__ = [
+    "Kernel", "EQ", "Exp", "Matern12", "Matern32", "Matern52", "Linear", "OneKernel", "ZeroKernel",
+    "Mean", "ZeroMean", "OneMean", "PosteriorKernel", "PosteriorMean", "SubspaceKernel",
+    "mean_var", "mean_var_diag", "uprank", "num_elements",
+]
+
+
+def uprank(x):
+    """``B.uprank``: scalars and vectors become column matrices."""
+    if not torch.is_tensor(x):
+        x = torch.as_tensor(x)
+    if x.dim() == 0:
+        return x.reshape(1, 1)
+    if x.dim() == 1:
+        return x[:, None]
+    return x
+
+
+def num_elements(x):
+    """``mlkernels.num_elements``: number of inputs (rows)."""
+    x = uprank(x)
+    return x.shape[-2]
+
+
+def _as_float(v):
+    if torch.is_tensor(v):
+        if v.numel() != 1:
+            raise ValueError("kernel hyper-parameters must be scalars")
+        return float(v)
+    return float(v)
+
+
+# ---------------------------------------------------------------------------
+# kernels
+# ---------------------------------------------------------------------------
+class Kernel:
+    """Base class.  A kernel that is a sum of stretched/scaled primitives exposes it as
+    ``terms()`` -> list of ``(kind, variance, scale)``; other kernels override
+    ``pairwise`` / ``elwise``."""
+
+    stationary = False
+
+    def terms(self):
+        return None
+
+    def num_outputs(self, x):
+        return num_elements(x)
+
+    # -- evaluation ------------------------------------------------------------
+    def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None):
+        """``k(x, y)`` as a tensor (..., N, M); ``y is None``: symmetric case, where
+        ``diag_add`` / ``diag_vec`` are added to the diagonal in the same pass."""
+        t = self.terms()
+        if t is None:
+            raise NotImplementedError(f"pairwise evaluation is not implemented for {type(self).__name__}")
+        x = uprank(x)
+        y = None if y is None else uprank(y)
+        return ops.get_backend().kmat(ops.KTerms(t), x, y, lower=lower, diag_add=diag_add, diag_vec=diag_vec)
+
+    def elwise(self, x, y=None, *, cache=None):
+        """``k(x_i, x_i)`` as a column (..., N, 1)."""
+        if y is not None and y is not x:
+            raise NotImplementedError("elwise is implemented for identical inputs")
+        t = self.terms()
+        if t is None:
+            raise NotImplementedError(f"elwise evaluation is not implemented for {type(self).__name__}")
+        return ops.get_backend().kdiag(ops.KTerms(t), uprank(x))[..., None]
+
+    def __call__(self, x, y=None):
+        """``k(x)`` / ``k(x, y)`` as a ``Dense`` matrix (lazily materialised for ``k(x)``)."""
+        if y is None:
+            return KernelDense(self, uprank(x), None)
+        return Dense(self.pairwise(x, y))
+
+    # -- algebra ---------------------------------------------------------------
+    def __add__(self, other):
+        if isinstance(other, (int, float)):
+            if other == 0:
+                return self
+            other = other * OneKernel()
+        if isinstance(other, ZeroKernel):
+            return self
+        if isinstance(self, ZeroKernel):
+            return other
+        if not isinstance(other, Kernel):
+            return NotImplemented
+        return Sum(self, other)
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        if isinstance(other, Kernel):
+            raise NotImplementedError("products of kernels are outside the accelerated path")
+        v = _as_float(other)
+        if v == 0:
+            return ZeroKernel()
+        return Scaled(self, v)
+
+    __rmul__ = __mul__
+
+    def stretch(self, scale):
+        return Stretched(self, _as_float(scale))
+
+    def __reversed__(self):
+        return Reversed(self)
+
+    def __eq__(self, other):
+        if isinstance(self, ZeroKernel) and isinstance(other, ZeroKernel):
+            return True
+        return self is other
+
+    def __hash__(self):
+        return id(self)
+
+
+class _Primitive(Kernel):
+    kind = None
+
+    def terms(self):
+        return [(self.kind, 1.0, 1.0)]
+
+    def __repr__(self):
+        return f"{type(self).__name__}()"
+
+
+class EQ(_Primitive):
+    """Exponentiated quadratic ``exp(-r^2 / 2)``."""
+    kind = "eq"
+    stationary = True
+
+
+class Matern12(_Primitive):
+    """Exponential kernel ``exp(-r)``."""
+    kind = "matern12"
+    stationary = True
+
+
+Exp = Matern12
+
+
+class Matern32(_Primitive):
+    kind = "matern32"
+    stationary = True
+
+
+class Matern52(_Primitive):
+    kind = "matern52"
+    stationary = True
+
+
+class Linear(_Primitive):
+    """``<x, y>``."""
+    kind = "linear"
+
+
+class OneKernel(_Primitive):
+    kind = "const"
+    stationary = True
+
+
+class ZeroKernel(Kernel):
+    stationary = True
+
+    def terms(self):
+        return []
+
+    def pairwise(self, x, y=None, **kw):
+        x = uprank(x)
+        y = x if y is None else uprank(y)
+        return torch.zeros(x.shape[:-1] + (y.shape[-2],), dtype=x.dtype, device=x.device)
+
+    def elwise(self, x, y=None, **kw):
+        x = uprank(x)
+        return torch.zeros(x.shape[:-1] + (1,), dtype=x.dtype, device=x.device)
+
+    def __repr__(self):
+        return "0"
+
+
+class Scaled(Kernel):
+    def __init__(self, k, v):
+        self.k, self.v = k, v
+        self.stationary = k.stationary
+
+    def terms(self):
+        t = self.k.terms()
+        return None if t is None else [(kind, var * self.v, s) for kind, var, s in t]
+
+    def pairwise(self, x, y=None, **kw):
+        if self.terms() is not None:
+            return super().pairwise(x, y, **kw)
+        da, dv = kw.pop("diag_add", 0.0), kw.pop("diag_vec", None)
+        out = self.v * self.k.pairwise(x, y, **kw)
+        return _add_diag(out, da, dv) if y is None else out
+
+    def elwise(self, x, y=None, **kw):
+        if self.terms() is not None:
+            return super().elwise(x, y, **kw)
+        return self.v * self.k.elwise(x, y, **kw)
+
+    def __repr__(self):
+        return f"{self.v} * {self.k!r}"
+
+
+class Stretched(Kernel):
+    def __init__(self, k, scale):
+        if k.terms() is None:
+            raise NotImplementedError("stretch is implemented for sums of primitive kernels")
+        self.k, self.scale = k, scale
+        self.stationary = k.stationary
+
+    def terms(self):
+        return [(kind, var, s * self.scale) for kind, var, s in self.k.terms()]
+
+    def __repr__(self):
+        return f"({self.k!r} > {self.scale})"
+
+
+class Sum(Kernel):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.stationary = a.stationary and b.stationary
+
+    def terms(self):
+        ta, tb = self.a.terms(), self.b.terms()
+        if ta is None or tb is None:
+            return None
+        return ta + tb
+
+    def pairwise(self, x, y=None, **kw):
+        if self.terms() is not None:
+            return super().pairwise(x, y, **kw)
+        da, dv = kw.pop("diag_add", 0.0), kw.pop("diag_vec", None)
+        kw.pop("lower", None)
+        out = self.a.pairwise(x, y, **kw) + self.b.pairwise(x, y, **kw)
+        return _add_diag(out, da, dv) if y is None else out
+
+    def elwise(self, x, y=None, **kw):
+        if self.terms() is not None:
+            return super().elwise(x, y, **kw)
+        return self.a.elwise(x, y, **kw) + self.b.elwise(x, y, **kw)
+
+    def __repr__(self):
+        return f"{self.a!r} + {self.b!r}"
+
+
+class Reversed(Kernel):
+    """``reversed(k)(x, y) = k(y, x)^T`` (used for cross-kernels, measure.py:111)."""
+
+    def __init__(self, k):
+        self.k = k
+
+    def terms(self):
+        return self.k.terms()   # sums of primitives are symmetric
+
+    def pairwise(self, x, y=None, **kw):
+        if self.terms() is not None or y is None:
+            return self.k.pairwise(x, y, **kw)
+        return self.k.pairwise(y, x, **kw).transpose(-1, -2)
+
+    def elwise(self, x, y=None, **kw):
+        return self.k.elwise(x, y, **kw)
+
+
+def _add_diag(out, diag_add, diag_vec):
+    if diag_add or diag_vec is not None:
+        ops.get_backend().add_diag_(out, diag_add, diag_vec)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# means
+# ---------------------------------------------------------------------------
+class Mean:
+    def __call__(self, x, cache=None):
+        raise NotImplementedError
+
+    def __add__(self, other):
+        if isinstance(other, (int, float)) and other == 0:
+            return self
+        return SumMean(self, other if isinstance(other, Mean) else _wrap_mean(other))
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        return ScaledMean(self, _as_float(other))
+
+    __rmul__ = __mul__
+
+
+class ZeroMean(Mean):
+    def __call__(self, x, cache=None):
+        x = uprank(x)
+        return torch.zeros(x.shape[:-1] + (1,), dtype=x.dtype, device=x.device)
+
+    def __repr__(self):
+        return "0"
+
+
+class OneMean(Mean):
+    def __call__(self, x, cache=None):
+        x = uprank(x)
+        return torch.ones(x.shape[:-1] + (1,), dtype=x.dtype, device=x.device)
+
+    def __repr__(self):
+        return "1"
+
+
+class FunctionMean(Mean):
+    """Mean given by a Python function of the (upranked) inputs, e.g. ``lambda x: x ** 2``."""
+
+    def __init__(self, f):
+        self.f = f
+
+    def __call__(self, x, cache=None):
+        return uprank(self.f(uprank(x)))
+
+
+class ScaledMean(Mean):
+    def __init__(self, m, v):
+        self.m, self.v = m, v
+
+    def __call__(self, x, cache=None):
+        return self.v * self.m(x, cache)
+
+
+class SumMean(Mean):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def __call__(self, x, cache=None):
+        return self.a(x, cache) + self.b(x, cache)
+
+
+def _wrap_mean(m):
+    if isinstance(m, Mean):
+        return m
+    if callable(m):
+        return FunctionMean(m)
+    v = _as_float(m)
+    return ZeroMean() if v == 0 else ScaledMean(OneMean(), v)
+
+
+# ---------------------------------------------------------------------------
+# posterior objects
+# ---------------------------------------------------------------------------
+def _cross(cache, k, z, x):
+    """Memoised ``k(z, x)`` tensor within one ``mean_var(_diag)`` evaluation: the
+    reference evaluates the data/inducing cross-kernel once per prediction
+    (pinned by ``tests/model/test_model.py:335-365``)."""
+    if cache is None:
+        return k.pairwise(z, x)
+    key = ("kzx", id(k), id(z), id(x))
+    if key not in cache:
+        cache[key] = k.pairwise(z, x)
+    return cache[key]
+
+
+def _whiten(cache, K_z, k, z, x):
+    """``L^{-1} k(z, x)`` (memoised), ``L = chol(K_z)``."""
+    key = ("v", id(K_z), id(k), id(z), id(x))
+    if cache is not None and key in cache:
+        return cache[key]
+    kzx = _cross(cache, k, z, x)
+    v = K_z.chol().solve(kzx)
+    if cache is not None:
+        cache[key] = v
+    return v
+
+
+class PosteriorKernel(Kernel):
+    """``k_ij(x, y) - k_zi(z, x)^T K_z^{-1} k_zj(z, y)`` (mlkernels.PosteriorKernel;
+    constructed at ``observations.py:148-154,256-261``)."""
+
+    def __init__(self, k_ij, k_zi, k_zj, z, K_z):
+        self.k_ij, self.k_zi, self.k_zj, self.z, self.K_z = k_ij, k_zi, k_zj, z, K_z
+
+    def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None):
+        x = uprank(x)
+        sym = y is None
+        y = x if sym else uprank(y)
+        out = self.k_ij.pairwise(x, None if sym else y, cache=cache) if _accepts_cache(self.k_ij) else \
+            self.k_ij.pairwise(x, None if sym else y)
+        vx = _whiten(cache, self.K_z, self.k_zi, self.z, x)
+        vy = vx if (sym and self.k_zi is self.k_zj) else _whiten(cache, self.K_z, self.k_zj, self.z, y)
+        # out -= vx^T vy   (operands stored (K, M) / (K, N): row index contiguous)
+        ops.get_backend().gemm(vx, vy, a_kmajor=False, b_kmajor=False, alpha=-1.0, beta=1.0, out=out)
+        return _add_diag(out, diag_add, diag_vec) if sym else out
+
+    def elwise(self, x, y=None, *, cache=None):
+        x = uprank(x)
+        out = self.k_ij.elwise(x)
+        vx = _whiten(cache, self.K_z, self.k_zi, self.z, x)
+        if self.k_zi is self.k_zj:
+            _, ss = ops.get_backend().colreduce(vx, want_ss=True)
+            return out - ss[..., None]
+        vy = _whiten(cache, self.K_z, self.k_zj, self.z, x)
+        return out - (vx * vy).sum(-2)[..., None]
+
+
+class SubspaceKernel(Kernel):
+    """``k_zi(z, x)^T A^{-1} k_zj(z, y)`` (mlkernels.SubspaceKernel; ``observations.py:262-267``)."""
+
+    def __init__(self, k_zi, k_zj, z, A):
+        self.k_zi, self.k_zj, self.z, self.A = k_zi, k_zj, z, A
+
+    def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None):
+        x = uprank(x)
+        sym = y is None
+        y = x if sym else uprank(y)
+        vx = _whiten(cache, self.A, self.k_zi, self.z, x)
+        vy = vx if (sym and self.k_zi is self.k_zj) else _whiten(cache, self.A, self.k_zj, self.z, y)
+        out = ops.get_backend().gemm(vx, vy, a_kmajor=False, b_kmajor=False)
+        return _add_diag(out, diag_add, diag_vec) if sym else out
+
+    def elwise(self, x, y=None, *, cache=None):
+        x = uprank(x)
+        vx = _whiten(cache, self.A, self.k_zi, self.z, x)
+        if self.k_zi is self.k_zj:
+            _, ss = ops.get_backend().colreduce(vx, want_ss=True)
+            return ss[..., None]
+        vy = _whiten(cache, self.A, self.k_zj, self.z, x)
+        return (vx * vy).sum(-2)[..., None]
+
+
+def _accepts_cache(k):
+    return isinstance(k, (PosteriorKernel, SubspaceKernel, Sum, Scaled, Reversed))
+
+
+class PosteriorMean(Mean):
+    """``m_i(x) + k_zi(z, x)^T K_z^{-1} (y - m_z(z))`` (mlkernels.PosteriorMean;
+    ``observations.py:161-168,270-277``), evaluated as ``(L^{-1} k_zx)^T (L^{-1} (y - m_z(z)))``."""
+
+    def __init__(self, m_i, m_z, k_zi, z, K_z, y):
+        self.m_i, self.m_z, self.k_zi, self.z, self.K_z, self.y = m_i, m_z, k_zi, z, K_z, y
+        self._w = None
+
+    def _whitened_residual(self):
+        if self._w is None:
+            r = uprank(self.y) - self.m_z(self.z)
+            self._w = self.K_z.chol().solve(r)          # (..., N, 1)
+        return self._w
+
+    def __call__(self, x, cache=None):
+        x = uprank(x)
+        v = _whiten(cache, self.K_z, self.k_zi, self.z, x)
+        dot, _ = ops.get_backend().colreduce(v, self._whitened_residual(), want_dot=True, want_ss=False)
+        return self.m_i(x) + dot[..., None]
+
+
+# ---------------------------------------------------------------------------
+# mean_var / mean_var_diag  (fdd.py:68-74)
+# ---------------------------------------------------------------------------
+def _call_mean(mean, x, cache):
+    return mean(x, cache) if isinstance(mean, Mean) else mean(x)
+
+
+def mean_var(mean, kernel, x):
+    """Mean and variance sharing the cross-kernel evaluations."""
+    cache = {}
+    x = uprank(x)
+    m = _call_mean(mean, x, cache)
+    if _accepts_cache(kernel):
+        var = Dense(kernel.pairwise(x, None, cache=cache))
+    else:
+        var = KernelDense(kernel, x, None)
+    return m, var
+
+
+def mean_var_diag(mean, kernel, x):
+    """Mean and marginal variances without forming the covariance
+    (``tests/model/test_gp.py:201-211``)."""
+    cache = {}
+    x = uprank(x)
+    m = _call_mean(mean, x, cache)
+    vd = kernel.elwise(x, cache=cache) if _accepts_cache(kernel) else kernel.elwise(x)
+    return m, vd

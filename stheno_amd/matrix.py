@@ -1,0 +1,355 @@
+"""Structured matrices for the GP path: ``Dense`` (with a cached Cholesky), ``Diagonal``,
+``Zero`` -- the slice of the reference's ``matrix`` dependency (PyPI ``backends-matrix``)
+that ``stheno/random.py`` and ``stheno/model/*.py`` touch -- plus ``KernelDense``, a
+kernel matrix that can be factorised without ever being materialised next to its factor.
+
+All heavy lifting goes through :mod:`stheno_amd.ops` (HIP kernels).
+"""
+import math
+
+import torch
+
+from . import ops
+
+__all__ = ["AbstractMatrix", "Dense", "Diagonal", "Zero", "KernelDense", "Chol", "config"]
+
+
+class _Config:
+    """Global knobs.  ``epsilon`` mirrors ``lab``'s ``B.epsilon`` (README.md:820-831):
+    the diagonal jitter added before every Cholesky."""
+
+    epsilon = 1e-12
+    #: raise ``torch.linalg.LinAlgError`` for non-positive-definite matrices (costs one
+    #: 4-byte device->host read per factorisation)
+    check_info = True
+    #: outer block of the blocked Cholesky (0 = library default)
+    potrf_nbo = 0
+
+
+config = _Config()
+
+
+def _solve_block(n):
+    """Diagonal-block size used by the many-right-hand-side triangular solve."""
+    if n >= 2048:
+        return 512
+    if n >= 512:
+        return 256
+    return 128
+
+
+class Chol:
+    """Lower Cholesky factor ``L`` (possibly batched) with the diagonal-block inverses
+    the HIP solve kernels use.  ``L``'s strict upper triangle is unspecified until
+    :meth:`lower` is called."""
+
+    def __init__(self, l, dinv, info):
+        self.l = l
+        self.dinv = dinv
+        self.info = info
+        self._checked = False
+        self._dinv_sb = {128: dinv}
+        self._clean = False
+
+    @classmethod
+    def factor_(cls, a):
+        """Factorise ``a`` (..., n, n; lower triangle read) IN PLACE."""
+        be = ops.get_backend()
+        dinv, info = be.potrf_(a, config.potrf_nbo)
+        c = cls(a, dinv, info)
+        if config.check_info:
+            c.check()
+        return c
+
+    def check(self):
+        if not self._checked:
+            bad = int(self.info.max().item()) if self.info.numel() else 0
+            self._checked = True
+            if bad != 0:
+                raise torch.linalg.LinAlgError(
+                    f"cholesky: the leading minor of order {bad} is not positive-definite "
+                    "(increase B.epsilon or the noise)"
+                )
+        return self
+
+    @property
+    def n(self):
+        return self.l.shape[-1]
+
+    def logdet(self):
+        return ops.get_backend().logdet_chol(self.l)
+
+    def _blocks(self, nrhs):
+        n = self.n
+        sb = 128 if (nrhs <= 8 or self.l.dim() > 2) else _solve_block(n)
+        if sb not in self._dinv_sb:
+            self._dinv_sb[sb] = ops.get_backend().trtri_merge(self.l, self.dinv, sb)
+        return sb, self._dinv_sb[sb]
+
+    def solve_(self, b):
+        """``b <- L^{-1} b`` in place (``b``: (..., n, nrhs), unit inner stride)."""
+        sb, dsb = self._blocks(b.shape[-1])
+        return ops.get_backend().tri_solve_(self.l, dsb, sb, b)
+
+    def solve(self, b):
+        """``L^{-1} b`` as a new tensor."""
+        if b.shape[-2] != self.n:
+            raise ValueError(f"right-hand side has {b.shape[-2]} rows, the factor has order {self.n}")
+        lb, bb = tuple(self.l.shape[:-2]), tuple(b.shape[:-2])
+        if lb and bb and lb != bb:
+            raise ValueError(f"batch shapes {lb} and {bb} do not match")
+        out = b.expand((lb or bb) + tuple(b.shape[-2:])).clone(memory_format=torch.contiguous_format)
+        return self.solve_(out)
+
+    def iqf_diag(self, b):
+        """Column-wise ``|L^{-1} b|^2``: (..., nrhs)."""
+        v = self.solve(b)
+        _, ss = ops.get_backend().colreduce(v, want_ss=True)
+        return ss
+
+    def lower(self):
+        """The clean lower-triangular factor (zeros above the diagonal)."""
+        if not self._clean:
+            ops.get_backend().tril_(self.l)
+            self._clean = True
+        return self.l
+
+
+class AbstractMatrix:
+    """Base class of the structured matrices."""
+
+    @property
+    def dtype(self):
+        raise NotImplementedError
+
+    @property
+    def device(self):
+        raise NotImplementedError
+
+    @property
+    def shape(self):
+        raise NotImplementedError
+
+    def __radd__(self, other):
+        return self.__add__(other)
+
+
+class Zero(AbstractMatrix):
+    """``n x m`` zero matrix (``fdd.py:26``: no noise)."""
+
+    def __init__(self, dtype, rows, cols, device=None, batch=()):
+        self._dtype, self.rows, self.cols, self._device, self.batch = dtype, rows, cols, device, tuple(batch)
+
+    dtype = property(lambda self: self._dtype)
+    device = property(lambda self: self._device)
+    shape = property(lambda self: self.batch + (self.rows, self.cols))
+
+    def dense(self):
+        return torch.zeros(self.shape, dtype=self._dtype, device=self._device)
+
+    def diag(self):
+        return torch.zeros(self.batch + (min(self.rows, self.cols),), dtype=self._dtype, device=self._device)
+
+    def __add__(self, other):
+        if isinstance(other, (int, float)) and other == 0:
+            return self
+        return other
+
+    def __eq__(self, other):
+        return isinstance(other, Zero) and self.shape == other.shape
+
+    def __hash__(self):
+        return id(self)
+
+    def __repr__(self):
+        return f"<zero matrix: shape={self.rows}x{self.cols}, dtype={self._dtype}>"
+
+
+class Diagonal(AbstractMatrix):
+    """Diagonal matrix given by its diagonal (..., n)."""
+
+    def __init__(self, diag):
+        self._diag = diag
+
+    dtype = property(lambda self: self._diag.dtype)
+    device = property(lambda self: self._diag.device)
+    shape = property(lambda self: tuple(self._diag.shape) + (self._diag.shape[-1],))
+
+    def diag(self):
+        return self._diag
+
+    def dense(self):
+        return torch.diag_embed(self._diag)
+
+    def logdet(self):
+        return torch.log(self._diag).sum(-1)
+
+    def iqf_diag(self, b):
+        return (b * b / self._diag[..., :, None]).sum(-2)
+
+    def __add__(self, other):
+        if isinstance(other, Zero):
+            return self
+        if isinstance(other, Diagonal):
+            return Diagonal(self._diag + other._diag)
+        if isinstance(other, (int, float)):
+            if other == 0:
+                return self
+            raise TypeError("adding a non-zero scalar to a Diagonal densifies it; add to .dense() instead")
+        if isinstance(other, Dense):
+            return other + self
+        return NotImplemented
+
+    def __sub__(self, other):
+        if isinstance(other, Diagonal):
+            return Diagonal(self._diag - other._diag)
+        return NotImplemented
+
+    def __mul__(self, s):
+        return Diagonal(self._diag * s)
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return f"<diagonal matrix: shape={self.shape}, dtype={self.dtype}>"
+
+
+class Dense(AbstractMatrix):
+    """Dense (symmetric when used as a variance) matrix with a cached Cholesky factor --
+    the behaviour of ``matrix.Dense`` the reference relies on: ``B.logdet`` and
+    ``B.iqf_diag`` in ``random.py:274-276`` share one factorisation."""
+
+    def __init__(self, mat):
+        self._mat = mat
+        self._chol = None
+
+    # materialisation ---------------------------------------------------------
+    @property
+    def mat(self):
+        return self._mat
+
+    dtype = property(lambda self: self.mat.dtype)
+    device = property(lambda self: self.mat.device)
+    shape = property(lambda self: tuple(self.mat.shape))
+
+    def dense(self):
+        return self.mat
+
+    def diag(self):
+        return torch.diagonal(self.mat, dim1=-2, dim2=-1)
+
+    # Cholesky ----------------------------------------------------------------
+    def chol(self):
+        """``chol(self + epsilon * I)``, computed once (a copy is factorised)."""
+        if self._chol is None:
+            be = ops.get_backend()
+            a = be.copy(self.mat)
+            if config.epsilon:
+                be.add_diag_(a, config.epsilon)
+            self._chol = Chol.factor_(a)
+        return self._chol
+
+    def logdet(self):
+        return self.chol().logdet()
+
+    def iqf_diag(self, b):
+        return self.chol().iqf_diag(b)
+
+    # algebra -----------------------------------------------------------------
+    def __add__(self, other):
+        be = ops.get_backend()
+        if isinstance(other, Zero) or (isinstance(other, (int, float)) and other == 0):
+            return self
+        if isinstance(other, Diagonal):
+            return Dense(be.add_diag_(be.copy(self.mat), 0.0, other.diag()))
+        if isinstance(other, Dense):
+            return Dense(self.mat + other.mat)
+        if torch.is_tensor(other):
+            return Dense(self.mat + other)
+        return NotImplemented
+
+    def __repr__(self):
+        return f"<dense matrix: shape={self.shape}, dtype={self.dtype}>"
+
+
+class KernelDense(Dense):
+    """``k(x) + noise`` as a lazily materialised ``Dense`` (``fdd.py:79``,
+    ``observations.py:139,286``).
+
+    If only the Cholesky factor is needed (logpdf, conditioning), the kernel matrix is
+    built lower-triangle-only straight into the buffer that is then factorised in
+    place: ``K`` and ``L`` are never both resident (N = 32768 fp32 is 4.3 GB per copy).
+    """
+
+    def __init__(self, kernel, x, noise):
+        super().__init__(None)
+        self.kernel, self.x, self.noise = kernel, x, noise
+
+    def _noise_parts(self):
+        noise = self.noise
+        if noise is None or isinstance(noise, Zero):
+            return 0.0, None, None
+        if isinstance(noise, Diagonal):
+            return 0.0, noise.diag(), None
+        if isinstance(noise, Dense):
+            return 0.0, None, noise.mat
+        raise TypeError(f"unsupported noise type {type(noise).__name__}")
+
+    def _build(self, lower, jitter):
+        _, dvec, dense_noise = self._noise_parts()
+        out = self.kernel.pairwise(self.x, None, lower=lower and dense_noise is None, diag_add=jitter, diag_vec=dvec)
+        if dense_noise is not None:
+            out = out + dense_noise
+        return out
+
+    @property
+    def mat(self):
+        if self._mat is None:
+            self._mat = self._build(lower=False, jitter=0.0)
+        return self._mat
+
+    @property
+    def dtype(self):
+        return self.x.dtype
+
+    @property
+    def device(self):
+        return self.x.device
+
+    @property
+    def shape(self):
+        n = self.kernel.num_outputs(self.x)
+        return tuple(self.x.shape[:-2]) + (n, n)
+
+    def diag(self):
+        if self._mat is not None:
+            return torch.diagonal(self._mat, dim1=-2, dim2=-1)
+        d = self.kernel.elwise(self.x)[..., 0]
+        _, dvec, dense_noise = self._noise_parts()
+        if dvec is not None:
+            d = d + dvec
+        if dense_noise is not None:
+            d = d + torch.diagonal(dense_noise, dim1=-2, dim2=-1)
+        return d
+
+    def chol(self):
+        if self._chol is None:
+            if self._mat is not None:
+                return super().chol()
+            a = self._build(lower=True, jitter=config.epsilon)
+            self._chol = Chol.factor_(a)
+        return self._chol
+
+
+def to_matrix(a):
+    """``convert(a, AbstractMatrix)`` (random.py:110)."""
+    if isinstance(a, AbstractMatrix):
+        return a
+    if torch.is_tensor(a):
+        if a.dim() < 2:
+            raise ValueError("a variance must be a matrix")
+        return Dense(a)
+    raise TypeError(f"cannot interpret {type(a).__name__} as a matrix")
+
+
+LOG_2_PI = math.log(2 * math.pi)

@@ -1,0 +1,85 @@
+"""``FDD``: a GP at finite inputs (``stheno/model/fdd.py``)."""
+import torch
+
+from .. import kernels as _k
+from ..matrix import AbstractMatrix, Dense, Diagonal, KernelDense, Zero
+from ..random import Normal
+
+__all__ = ["FDD"]
+
+
+def _noise_as_matrix(noise, x, n):
+    """Represent noise as a structured matrix (``fdd.py:14-41``): ``None`` -> ``Zero``,
+    scalar -> ``Diagonal`` (``B.fill_diag``), vector -> ``Diagonal``, matrix -> ``Dense``."""
+    if noise is None:
+        return Zero(x.dtype, n, n, device=x.device, batch=tuple(x.shape[:-2]))
+    if isinstance(noise, AbstractMatrix):
+        return noise
+    if not torch.is_tensor(noise):
+        noise = torch.as_tensor(noise, dtype=x.dtype, device=x.device)
+    noise = noise.to(dtype=x.dtype, device=x.device)
+    if noise.dim() == 0:
+        return Diagonal(noise.expand(tuple(x.shape[:-2]) + (n,)).contiguous())
+    if noise.dim() == 1 or (x.dim() > 2 and noise.dim() == x.dim() - 1):
+        return Diagonal(noise)
+    return Dense(noise)
+
+
+class FDD(Normal):
+    """Finite-dimensional distribution of process ``p`` at inputs ``x`` with additive
+    ``noise``.  Nothing is computed at construction (``fdd.py:59-83``)."""
+
+    def __init__(self, p, x, noise=None):
+        self.p = p
+        if isinstance(p, int):
+            self.x = x
+            self.noise = None
+            return
+        xr = _k.uprank(x)
+        self.x = x
+        self._xr = xr
+        self.noise = _noise_as_matrix(noise, xr, p.kernel.num_outputs(xr))
+
+        def var_diag():
+            return p.kernel.elwise(xr)[..., 0] + self.noise.diag()
+
+        def mean_var():
+            mean, var = _k.mean_var(p.mean, p.kernel, xr)
+            return mean, var + self.noise
+
+        def mean_var_diag():
+            mean, vd = _k.mean_var_diag(p.mean, p.kernel, xr)
+            return mean, vd[..., 0] + self.noise.diag()
+
+        def var():
+            k = p.kernel
+            if k.terms() is not None:
+                return KernelDense(k, xr, self.noise)      # K + noise fused, factorised in place
+            return k(xr) + self.noise
+
+        Normal.__init__(self, lambda: p.mean(xr), var, var_diag=var_diag, mean_var=mean_var,
+                        mean_var_diag=mean_var_diag)
+
+    @property
+    def dtype(self):
+        return self._xr.dtype if not isinstance(self.p, int) else self.x.dtype
+
+    def __repr__(self):
+        return f"<FDD:\n process={self.p!r},\n input={self.x!r},\n noise={self.noise!r}>"
+
+    __str__ = __repr__
+
+
+def take(fdd, mask):
+    """``B.take(fdd, mask)`` (``fdd.py:125-132``): sub-select observations by a boolean mask."""
+    if mask.dtype != torch.bool:
+        raise AssertionError("Can only take from finite-dimensional distributions according to a mask.")
+    idx = torch.nonzero(mask)[:, 0]
+    noise = fdd.noise
+    if isinstance(noise, Diagonal):
+        noise = Diagonal(noise.diag()[idx])
+    elif isinstance(noise, Dense):
+        noise = Dense(noise.mat[idx][:, idx])
+    elif isinstance(noise, Zero):
+        noise = None
+    return FDD(fdd.p, _k.uprank(fdd.x)[idx], noise)

@@ -1,0 +1,151 @@
+"""``Measure``: a joint model over processes (``stheno/model/measure.py``), reduced to the
+bookkeeping the dense inference path needs: registering processes, lazy (cross-)kernels
+and means, conditioning, re-binding a GP / FDD under a posterior, ``logpdf`` and ``sample``."""
+import torch
+
+from .. import kernels as _k
+from ..lazy import LazyMatrix, LazyVector
+from .fdd import FDD
+from .gp import GP, assert_same_measure
+from .observations import AbstractObservations, AbstractPseudoObservations, Observations, combine
+
+__all__ = ["Measure"]
+
+
+class Measure:
+    """A GP model.  ``with Measure() as prior:`` makes it the default for new GPs
+    (``measure.py:35-55``)."""
+
+    default = None
+
+    def __init__(self):
+        self.ps = []
+        self._pids = set()
+        self.means = LazyVector()
+        self.kernels = LazyMatrix()
+        self._gps_by_name = {}
+        self._names_by_gp = {}
+        self._prev_default = None
+
+    def __enter__(self):
+        self._prev_default = Measure.default
+        Measure.default = self
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        Measure.default = self._prev_default
+
+    def __hash__(self):
+        return id(self)
+
+    def __eq__(self, other):
+        return self is other
+
+    # -- naming (measure.py:62-91) ----------------------------------------------
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self._gps_by_name[key]
+        return self._names_by_gp[id(key)]
+
+    def name(self, p, name):
+        if id(p) in self._names_by_gp:
+            del self._gps_by_name[self._names_by_gp[id(p)]]
+            del self._names_by_gp[id(p)]
+        if name in self._gps_by_name:
+            raise RuntimeError(f'Name "{name}" for "{p}" already taken by "{self[name]}".')
+        self._gps_by_name[name] = p
+        self._names_by_gp[id(p)] = name
+
+    # -- registering processes ---------------------------------------------------
+    def _add_p(self, p):
+        self.ps.append(p)
+        self._pids.add(id(p))
+        p._measures.append(self)
+
+    def _update(self, p, mean, kernel, left_rule, right_rule=None):
+        self.means[p] = mean
+        self.kernels[p] = kernel
+        self.kernels.add_left_rule(id(p), self._pids, left_rule)
+        if right_rule:
+            self.kernels.add_right_rule(id(p), self._pids, right_rule)
+        else:
+            self.kernels.add_right_rule(id(p), self._pids, lambda i: reversed(self.kernels[p, i]))
+        self._add_p(p)
+        return p
+
+    def add_independent_gp(self, p, mean, kernel):
+        """Register ``p`` with zero cross-covariance to every other process (``measure.py:156-178``)."""
+        self.means[p] = mean
+        self.kernels[p] = kernel
+        self.kernels.add_left_rule(id(p), self._pids, lambda j: _k.ZeroKernel())
+        self.kernels.add_right_rule(id(p), self._pids, lambda i: _k.ZeroKernel())
+        self._add_p(p)
+        return p
+
+    def __call__(self, p):
+        """``measure(p)``: a new GP that is ``p`` under this measure; ``measure(fdd)``: the FDD
+        re-bound under this measure (``measure.py:139-154``)."""
+        if isinstance(p, FDD):
+            return self(p.p)(p.x, p.noise)
+        p_copy = GP()
+        return self._update(p_copy, self.means[p], self.kernels[p], lambda j: self.kernels[p, j],
+                            lambda i: self.kernels[i, p])
+
+    # -- bookkeeping-only algebra (measure.py:180-239) ---------------------------
+    def sum(self, p_sum, p, other):
+        if isinstance(other, GP):
+            assert_same_measure(p, other)
+            p1, p2 = p, other
+            return self._update(
+                p_sum, self.means[p1] + self.means[p2],
+                self.kernels[p1] + self.kernels[p2] + self.kernels[p1, p2] + self.kernels[p2, p1],
+                lambda j: self.kernels[p1, j] + self.kernels[p2, j],
+            )
+        return self._update(p_sum, self.means[p] + other, self.kernels[p], lambda j: self.kernels[p, j])
+
+    def mul(self, p_mul, p, other):
+        v = float(other)
+        return self._update(p_mul, self.means[p] * v, self.kernels[p] * v**2, lambda j: self.kernels[p, j] * v)
+
+    # -- conditioning (measure.py:362-401) --------------------------------------
+    def condition(self, *args):
+        if len(args) == 1 and isinstance(args[0], AbstractObservations):
+            obs = args[0]
+        elif len(args) == 2 and isinstance(args[0], FDD):
+            obs = Observations(*args)
+        elif len(args) == 1 and isinstance(args[0], tuple) and len(args[0]) == 2 and isinstance(args[0][0], FDD):
+            obs = Observations(*args[0])
+        elif len(args) == 1 and isinstance(args[0], tuple):
+            obs = Observations(*args[0])
+        else:
+            obs = Observations(*args)
+        posterior = Measure()
+        posterior.ps = list(self.ps)
+        posterior._pids = set(self._pids)
+        posterior.means.add_rule(posterior._pids, lambda i: obs.posterior_mean(self, i))
+        posterior.kernels.add_rule(posterior._pids, lambda i, j: obs.posterior_kernel(self, i, j))
+        for p in posterior.ps:
+            p._measures.append(posterior)
+        return posterior
+
+    def __or__(self, args):
+        return self.condition(*args) if isinstance(args, tuple) and not isinstance(args[0], FDD) else self.condition(args)
+
+    # -- sampling / logpdf (measure.py:425-489) -----------------------------------
+    def sample(self, *args, generator=None):
+        n = 1
+        if args and isinstance(args[0], int):
+            n, args = args[0], args[1:]
+        fdd = combine(*args)
+        return self(fdd).sample(n, generator=generator)
+
+    def logpdf(self, *args):
+        if len(args) == 1 and isinstance(args[0], AbstractPseudoObservations):
+            return args[0].elbo(self)
+        if len(args) == 1 and isinstance(args[0], Observations):
+            return self.logpdf(args[0].fdd, args[0].y)
+        if len(args) == 2 and isinstance(args[0], FDD):
+            fdd, y = args
+            return self(fdd).logpdf(y)
+        fdd, y = combine(*args)
+        return self(fdd).logpdf(y)

@@ -1,0 +1,249 @@
+"""Observations: exact conditioning and the pseudo-point (VFE / FITC / DTC)
+approximations (``stheno/model/observations.py``)."""
+import math
+
+import torch
+
+from .. import kernels as _k
+from .. import ops
+from ..matrix import AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, config
+from .fdd import FDD, take
+
+__all__ = [
+    "combine", "AbstractObservations", "AbstractPseudoObservations", "Observations", "Obs",
+    "PseudoObservations", "SparseObservations", "PseudoObs", "SparseObs", "PseudoObservationsFITC",
+    "PseudoObsFITC", "PseudoObservationsDTC", "PseudoObsDTC",
+]
+
+
+def combine(*args):
+    """Combine FDDs / (FDD, y) pairs into one (``observations.py:28-47``).  Only the
+    single-process case lies on the accelerated path."""
+    if len(args) == 1:
+        return args[0]
+    raise NotImplementedError(
+        "combining observations of several processes (multi-output block kernels) is not on the "
+        "accelerated path yet"
+    )
+
+
+def _kernel_matrix(kernel, x, noise):
+    """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``)."""
+    if kernel.terms() is not None:
+        return KernelDense(kernel, x, noise)
+    return kernel(x) + noise
+
+
+class AbstractObservations:
+    """``(fdd, y)``: ``y`` must be one column (``observations.py:64-79``)."""
+
+    def __init__(self, *args):
+        if len(args) == 2 and isinstance(args[0], FDD):
+            fdd, y = args
+        elif len(args) >= 1 and all(isinstance(a, tuple) for a in args):
+            fdd, y = combine(*args)
+        else:
+            raise TypeError("Observations(fdd, y) or Observations((fdd, y), ...)")
+        if not torch.is_tensor(y):
+            y = torch.as_tensor(y, dtype=fdd.dtype, device=_k.uprank(fdd.x).device)
+        y_shape = tuple(y.shape)
+        if y.dim() <= 1:
+            y = y.reshape(-1, 1)
+        if y.shape[-1] != 1:
+            raise ValueError(f"Invalid shape of observed values {y_shape}.")
+        # Missing data (host sync, as in the reference: observations.py:73-76).
+        if y.dim() == 2:
+            available = ~torch.isnan(y[:, 0])
+            if not bool(available.all()):
+                fdd = take(fdd, available)
+                y = y[torch.nonzero(available)[:, 0]]
+        self.fdd = fdd
+        self.y = y
+
+    def posterior_kernel(self, measure, p_i, p_j):  # pragma: no cover
+        raise NotImplementedError("Posterior kernel construction not implemented.")
+
+    def posterior_mean(self, measure, p):  # pragma: no cover
+        raise NotImplementedError("Posterior mean construction not implemented.")
+
+
+class Observations(AbstractObservations):
+    """Exact conditioning (``observations.py:112-168``)."""
+
+    def __init__(self, *args):
+        AbstractObservations.__init__(self, *args)
+        self._K_x = {}
+
+    def K_x(self, measure):
+        """``k(x) + noise`` of the data under ``measure``; built once per measure, its
+        Cholesky factor is shared by every later prediction (``observations.py:127-141``)."""
+        try:
+            return self._K_x[id(measure)]
+        except KeyError:
+            p = self.fdd.p
+            if p._measures and p._measures[0] is measure and self.fdd.noise is not None:
+                # The FDD was built under this very measure: its variance IS k(x) + noise.
+                # Re-use the object, so a logpdf and a conditioning on the same FDD share
+                # one kernel matrix and one Cholesky factor.
+                K_x = self.fdd.var
+            else:
+                K_x = _kernel_matrix(measure.kernels[p], _k.uprank(self.fdd.x), self.fdd.noise)
+            self._K_x[id(measure)] = K_x
+            return K_x
+
+    def posterior_kernel(self, measure, p_i, p_j):
+        if _k.num_elements(self.fdd.x) == 0:
+            return measure.kernels[p_i, p_j]
+        return _k.PosteriorKernel(
+            measure.kernels[p_i, p_j], measure.kernels[self.fdd.p, p_i], measure.kernels[self.fdd.p, p_j],
+            _k.uprank(self.fdd.x), self.K_x(measure),
+        )
+
+    def posterior_mean(self, measure, p):
+        if _k.num_elements(self.fdd.x) == 0:
+            return measure.means[p]
+        return _k.PosteriorMean(
+            measure.means[p], measure.means[self.fdd.p], measure.kernels[self.fdd.p, p], _k.uprank(self.fdd.x),
+            self.K_x(measure), self.y,
+        )
+
+
+class _FactoredDense(Dense):
+    """A ``Dense`` whose Cholesky factor is already known."""
+
+    def __init__(self, mat, chol):
+        super().__init__(mat)
+        self._chol = chol
+
+
+class AbstractPseudoObservations(AbstractObservations):
+    """Observations through inducing points ``u`` (``observations.py:171-336``)."""
+
+    method = None
+
+    def __init__(self, u, *args):
+        AbstractObservations.__init__(self, *args)
+        if isinstance(u, tuple):
+            u = combine(*u)
+        self.u = u
+        self._K_z, self._elbo, self._mu, self._A, self._parts = {}, {}, {}, {}, {}
+
+    def K_z(self, measure):
+        if id(measure) not in self._K_z:
+            self._compute(measure)
+        return self._K_z[id(measure)]
+
+    def elbo(self, measure):
+        if id(measure) not in self._elbo:
+            self._compute(measure)
+        return self._elbo[id(measure)]
+
+    def mu(self, measure):
+        """Mean of the optimal approximating distribution (``observations.py:224-237``)."""
+        if id(measure) not in self._mu:
+            self.elbo(measure)
+            be = ops.get_backend()
+            p = self._parts[id(measure)]
+            l_z = p["K_z"].chol().lower()
+            t = p["chol_A"].solve(l_z.transpose(-1, -2).contiguous())      # L_A^{-1} L_z^T
+            dot, _ = be.colreduce(t, p["u"], want_dot=True, want_ss=False)  # (L_A^{-1} L_z^T)^T L_A^{-1} p
+            z = _k.uprank(self.u.x)
+            self._mu[id(measure)] = measure.means[self.u.p](z) + dot[..., None]
+        return self._mu[id(measure)]
+
+    def A(self, measure):
+        """``L_z A L_z^T`` (``observations.py:239-253,323``) as a ``Dense``."""
+        if id(measure) not in self._A:
+            self.elbo(measure)
+            be = ops.get_backend()
+            p = self._parts[id(measure)]
+            l_z = p["K_z"].chol().lower()
+            a_full = be.symmetrize_(be.copy(p["A"]))
+            w = be.gemm(a_full, l_z, a_kmajor=True, b_kmajor=True)          # A L_z^T
+            self._A[id(measure)] = Dense(be.gemm(l_z, w, a_kmajor=True, b_kmajor=False))
+        return self._A[id(measure)]
+
+    def posterior_kernel(self, measure, p_i, p_j):
+        z = _k.uprank(self.u.x)
+        return _k.PosteriorKernel(
+            measure.kernels[p_i, p_j], measure.kernels[self.u.p, p_i], measure.kernels[self.u.p, p_j], z,
+            self.K_z(measure),
+        ) + _k.SubspaceKernel(measure.kernels[self.u.p, p_i], measure.kernels[self.u.p, p_j], z, self.A(measure))
+
+    def posterior_mean(self, measure, p):
+        return _k.PosteriorMean(
+            measure.means[p], measure.means[self.u.p], measure.kernels[self.u.p, p], _k.uprank(self.u.x),
+            self.K_z(measure), self.mu(measure),
+        )
+
+    def _compute(self, measure):
+        """``observations.py:279-336``.  Heavy steps: ``K_zx`` (kmat), ``chol(K_z)`` (potrf),
+        ``V = L_z^{-1} K_zx`` (blocked TRSM, in place on ``K_zx``), ``A = I + V K_n^{-1} V^T``
+        (lower SYRK on MFMA over column-scaled ``V``), ``chol(A)``."""
+        be = ops.get_backend()
+        p_x, x, noise_x = self.fdd.p, _k.uprank(self.fdd.x), self.fdd.noise
+        p_z, z, noise_z = self.u.p, _k.uprank(self.u.x), self.u.noise
+
+        K_zx = measure.kernels[p_z, p_x].pairwise(z, x)                       # :285
+        K_z = _kernel_matrix(measure.kernels[p_z], z, noise_z)                # :286
+        self._K_z[id(measure)] = K_z
+
+        if not isinstance(noise_x, Diagonal):                                 # :293-297
+            raise RuntimeError(
+                f'Kernel matrix of observation noise must be diagonal, not "{type(noise_x).__name__}".'
+            )
+        K_n = noise_x.diag()
+
+        v = K_z.chol().solve_(K_zx)                                           # :300-301
+        trace_part = 0.0
+        if self.method in {"vfe", "fitc"}:
+            k_x_diag = measure.kernels[p_x].elwise(x)[..., 0]                 # :304
+            _, q_x_diag = be.colreduce(v, want_ss=True)                       # :305
+            corr = k_x_diag - q_x_diag
+            if self.method == "vfe":
+                trace_part = (corr / K_n).sum(-1)                             # :310
+            else:
+                K_n = K_n + corr                                              # :312
+        elif self.method != "dtc":  # pragma: no cover
+            raise ValueError(f'Invalid approximation method "{self.method}".')
+
+        s = torch.rsqrt(K_n)
+        be.scale_cols_(v, s)                                                  # V K_n^{-1/2}
+        m = z.shape[-2]
+        A = torch.eye(m, dtype=x.dtype, device=x.device).expand(v.shape[:-2] + (m, m)).contiguous()
+        be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=1.0, out=A, lower_only=True)   # :322 (lower)
+        y_bar = self.y - measure.means[p_x](x)                                # :326
+        prod_y_bar = be.gemv(v, y_bar * s[..., None])                         # :327
+        a_fac = be.copy(A)
+        if config.epsilon:
+            be.add_diag_(a_fac, config.epsilon)
+        chol_A = Chol.factor_(a_fac)
+        u = chol_A.solve(prod_y_bar)
+        _, uu = be.colreduce(u, want_ss=True)
+        det_part = torch.log(2 * math.pi * K_n).sum(-1) + chol_A.logdet()     # :334
+        iqf_part = (y_bar[..., 0] ** 2 / K_n).sum(-1) - uu[..., 0]            # :335
+        self._parts[id(measure)] = dict(K_z=K_z, A=A, chol_A=chol_A, u=u)
+        self._elbo[id(measure)] = -0.5 * (det_part + iqf_part + trace_part)   # :336
+
+
+class PseudoObservations(AbstractPseudoObservations):
+    """VFE approximation (Titsias, 2009)."""
+    method = "vfe"
+
+
+class PseudoObservationsFITC(AbstractPseudoObservations):
+    """FITC approximation (Snelson & Ghahramani, 2006)."""
+    method = "fitc"
+
+
+class PseudoObservationsDTC(AbstractPseudoObservations):
+    """DTC approximation (Csato & Opper, 2002; Seeger et al., 2003)."""
+    method = "dtc"
+
+
+Obs = Observations
+PseudoObs = PseudoObservations
+PseudoObsFITC = PseudoObservationsFITC
+PseudoObsDTC = PseudoObservationsDTC
+SparseObs = PseudoObservations
+SparseObservations = PseudoObservations

@@ -1,0 +1,261 @@
+"""``Normal``: the multivariate normal of the reference (``stheno/random.py``), restated
+over torch tensors on a HIP device, with the lazy mean / variance / variance-diagonal
+resolution semantics of ``random.py:96-117,149-227`` and ``logpdf`` of
+``random.py:248-280``.
+
+What is computed once: the variance is resolved once; its Cholesky factor is cached on
+the matrix object and shared by ``logdet`` and ``iqf_diag`` (one POTRF per logpdf, one
+per conditioning).
+"""
+import types
+
+import torch
+
+from . import ops
+from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, Zero, to_matrix
+
+__all__ = ["Random", "RandomProcess", "RandomVector", "Normal"]
+
+
+class Random:
+    """A random object."""
+
+    def __radd__(self, other):
+        return self + other
+
+    def __rmul__(self, other):
+        return self * other
+
+    def __neg__(self):
+        return -1 * self
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def __rsub__(self, other):
+        return (-self) + other
+
+    def __truediv__(self, other):
+        return self * (1 / other)
+
+
+class RandomProcess(Random):
+    """A random process."""
+
+
+class RandomVector(Random):
+    """A random vector."""
+
+
+def _is_zero(x):
+    return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 0
+
+
+class Normal(RandomVector):
+    """Normal random variable.
+
+    ``Normal(var)``, ``Normal(mean, var)`` with tensors / structured matrices, or
+    ``Normal(mean_fn, var_fn, var_diag=..., mean_var=..., mean_var_diag=...)`` with
+    zero-argument constructors that are called lazily (``random.py:56-94``).
+    """
+
+    def __init__(self, *args, var_diag=None, mean_var=None, mean_var_diag=None):
+        if len(args) == 1:
+            mean, var = (lambda: 0) if isinstance(args[0], types.FunctionType) else 0, args[0]
+        elif len(args) == 2:
+            mean, var = args
+        else:
+            raise TypeError("Normal(var) or Normal(mean, var)")
+        self._mean_is_zero = None
+        self._var_diag = None
+        if isinstance(var, types.FunctionType):
+            if not isinstance(mean, types.FunctionType):
+                raise TypeError("mean and var must both be constructors or both be values")
+            self._mean = None
+            self._construct_mean = mean
+            self._var = None
+            self._construct_var = var
+            self._construct_var_diag = var_diag
+            self._construct_mean_var = mean_var
+            self._construct_mean_var_diag = mean_var_diag
+        else:
+            self._mean = mean
+            self._var = var
+            self._construct_mean = None
+            self._construct_var = None
+            self._construct_var_diag = None
+            self._construct_mean_var = None
+            self._construct_mean_var_diag = None
+
+    # -- lazy resolution (random.py:96-117) ------------------------------------
+    def _resolve_mean(self, construct_zeros):
+        if self._mean is None:
+            self._mean = self._construct_mean()
+        if self._mean_is_zero is None:
+            self._mean_is_zero = _is_zero(self._mean) or isinstance(self._mean, Zero)
+        if _is_zero(self._mean) and construct_zeros:
+            var = self.var
+            shape = tuple(var.shape)
+            self._mean = torch.zeros(shape[:-2] + (shape[-1], 1), dtype=var.dtype, device=var.device)
+
+    def _resolve_var(self):
+        if self._var is None:
+            self._var = self._construct_var()
+        self._var = to_matrix(self._var)
+
+    def _resolve_var_diag(self):
+        if self._var_diag is None:
+            if self._construct_var_diag is not None:
+                self._var_diag = self._construct_var_diag()
+            else:
+                self._var_diag = self.var.diag()
+
+    def __repr__(self):
+        m = "unresolved" if self._mean is None else repr(self._mean)
+        v = "unresolved" if self._var is None else repr(self._var)
+        return f"<Normal:\n mean={m},\n var={v}>"
+
+    __str__ = __repr__
+
+    @property
+    def mean(self):
+        """Column vector: mean."""
+        self._resolve_mean(construct_zeros=True)
+        m = self._mean
+        return m.dense() if isinstance(m, AbstractMatrix) else m
+
+    @property
+    def mean_is_zero(self):
+        self._resolve_mean(construct_zeros=False)
+        return self._mean_is_zero
+
+    @property
+    def var(self):
+        """Variance as a structured matrix (``B.dense(d.var)`` for the plain tensor)."""
+        self._resolve_var()
+        return self._var
+
+    @property
+    def var_diag(self):
+        self._resolve_var_diag()
+        return self._var_diag
+
+    @property
+    def mean_var(self):
+        if self._mean is not None and self._var is not None:
+            return self.mean, self.var
+        elif self._mean is not None:
+            return self.mean, self.var
+        elif self._var is not None:
+            return self.mean, self.var
+        else:
+            if self._construct_mean_var is not None:
+                self._mean, self._var = self._construct_mean_var()
+                self._resolve_mean(construct_zeros=True)
+                self._resolve_var()
+            return self.mean, self.var
+
+    @property
+    def dtype(self):
+        return self.var.dtype
+
+    @property
+    def dim(self):
+        return self.var.shape[-1]
+
+    @property
+    def m2(self):
+        m = self.mean
+        return self.var.dense() + m @ m.transpose(-1, -2)
+
+    # -- marginals (random.py:204-238) -----------------------------------------
+    def marginals(self):
+        """Marginal means and variances (the covariance is not formed when a
+        ``mean_var_diag`` constructor is available)."""
+        if self._mean is not None and self._var_diag is not None:
+            mean, var_diag = self.mean, self._var_diag
+        elif self._mean is not None:
+            mean, var_diag = self.mean, self.var_diag
+        elif self._var_diag is not None:
+            mean, var_diag = self.mean, self._var_diag
+        else:
+            if self._construct_mean_var_diag is not None:
+                self._mean, self._var_diag = self._construct_mean_var_diag()
+                self._resolve_mean(construct_zeros=True)
+            mean, var_diag = self.mean, self.var_diag
+        if isinstance(var_diag, AbstractMatrix):
+            var_diag = var_diag.dense()
+        # Variances can come out slightly negative through round-off (random.py:221-227).
+        if torch.is_tensor(mean) and mean.dim() >= 1:
+            mean = mean[..., 0]
+        if torch.is_tensor(var_diag):
+            var_diag = torch.clamp(var_diag, min=0)
+        return mean, var_diag
+
+    def marginal_credible_bounds(self):
+        """Marginal means with lower and upper 95% central credible bounds."""
+        mean, var = self.marginals()
+        error = 1.96 * torch.sqrt(var)
+        return mean, mean - error, mean + error
+
+    def diagonalise(self):
+        return Normal(self.mean, Diagonal(self.var_diag))
+
+    # -- logpdf (random.py:248-280) --------------------------------------------
+    def logpdf(self, x):
+        """Log-density at ``x``: ``(N,)``/``(N, 1)`` -> scalar tensor, ``(N, C)`` -> ``(C,)``,
+        batched ``(B, N, 1)`` -> ``(B,)``."""
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(x, dtype=self.dtype, device=self.var.device)
+        if x.dim() <= 1:
+            x = x.reshape(-1, 1)
+
+        # Missing data (not for batched computation): random.py:261-270.
+        if x.dim() == 2 and x.shape[1] == 1:
+            available = ~torch.isnan(x[:, 0])
+            if not bool(available.all()):
+                idx = torch.nonzero(available)[:, 0]
+                mean = self.mean[idx]
+                var = self.var.dense()[idx][:, idx]
+                return Normal(mean, var).logpdf(x[idx])
+
+        var = self.var
+        n = self.dim
+        r = x - self.mean
+        if isinstance(var, Zero):
+            raise torch.linalg.LinAlgError("the variance is identically zero")
+        logdet = var.logdet()
+        iqf = var.iqf_diag(r)
+        logpdfs = -(logdet[..., None] + n * LOG_2_PI + iqf) / 2
+        return logpdfs[..., 0] if logpdfs.shape[-1] == 1 else logpdfs
+
+    def entropy(self):
+        return (self.var.logdet() + self.dim * (LOG_2_PI + 1)) / 2
+
+    # -- sampling (random.py:331-363; adjacent to the hot path) ----------------
+    def sample(self, num=1, noise=None, generator=None):
+        """Samples as column vectors (..., N, num): ``chol(var) @ xi`` on the MFMA GEMM."""
+        var = self.var
+        if isinstance(var, Diagonal):
+            d = var.diag() + (noise if noise is not None else 0)
+            xi = torch.randn(d.shape + (num,), dtype=d.dtype, device=d.device, generator=generator)
+            out = torch.sqrt(d)[..., None] * xi
+        else:
+            if noise is not None:
+                var = var + Diagonal(torch.full(tuple(var.shape[:-1]), float(noise), dtype=var.dtype, device=var.device))
+            chol = var.chol() if isinstance(var, Dense) else to_matrix(var.dense()).chol()
+            l = chol.lower()
+            xi = torch.randn(tuple(var.shape[:-1]) + (num,), dtype=var.dtype, device=var.device, generator=generator)
+            out = ops.get_backend().gemm(l, xi, a_kmajor=True, b_kmajor=False)
+        if not self.mean_is_zero:
+            out = out + self.mean
+        return out
+
+    # -- arithmetic (random.py:365-393) ----------------------------------------
+    def __add__(self, other):
+        if isinstance(other, Normal):
+            return Normal(self.mean + other.mean, self.var + other.var)
+        return Normal(self.mean + other, self.var)
+
+    def __mul__(self, other):
+        return Normal(self.mean * other, Dense(self.var.dense() * (other * other)))

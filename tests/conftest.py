@@ -1,0 +1,165 @@
+"""pytest configuration.
+
+* ``-m "not gpu"`` (CPU box): the oracle is checked against the reference's known
+  answers, the golden fixtures and SciPy; the host-side model logic runs on top of
+  ``OracleBackend`` -- a TEST-ONLY op backend implemented with ``oracle/gp_oracle.py``
+  and installed through ``stheno_amd.ops.set_backend``; the C ABI library is loaded and
+  its exported symbols compared with ``include/gpk.h``.
+* ``-m gpu`` (MI355X box): everything goes through ``libgpk.so`` (``HipBackend``) and is
+  compared with the oracle / golden fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import gp_oracle as O  # noqa: E402
+from stheno_amd import ops  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+class OracleBackend:
+    """NumPy/SciPy stand-in for ``stheno_amd.ops.HipBackend`` (same method contracts),
+    so that the Python host logic can be unit-tested without a GPU.  Never used by the
+    package itself."""
+
+    name = "oracle-test-backend"
+
+    @staticmethod
+    def _t(a, like):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=like.dtype, device=like.device)
+
+    def kmat(self, terms, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, out=None, accumulate=False):
+        xs = _np(x)
+        k = O.kernel_matrix(terms.terms, xs, None if y is None else _np(y)) if len(terms) else \
+            np.zeros(xs.shape[:-1] + ((xs if y is None else _np(y)).shape[-2],), dtype=xs.dtype)
+        k = np.array(k, dtype=xs.dtype)
+        if y is None:
+            n = k.shape[-1]
+            idx = np.arange(n)
+            k[..., idx, idx] += diag_add
+            if diag_vec is not None:
+                k[..., idx, idx] += _np(diag_vec).reshape(k.shape[:-2] + (n,))
+        res = self._t(k, x)
+        if out is not None:
+            if accumulate:
+                out += res
+            else:
+                out.copy_(res)
+            return out
+        return res
+
+    def kdiag(self, terms, x):
+        return self._t(O.kernel_diag(terms.terms, _np(x)), x)
+
+    def potrf_(self, a, nbo=0):
+        arr = _np(a)
+        batch = int(np.prod(arr.shape[:-2])) if arr.ndim > 2 else 1
+        info = torch.zeros((batch,), dtype=torch.int32)
+        flat = arr.reshape((-1,) + arr.shape[-2:]).copy()
+        for b in range(flat.shape[0]):
+            sym = np.tril(flat[b]) + np.tril(flat[b], -1).T
+            try:
+                flat[b] = np.linalg.cholesky(sym)
+            except np.linalg.LinAlgError:
+                info[b] = 1
+                flat[b] = np.nan
+        a.copy_(self._t(flat.reshape(arr.shape), a))
+        return None, info
+
+    def trtri_merge(self, l, dinv, sb):
+        return None
+
+    def tri_solve_(self, l, dinv_sb, sb, b):
+        L, Bm = _np(l), _np(b)
+        Lf = L.reshape((-1,) + L.shape[-2:])
+        Bf = Bm.reshape((-1,) + Bm.shape[-2:]).copy()
+        for i in range(Bf.shape[0]):
+            if Bf[i].size:
+                Bf[i] = O.solve_lower(np.tril(Lf[i if Lf.shape[0] > 1 else 0]), Bf[i])
+        b.copy_(self._t(Bf.reshape(Bm.shape), b))
+        return b
+
+    def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False):
+        A = a if a_kmajor else a.transpose(-1, -2)
+        Bt = b.transpose(-1, -2) if b_kmajor else b
+        res = alpha * (A @ Bt)
+        if out is None:
+            return res.contiguous()
+        out.copy_(res + beta * out if beta != 0.0 else res)
+        return out
+
+    def gemv(self, a, x, *, alpha=1.0, beta=0.0, out=None):
+        res = alpha * (a @ x)
+        if out is None:
+            return res
+        out.copy_(res + beta * out if beta != 0.0 else res)
+        return out
+
+    def logdet_chol(self, l):
+        return 2 * torch.log(torch.diagonal(l, dim1=-2, dim2=-1)).sum(-1)
+
+    def colreduce(self, v, w=None, *, want_dot=False, want_ss=True):
+        dot = ss = None
+        if want_dot:
+            dot = (v * w.reshape(v.shape[:-1] + (1,))).sum(-2)
+        if want_ss:
+            ss = (v * v).sum(-2)
+        return dot, ss
+
+    def tril_(self, a):
+        a.copy_(torch.tril(a))
+        return a
+
+    def symmetrize_(self, a):
+        a.copy_(torch.tril(a) + torch.tril(a, -1).transpose(-1, -2))
+        return a
+
+    def add_diag_(self, a, s=0.0, v=None):
+        d = torch.diagonal(a, dim1=-2, dim2=-1)
+        d += s
+        if v is not None:
+            d += v.reshape(d.shape)
+        return a
+
+    def scale_cols_(self, v, s):
+        v *= s.reshape(v.shape[:-2] + (1, v.shape[-1]))
+        return v
+
+    def copy(self, src):
+        return src.clone(memory_format=torch.contiguous_format)
+
+
+@pytest.fixture()
+def oracle_backend():
+    """Install the test-only CPU backend for one test."""
+    prev = ops.set_backend(OracleBackend())
+    yield
+    ops.set_backend(prev)
+
+
+@pytest.fixture()
+def hip_backend():
+    """Make sure the real HIP backend is active (GPU tests)."""
+    prev = ops.set_backend(None)
+    be = ops.get_backend()
+    assert be.name == "hip"
+    yield be
+    ops.set_backend(prev)
+
+
+def golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)

@@ -1,0 +1,229 @@
+"""Parity of the HIP path (libgpk.so through the C ABI, via stheno_amd) with the CPU
+oracle and the committed golden fixtures, on a real MI355X.
+
+Tolerances (BASELINE.json north_star): logpdf / ELBO 1e-6 relative in fp64, 1e-3 in fp32;
+posterior mean / variance norm-wise ``max|a - b| / max|b|`` at the same levels.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+from stheno_amd import B, ops
+from stheno_amd.matrix import Chol
+
+from .conftest import ROOT, golden
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hip_backend")]
+
+DEV = "cuda"
+TOL = {torch.float64: 1e-6, torch.float32: 1e-3}
+EPS = {torch.float64: 1e-12, torch.float32: 1e-6}
+KINDS = {"eq": st.EQ, "matern12": st.Matern12, "matern32": st.Matern32, "matern52": st.Matern52, "linear": st.Linear}
+
+
+def dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.asarray(a), dtype=dtype, device=DEV)
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def kernel_from(g):
+    return sum(float(v) * KINDS[str(k)]().stretch(float(s)) for k, v, s in zip(g["kinds"], g["variances"], g["scales"]))
+
+
+class eps:
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        self.prev = B.epsilon
+        B.epsilon = self.value
+
+    def __exit__(self, *a):
+        B.epsilon = self.prev
+
+
+def test_native_library_is_the_backend():
+    be = ops.get_backend()
+    assert be.name == "hip" and be.lib.gpk_version() >= 100
+    with open("/proc/self/maps") as f:
+        assert "libgpk.so" in f.read()
+
+
+# ------------------------------------------------------------------ ops vs oracle
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kind", ["eq", "matern12", "matern32", "matern52", "linear", "const"])
+def test_kmat_kinds(dtype, kind):
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal((2, 150, 5)), rng.standard_normal((2, 97, 5))
+    terms = [(kind, 1.7, 0.8)]
+    k = ops.get_backend().kmat(ops.KTerms(terms), dev(x, dtype), dev(y, dtype))
+    assert k.shape == (2, 150, 97)
+    assert rel(k, O.kernel_matrix(terms, x, y)) < (1e-12 if dtype == torch.float64 else 1e-5)
+    ks = ops.get_backend().kmat(ops.KTerms(terms), dev(x, dtype), None, diag_add=0.3, diag_vec=dev(np.ones((2, 150)), dtype))
+    ref = O.kernel_matrix(terms, x) + 1.3 * np.eye(150)
+    assert rel(ks, ref) < (1e-12 if dtype == torch.float64 else 1e-5)
+    assert rel(ops.get_backend().kdiag(ops.KTerms(terms), dev(x, dtype)), O.kernel_diag(terms, x)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", [1, 7, 127, 128, 129, 300, 1000])
+def test_cholesky_solve_logdet(dtype, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 3))
+    k = O.kernel_matrix([("eq", 1.0, 1.0)], x) + 0.5 * np.eye(n)
+    c = Chol.factor_(dev(k, dtype).clone())
+    l_ref = np.linalg.cholesky(k)
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    assert rel(torch.tril(c.l), l_ref) < tol
+    assert abs(float(c.logdet()) - O.logdet_chol(l_ref)) < tol * max(1.0, abs(O.logdet_chol(l_ref)))
+    for nrhs in (1, 3, 40):
+        b = rng.standard_normal((n, nrhs))
+        assert rel(c.solve(dev(b, dtype)), O.solve_lower(l_ref, b)) < tol * 10
+    assert rel(c.iqf_diag(dev(b, dtype)), O.iqf_diag(l_ref, b)) < tol * 10
+
+
+def test_not_positive_definite_raises():
+    a = dev(np.array([[1.0, 2.0], [2.0, 1.0]]))
+    with pytest.raises(torch.linalg.LinAlgError):
+        Chol.factor_(a)
+    with pytest.raises(torch.linalg.LinAlgError):
+        st.Normal(dev(np.array([[1.0, 2.0], [2.0, 1.0]]))).logpdf(dev(np.zeros((2, 1))))
+
+
+def test_empty_inputs():
+    f = st.GP(1, st.EQ())
+    post = f | (f(dev(np.zeros((0, 1)))), dev(np.zeros((0, 1))))
+    assert post.mean is f.mean and post.kernel is f.kernel
+
+
+# ------------------------------------------------------------------ golden fixtures through the API
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("name", ["dense_eq_n256_d8", "dense_eq_n300_d1_c3", "dense_matern12_n200_d3",
+                                  "dense_matern32_n200_d3", "dense_matern52_n333_d5", "dense_eq_linear_n512_d4"])
+def test_dense_golden(name, dtype):
+    g = golden(name + ".npz")
+    tol = TOL[dtype]
+    with eps(EPS[dtype]):
+        f = st.GP(kernel_from(g))
+        x, xs, y = dev(g["x"], dtype), dev(g["xs"], dtype), dev(g["y"], dtype)
+        noise = float(g["noise"])
+        lp = f(x, noise).logpdf(y)
+        assert lp.shape == (() if g["y"].shape[1] == 1 else (g["y"].shape[1],))
+        assert rel(lp.reshape(-1), g["logpdf"]) < tol
+        post = f | (f(x, noise), y[:, :1])
+        mean, vd = post(xs).marginals()
+        assert rel(mean, g["post_mean"]) < tol
+        assert rel(vd, np.maximum(g["post_var_diag"], 0)) < tol
+        assert rel(B.dense(post(xs).var), g["post_var"]) < tol
+        m, lo, hi = post(xs).marginal_credible_bounds()
+        assert torch.all(lo <= m) and torch.all(m <= hi)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_batched_golden(dtype):
+    g = golden("batched_eq_b16_n100_d3.npz")
+    with eps(EPS[dtype]):
+        p = st.GP(kernel_from(g))
+        x, y = dev(g["x"], dtype), dev(g["y"], dtype)
+        lp = p(x, float(g["noise"])).logpdf(y)
+        assert lp.shape == (16,)
+        assert rel(lp, g["logpdf"]) < TOL[dtype]
+        post = p | (p(x, 0.1), y)
+        assert torch.all(post(x, 0.1).logpdf(y) > lp)          # tests/model/test_cases.py:146-155
+        assert p(x, 0.1).sample().shape == (16, 100, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_sparse_golden(dtype):
+    g = golden("sparse_eq_n400_m50_d2.npz")
+    tol = TOL[dtype] * (1 if dtype == torch.float64 else 5)
+    with eps(float(g["epsilon"]) if dtype == torch.float64 else 1e-5):
+        m = st.Measure()
+        f = st.GP(st.EQ(), measure=m)
+        x, z, xs, y = (dev(g[k], dtype) for k in ("x", "z", "xs", "y"))
+        for cls, tag in [(st.PseudoObs, "vfe"), (st.PseudoObsFITC, "fitc"), (st.PseudoObsDTC, "dtc")]:
+            obs = cls(f(z), f(x, float(g["noise"])), y)
+            assert rel(obs.elbo(m).reshape(1), g[f"elbo_{tag}"]) < tol
+            if dtype == torch.float64:
+                assert rel(obs.mu(m), g[f"mu_{tag}"]) < 1e-6
+                assert rel(B.dense(obs.A(m)), g[f"A_{tag}"]) < 1e-6
+            mean, vd = (m | obs)(f)(xs).marginals()
+            assert rel(mean, g[f"post_mean_{tag}"]) < max(tol, 1e-5)
+            assert rel(vd, g[f"post_var_diag_{tag}"]) < max(tol, 1e-5)
+        with pytest.raises(RuntimeError):
+            st.PseudoObs(f(z), (f(x, torch.eye(400, dtype=dtype, device=DEV)), y)).elbo(m)
+
+
+def test_readme_known_answers():
+    with open(os.path.join(ROOT, "tests", "golden", "readme_kats.json")) as fh:
+        k = json.load(fh)
+    f = st.GP(st.EQ())
+    x = dev(k["logpdf_y1"]["x"])
+    assert np.allclose(B.to_numpy(f(x).var), np.array(k["eq_matrix_x012"]["k"]), atol=5e-4)
+    assert abs(float(f(x).logpdf(dev(k["logpdf_y1"]["y"]))) - k["logpdf_y1"]["logpdf"]) < 5e-8
+    assert rel(f(x).logpdf(dev(k["logpdf_y2"]["y"])), k["logpdf_y2"]["logpdf"]) < 2e-8
+    p = k["posterior_20s"]
+    xl = torch.linspace(*p["x_linspace"][:2], int(p["x_linspace"][2]), dtype=torch.float64, device=DEV)
+    pred = (f | (f(xl), xl**2))(dev(p["x_new"]))
+    assert rel(pred.mean[:, 0], p["mean"]) < 1e-6          # kappa(K) ~ 1e12: see SURVEY A.6
+    assert abs(float(B.dense(pred.var)[2, 2]) - p["var"][2][2]) / p["var"][2][2] < 1e-3
+
+
+# ------------------------------------------------------------------ API scenarios on the device
+def test_conditioning_spellings_chain_rule_and_nan():
+    m = st.Measure()
+    p = st.GP(1, st.EQ() + 2 * st.Exp(), measure=m)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x1, x2 = torch.linspace(0, 2, 50, dtype=torch.float64, device=DEV), torch.linspace(1.01, 3, 60, dtype=torch.float64, device=DEV)
+    y = p(torch.cat([x1, x2]), 0.2).sample(generator=g)
+    y1, y2 = y[:50], y[50:]
+    xs = torch.linspace(0, 3, 33, dtype=torch.float64, device=DEV)
+    posts = [m.condition(p(x1, 0.2), y1), m | (p(x1, 0.2), y1), m | st.Obs(p(x1, 0.2), y1)]
+    for post in posts[1:]:
+        assert rel(post(p)(xs).mean, B.to_numpy(posts[0](p)(xs).mean)) < 1e-12
+    chain = p(x1, 0.2).logpdf(y1) + posts[0](p)(x2, 0.2).logpdf(y2)
+    assert abs(float(chain) - float(p(torch.cat([x1, x2]), 0.2).logpdf(y))) < 1e-8 * abs(float(chain))
+    y_nan = y1.clone(); y_nan[:3] = float("nan")
+    a, b = (p | (p(x1, 0.2), y_nan))(xs), (p | (p(x1[3:], 0.2), y1[3:]))(xs)
+    assert rel(a.mean, B.to_numpy(b.mean)) < 1e-10
+    with pytest.raises(ValueError):
+        p | (p(x1), torch.zeros(50, 2, dtype=torch.float64, device=DEV))
+
+
+@pytest.mark.parametrize("cls", [st.PseudoObs, st.PseudoObsFITC, st.PseudoObsDTC])
+def test_pseudo_points_at_inputs_are_exact(cls):
+    m = st.Measure()
+    p = st.GP(st.EQ() + 2 * st.Exp(), measure=m)
+    x = torch.linspace(3, 5, 40, dtype=torch.float64, device=DEV)
+    nz = torch.linspace(0.2, 0.5, 40, dtype=torch.float64, device=DEV)
+    y = p(x, nz).sample()
+    xs = torch.linspace(0, 5, 25, dtype=torch.float64, device=DEV)
+    exact, appr = m | (p(x, nz), y), m | cls(p(x), p(x, nz), y)
+    assert rel(appr(p)(xs).mean, B.to_numpy(exact(p)(xs).mean)) < 1e-7
+    assert rel(B.dense(appr(p)(xs).var), B.to_numpy(exact(p)(xs).var)) < 1e-7
+    assert abs(float(cls(p(x), p(x, nz), y).elbo(m)) - float(p(x, nz).logpdf(y))) < 1e-8 * abs(float(p(x, nz).logpdf(y)))
+
+
+def test_marginals_efficiency_10000_points():
+    p = st.GP(st.EQ())
+    x = torch.linspace(0, 5, 5, dtype=torch.float64, device=DEV)
+    y = p(x, 0.1).sample()
+    p = p | (p(x, 0.1), y)
+    xs = torch.linspace(0, 5, 10_000, dtype=torch.float64, device=DEV)
+    p(xs, 0.2).marginal_credible_bounds()    # warm
+    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    p(xs, 0.2).marginal_credible_bounds()
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 1

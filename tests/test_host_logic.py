@@ -1,0 +1,345 @@
+"""Host-side model logic (GP / Measure / FDD / Normal / Obs / PseudoObs) on the CPU box.
+
+The op backend here is the TEST-ONLY ``OracleBackend`` from conftest.py, so these tests
+pin what the Python layer composes -- lazy resolution, caching, shapes, errors, the
+formulas above the kernels -- mirroring the reference's own tests (cited per test).
+The same scenarios run through the HIP kernels in tests/test_gpu_*.py.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+from scipy.stats import multivariate_normal
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+from stheno_amd import B
+from stheno_amd.matrix import Dense, Diagonal, KernelDense, Zero
+
+from .conftest import golden
+
+pytestmark = pytest.mark.usefixtures("oracle_backend")
+f64 = torch.float64
+
+
+def t(a):
+    return torch.as_tensor(np.asarray(a), dtype=f64)
+
+
+def approx(a, b, atol=1e-8, rtol=1e-8):
+    a = B.to_numpy(a) if torch.is_tensor(a) or hasattr(a, "dense") else np.asarray(a)
+    b = B.to_numpy(b) if torch.is_tensor(b) or hasattr(b, "dense") else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+# ---------------------------------------------------------------- Normal (tests/test_random.py)
+def test_normal_lazy_zero_mean():          # test_random.py:68-83
+    dist = st.Normal(lambda: torch.eye(3, dtype=f64))
+    assert dist.mean_is_zero
+    assert dist._mean == 0 and dist._var is None
+    approx(dist.mean, np.zeros((3, 1)))
+    assert dist._var is not None
+    approx(dist.var, np.eye(3))
+
+
+def test_normal_lazy_nonzero_mean():       # test_random.py:86-96
+    dist = st.Normal(lambda: torch.ones(3, 1, dtype=f64), lambda: torch.eye(3, dtype=f64))
+    assert dist._mean is None and dist._var is None
+    approx(dist.mean, np.ones((3, 1)))
+    assert dist._var is None
+    approx(dist.var, np.eye(3))
+
+
+def test_normal_lazy_var_diag():           # test_random.py:99-108
+    dist = st.Normal(lambda: torch.eye(3, dtype=f64))
+    approx(dist.var_diag, np.ones(3))
+    assert dist._var is not None
+    dist = st.Normal(lambda: torch.eye(3, dtype=f64), var_diag=lambda: 9)
+    assert dist.var_diag == 9 and dist._var is None
+
+
+def test_normal_lazy_mean_var_called_only_when_both_missing():    # test_random.py:111-133
+    calls = []
+
+    def mv():
+        calls.append(1)
+        return torch.full((3, 1), 8.0, dtype=f64), 9 * torch.eye(3, dtype=f64)
+
+    dist = st.Normal(lambda: torch.ones(3, 1, dtype=f64), lambda: torch.eye(3, dtype=f64), mean_var=mv)
+    m, v = dist.mean_var
+    approx(m, 8 * np.ones((3, 1))); approx(v, 9 * np.eye(3)); assert len(calls) == 1
+    dist = st.Normal(lambda: torch.ones(3, 1, dtype=f64), lambda: torch.eye(3, dtype=f64), mean_var=mv)
+    approx(dist.mean, np.ones((3, 1)))
+    m, v = dist.mean_var
+    approx(m, np.ones((3, 1))); approx(v, np.eye(3)); assert len(calls) == 1
+
+
+def test_normal_lazy_mean_var_diag():      # test_random.py:136-158
+    mvd = lambda: (torch.full((3, 1), 8.0, dtype=f64), torch.full((3,), 9.0, dtype=f64))  # noqa: E731
+    dist = st.Normal(lambda: torch.ones(3, 1, dtype=f64), lambda: torch.eye(3, dtype=f64), mean_var_diag=mvd)
+    m, v = dist.marginals()
+    approx(m, 8 * np.ones(3)); approx(v, 9 * np.ones(3))
+    dist = st.Normal(lambda: torch.ones(3, 1, dtype=f64), lambda: torch.eye(3, dtype=f64), mean_var_diag=mvd)
+    approx(dist.var_diag, np.ones(3))
+    m, v = dist.marginals()
+    approx(m, np.ones(3)); approx(v, np.ones(3))
+
+
+@pytest.fixture()
+def normal1():
+    g = torch.Generator().manual_seed(0)
+    mean = torch.randn(3, 1, dtype=f64, generator=g)
+    chol = torch.randn(3, 3, dtype=f64, generator=g)
+    return st.Normal(mean, chol @ chol.T)
+
+
+def test_normal_marginals_and_bounds(normal1):     # test_random.py:165-175
+    mean, var = normal1.marginals()
+    approx(mean, normal1.mean[:, 0]); approx(var, torch.diagonal(B.dense(normal1.var)))
+    m, lo, hi = normal1.marginal_credible_bounds()
+    approx(lo, normal1.mean[:, 0] - 1.96 * torch.diagonal(B.dense(normal1.var)) ** 0.5)
+    approx(hi, normal1.mean[:, 0] + 1.96 * torch.diagonal(B.dense(normal1.var)) ** 0.5)
+
+
+def test_normal_logpdf_vs_scipy(normal1):          # test_random.py:185-192
+    B.epsilon = 0.0
+    try:
+        sp = multivariate_normal(B.to_numpy(normal1.mean)[:, 0], B.to_numpy(normal1.var))
+        x = torch.randn(3, 10, dtype=f64, generator=torch.Generator().manual_seed(1))
+        approx(normal1.logpdf(x), sp.logpdf(B.to_numpy(x).T), rtol=1e-6)
+        assert normal1.logpdf(torch.ones(3, 1, dtype=f64)).shape == ()
+        assert normal1.logpdf(torch.ones(3, 2, dtype=f64)).shape == (2,)
+        approx(normal1.entropy(), sp.entropy(), rtol=1e-8)
+    finally:
+        B.epsilon = 1e-12
+
+
+def test_normal_logpdf_missing_data(normal1):      # test_random.py:195-204
+    x = torch.randn(3, 1, dtype=f64)
+    x[1] = float("nan")
+    sub = st.Normal(normal1.mean[[0, 2]], B.dense(normal1.var)[[0, 2]][:, [0, 2]])
+    approx(normal1.logpdf(x), sub.logpdf(x[[0, 2]]))
+
+
+# ---------------------------------------------------------------- FDD (tests/model/test_fdd.py)
+def test_fdd_noise_typing_and_var():       # test_fdd.py:15-82, test_gp.py:57-92
+    p = st.GP(st.EQ())
+    x = t(np.linspace(0, 5, 5))
+    assert isinstance(p(x).noise, Zero)
+    assert isinstance(p(x, 0.1).noise, Diagonal)
+    approx(p(x, 0.1).noise.diag(), 0.1 * np.ones(5))
+    assert isinstance(p(x, t(np.full(5, 0.2))).noise, Diagonal)
+    assert isinstance(p(x, 0.3 * torch.eye(5, dtype=f64)).noise, Dense)
+    d = p(x, 1.0)
+    assert d._var is None and d._mean is None            # nothing computed at construction
+    approx(d.var, O.kernel_matrix([("eq", 1, 1)], np.linspace(0, 5, 5)) + np.eye(5))
+    approx(d.mean, np.zeros((5, 1)))
+    assert isinstance(d.var, KernelDense)
+    assert p(x).dtype == f64
+
+
+def test_fdd_properties_under_posterior():  # test_fdd.py:111-134
+    p = st.GP(1, st.EQ())
+    x = t(np.linspace(0, 5, 5))
+    y = p(x, 0.1).sample()
+    post = p | (p(x, 0.1), y)
+    xs = t(np.linspace(0, 5, 10))
+    fdd = post(xs, 0.2)
+    mean, var = fdd.mean, B.dense(fdd.var)
+    approx(post(xs, 0.2).var_diag, torch.diagonal(var))
+    m2, v2 = post(xs, 0.2).mean_var
+    approx(m2, mean); approx(v2, var)
+    m3, vd3 = post(xs, 0.2).marginals()
+    approx(m3, mean[:, 0]); approx(vd3, torch.diagonal(var))
+
+
+def test_marginals_do_not_form_the_covariance():   # test_gp.py:201-211
+    p = st.GP(st.EQ())
+    x = t(np.linspace(0, 5, 5))
+    y = p(x, 0.1).sample()
+    p = p | (p(x, 0.1), y)
+    xs = t(np.linspace(0, 5, 10_000))
+    start = time.time()
+    p(xs, 0.2).marginal_credible_bounds()
+    assert time.time() - start < 1
+
+
+# ---------------------------------------------------------------- conditioning (tests/model/test_model.py)
+def test_conditioning_spellings_agree():   # test_model.py:123-178
+    m = st.Measure()
+    p = st.GP(1, st.EQ(), measure=m)
+    x = t(np.linspace(0, 2, 3))
+    y = p(x, 0.1).sample()
+    xs = t(np.linspace(0, 5, 5))
+    posts = [m.condition(p(x, 0.1), y), m.condition((p(x, 0.1), y)), m | (p(x, 0.1), y), m | ((p(x, 0.1), y),),
+             m | st.Obs(p(x, 0.1), y), m | st.Obs((p(x, 0.1), y))]
+    ref_m, ref_v = posts[0](p)(xs).mean, B.dense(posts[0](p)(xs).var)
+    for post in posts[1:]:
+        approx(post(p)(xs).mean, ref_m); approx(post(p)(xs).var, ref_v)
+    post = m | (p(x, 0.1), y)
+    assert isinstance(post(p(x, 0.1)), st.FDD)
+    approx(post(p(x, 0.1)).var, post(p)(x, 0.1).var)
+    # agreement with the oracle
+    om, ov, _ = O.gp_posterior([("eq", 1, 1)], B.to_numpy(x), 0.1, B.to_numpy(y) - 1.0, B.to_numpy(xs))
+    approx(ref_m[:, 0], om + 1.0); approx(ref_v, ov)
+
+
+def test_conditioning_interpolates_and_chains():   # test_model.py:211-228
+    p = st.GP(1, st.EQ())
+    x = t(np.linspace(0, 5, 10))
+    y = p(x).sample()
+    approx(p.condition(p(x), y).mean(x), y, atol=1e-5)
+    p1 = p | (p(x), y)
+    x2 = t(np.linspace(10, 20, 10))
+    y2 = p1(x2).sample()
+    p2 = p1 | (p1(x2), y2)
+    approx(p2.mean(x2), y2, atol=1e-5)
+    approx(p2.mean(x), y, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(0,), (0, 1)])
+def test_conditioning_on_nothing_returns_prior_objects(shape):   # test_model.py:198-208
+    p = st.GP(1, st.EQ())
+    x = torch.zeros(*shape, dtype=f64)
+    post = p | (p(x), torch.zeros(0, 1, dtype=f64))
+    assert post.mean is p.mean and post.kernel is p.kernel
+
+
+def test_conditioning_missing_data_and_shape_check():   # test_model.py:231-246
+    p = st.GP(1, st.EQ())
+    x = t(np.linspace(0, 5, 10))
+    y = p(x, 0.1).sample()
+    y_nan = y.clone(); y_nan[:3] = float("nan")
+    xs = t(np.linspace(0, 5, 7))
+    a, b = (p | (p(x, 0.1), y_nan))(xs), (p | (p(x[3:], 0.1), y[3:]))(xs)
+    approx(a.mean, b.mean); approx(a.var, b.var)
+    f = st.GP(1, st.EQ())
+    xx = torch.randn(2, dtype=f64)
+    f | (f(xx), torch.randn(2, 1, dtype=f64))
+    with pytest.raises(ValueError):
+        f | (f(xx), torch.randn(2, 2, dtype=f64))
+
+
+def test_chain_rule_of_logpdfs():          # test_model.py:391-398 (single-process form)
+    m = st.Measure()
+    p = st.GP(st.EQ() + 2 * st.Exp(), measure=m)
+    x1, x2 = t(np.linspace(0, 2, 5)), t(np.linspace(1.1, 3, 6))
+    y = p(torch.cat([x1, x2]), 0.2).sample()
+    y1, y2 = y[:5], y[5:]
+    d2 = m | (p(x1, 0.2), y1)
+    approx(p(x1, 0.2).logpdf(y1) + d2(p)(x2, 0.2).logpdf(y2), p(torch.cat([x1, x2]), 0.2).logpdf(y))
+    approx(m.logpdf(p(x1, 0.2), y1), p(x1, 0.2).logpdf(y1))
+    approx(m.logpdf(st.Obs(p(x1, 0.2), y1)), p(x1, 0.2).logpdf(y1))
+
+
+# ---------------------------------------------------------------- pseudo-points (test_model.py:249-332)
+@pytest.mark.parametrize("cls", [st.PseudoObs, st.PseudoObsFITC, st.PseudoObsDTC])
+@pytest.mark.parametrize("noise_form", ["scalar", "vector", "Diagonal"])
+def test_pseudoobs_exact_when_inducing_equals_inputs(cls, noise_form):
+    m = st.Measure()
+    p = st.GP(1, st.EQ() + 2 * st.Exp(), measure=m)
+    x = t(np.linspace(3, 5, 6))
+    nz = {"scalar": 0.3, "vector": t(np.linspace(0.2, 0.5, 6)), "Diagonal": Diagonal(t(np.linspace(0.2, 0.5, 6)))}[noise_form]
+    y = p(x, nz).sample()
+    xs = t(np.linspace(0, 5, 5))
+    exact, approx_post = m | (p(x, nz), y), m | cls(p(x), p(x, nz), y)
+    approx(approx_post(p)(xs).mean, exact(p)(xs).mean, atol=1e-7)
+    approx(approx_post(p)(xs).var, exact(p)(xs).var, atol=1e-7)
+    m1, v1 = approx_post(p)(xs).marginals()
+    approx(v1, torch.diagonal(B.dense(exact(p)(xs).var)), atol=1e-7)
+    approx(cls(p(x), p(x, nz), y).elbo(m), m.logpdf(st.Obs(p(x, nz), y)))
+    approx(m.logpdf(cls(p(x), p(x, nz), y)), p(x, nz).logpdf(y))
+    obs = cls(p(x), p(x, nz), y)
+    for name in ["K_z", "elbo", "mu", "A"]:
+        assert getattr(obs, name)(m) is getattr(obs, name)(m)
+    with pytest.raises(RuntimeError):
+        cls(p(x), (p(x, B.dense(p(x).var)), y)).elbo(m)
+
+
+def test_sparse_golden_through_the_api():
+    g = golden("sparse_eq_n400_m50_d2.npz")
+    B.epsilon = float(g["epsilon"])
+    try:
+        m = st.Measure()
+        f = st.GP(st.EQ(), measure=m)
+        x, z, xs, y = (t(g[k]) for k in ("x", "z", "xs", "y"))
+        for cls, tag in [(st.PseudoObs, "vfe"), (st.PseudoObsFITC, "fitc"), (st.PseudoObsDTC, "dtc")]:
+            obs = cls(f(z), f(x, float(g["noise"])), y)
+            approx(obs.elbo(m), g[f"elbo_{tag}"][0], rtol=1e-9)
+            approx(obs.mu(m), g[f"mu_{tag}"], atol=1e-7)
+            approx(obs.A(m), g[f"A_{tag}"], rtol=1e-7, atol=1e-7)
+            mean, vd = (m | obs)(f)(xs).marginals()
+            approx(mean, g[f"post_mean_{tag}"], atol=1e-7)
+            approx(vd, g[f"post_var_diag_{tag}"], atol=1e-7)
+        assert st.SparseObs is st.PseudoObs and st.SparseObservations is st.PseudoObs
+    finally:
+        B.epsilon = 1e-12
+
+
+# ---------------------------------------------------------------- golden / batched / misc
+@pytest.mark.parametrize("name", ["dense_eq_n256_d8", "dense_eq_n300_d1_c3", "dense_matern12_n200_d3",
+                                  "dense_matern32_n200_d3", "dense_matern52_n333_d5", "dense_eq_linear_n512_d4"])
+def test_dense_golden_through_the_api(name):
+    g = golden(name + ".npz")
+    kinds = {"eq": st.EQ, "matern12": st.Matern12, "matern32": st.Matern32, "matern52": st.Matern52, "linear": st.Linear}
+    k = sum(float(v) * kinds[str(kd)]().stretch(float(s)) for kd, v, s in zip(g["kinds"], g["variances"], g["scales"]))
+    f = st.GP(k)
+    x, xs, y = t(g["x"]), t(g["xs"]), t(g["y"])
+    approx(np.atleast_1d(B.to_numpy(f(x, float(g["noise"])).logpdf(y))), g["logpdf"], rtol=1e-10)
+    post = f | (f(x, float(g["noise"])), y[:, :1])
+    mean, vd = post(xs).marginals()
+    approx(mean, g["post_mean"], atol=1e-9); approx(vd, np.maximum(g["post_var_diag"], 0), atol=1e-9)
+    approx(post(xs).var, g["post_var"], atol=1e-9)
+    approx(f.kernel.elwise(x)[:, 0], g["kdiag"]); approx(f.kernel(x[:8], xs[:8]), g["k_corner"])
+
+
+def test_batched_shapes_and_values():      # tests/model/test_cases.py:134-155, README.md:744-766
+    g = golden("batched_eq_b16_n100_d3.npz")
+    p = st.GP(2 * st.EQ().stretch(0.5))
+    x, y = t(g["x"]), t(g["y"])
+    lp = p(x, 0.1).logpdf(y)
+    assert lp.shape == (16,)
+    approx(lp, g["logpdf"], rtol=1e-10)
+    ys = p(x, 0.1).sample()
+    assert ys.shape == (16, 100, 1)
+    post = p | (p(x, 0.1), y)
+    assert torch.all(post(x, 0.1).logpdf(y) > lp)
+
+
+def test_measures_names_and_defaults():    # test_model.py:62-121
+    m = st.Measure()
+    p1, p2 = st.GP(st.EQ(), measure=m), st.GP(st.EQ(), name="two", measure=m)
+    p1.name = "one"
+    assert m["one"] is p1 and m["two"] is p2 and p1.name == "one" and m[p2] == "two"
+    with pytest.raises(RuntimeError):
+        p1.name = "two"
+    with st.Measure() as prior:
+        q = st.GP(st.EQ())
+        assert q.measure is prior
+    assert st.Measure.default is None
+    assert m.kernels[p1, p2] == st.ZeroKernel()
+    with pytest.raises(AssertionError):
+        p1 + q
+    s = p1 + p2
+    approx(s(t([0.0, 1.0])).var, 2 * O.kernel_matrix([("eq", 1, 1)], np.array([0.0, 1.0])))
+    approx((2 * p1)(t([0.0, 1.0])).var, 4 * O.kernel_matrix([("eq", 1, 1)], np.array([0.0, 1.0])))
+
+
+def test_non_positive_definite_raises():
+    with pytest.raises(torch.linalg.LinAlgError):
+        st.Normal(torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=f64)).logpdf(torch.zeros(2, 1, dtype=f64))
+
+
+def test_epsilon_is_read_at_factorisation_time():    # README.md:820-831
+    x = t(np.linspace(0, 2, 10))
+    f = st.GP(st.EQ())
+    y = x**2
+    mean = (f | (f(x), y))(t([1.0, 2.0, 3.0])).mean
+    approx(mean[:, 0], [1.00000068, 3.99999999, 8.4825932], rtol=2e-7)
+    B.epsilon = 1e-8
+    try:
+        mean8 = (f | (f(x), y))(t([1.0, 2.0, 3.0])).mean
+    finally:
+        B.epsilon = 1e-12
+    assert abs(float(mean8[2, 0]) - 8.4825932) > 1e-3
