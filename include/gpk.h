@@ -155,8 +155,8 @@ int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha,
  * gpk_prof_stop every MFMA GEMM launch of this process is bracketed by HIP events on its
  * launch stream; gpk_prof_stop synchronises those events and returns the summed duration,
  * launch count and ALGORITHMIC flops (2mnk; mnk for a lower-only symmetric update) of the
- * launches of one kernel variant: 8*(f64) + 4*(a_kmajor) + 2*(b_kmajor) + 1*(bounds-checked
- * kernel), or -1 for all.  Not thread-safe; off by default; not used by the product path. */
+ * launches of one kernel variant: 16*(64x64-tile kernel) + 8*(f64) + 4*(a_kmajor) + 2*(b_kmajor)
+ * + 1*(bounds-checked kernel), or -1 for all.  Not thread-safe; off by default; not used by the product path. */
 int gpk_prof_start(void);
 int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops);
 

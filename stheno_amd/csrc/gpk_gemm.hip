@@ -34,9 +34,9 @@
 
 namespace {
 
-constexpr int OP_BYTES = 18432;               // one operand tile, either LDS image
-constexpr int STAGE_BYTES = 2 * OP_BYTES;     // A + B
-constexpr int RMAJ_PITCH = 144;               // elements per k-row of the row-contiguous image
+// One operand tile of TS rows in LDS, either image: k-contiguous [TS][128 B] or
+// row-contiguous [BK][TS + 16] (BK * sizeof(T) = 128 B), so (TS + 16) * 128 bytes cover both.
+constexpr int op_bytes(int ts) { return (ts + 16) * 128; }
 
 template <typename T>
 struct GemmArgs {
@@ -91,15 +91,15 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
 }
 
 // ---- global -> registers ---------------------------------------------------
-template <typename T, bool KMAJ, bool EDGE>
-__device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[4], const T* __restrict__ base,
+template <typename T, int TS, bool KMAJ, bool EDGE>
+__device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], const T* __restrict__ base,
                                       int64_t ld, int r0, int k0, int R, int K, int tid) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
     if (KMAJ) {
         const int c = tid & 7, rr0 = tid >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TS / 32; ++i) {
             const int row = r0 + rr0 + 32 * i;
             const int k = k0 + c * VEC;
             const T* p = base + (int64_t)row * ld + k;
@@ -111,9 +111,9 @@ __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[4], const T
             }
         }
     } else {
-        constexpr int CPR = GPK_TILE / VEC;   // 16-byte chunks per k-row
+        constexpr int CPR = TS / VEC;   // 16-byte chunks per k-row
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TS / 32; ++i) {
             const int id = tid + 256 * i;
             const int krow = id / CPR, cc = id % CPR;
             const int k = k0 + krow;
@@ -130,25 +130,25 @@ __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[4], const T
 }
 
 // ---- registers -> LDS --------------------------------------------------------
-template <typename T, bool KMAJ>
-__device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_t (&r)[4], int tid) {
+template <typename T, int TS, bool KMAJ>
+__device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_t (&r)[TS / 32], int tid) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
     if (KMAJ) {
         const int c = tid & 7, rr0 = tid >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TS / 32; ++i) {
             const int rr = rr0 + 32 * i;
             const int off = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4);
             *reinterpret_cast<vec_t*>(lds + off) = r[i];
         }
     } else {
-        constexpr int CPR = GPK_TILE / VEC;
+        constexpr int CPR = TS / VEC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TS / 32; ++i) {
             const int id = tid + 256 * i;
             const int krow = id / CPR, cc = id % CPR;
-            const int off = krow * (RMAJ_PITCH * (int)sizeof(T)) + cc * 16;
+            const int off = krow * ((TS + 16) * (int)sizeof(T)) + cc * 16;
             *reinterpret_cast<vec_t*>(lds + off) = r[i];
         }
     }
@@ -156,7 +156,7 @@ __device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_
 
 // ---- LDS -> MFMA operand -----------------------------------------------------
 // rowbase: first tile row of this 16-row fragment; lr = lane & 15; k = element index in chunk.
-template <typename T, bool KMAJ>
+template <typename T, int TS, bool KMAJ>
 __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int k, int swz) {
     constexpr int VEC = Traits<T>::VEC;
     int off;
@@ -164,18 +164,21 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
         const int chunk = k / VEC, within = k % VEC;
         off = (rowbase + lr) * 128 + ((chunk ^ swz) << 4) + within * (int)sizeof(T);
     } else {
-        off = k * (RMAJ_PITCH * (int)sizeof(T)) + (rowbase + lr) * (int)sizeof(T);
+        off = k * ((TS + 16) * (int)sizeof(T)) + (rowbase + lr) * (int)sizeof(T);
     }
     return *reinterpret_cast<const T*>(lds + off);
 }
 
-template <typename T, bool A_KMAJ, bool B_KMAJ, bool EDGE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs<T> p) {
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE>
+__global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
+    constexpr int FR = TS / 32;          // 16x16 fragments per wave in each direction
+    constexpr int WT = TS / 2;           // wave sub-tile edge
+    constexpr int OPB = op_bytes(TS), STAGE = 2 * OPB;
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
     int ti, tj;
     if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
@@ -192,94 +195,94 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs<T> p) {
     const T* __restrict__ B = p.B + b * p.sB + b2 * p.sB2;
     T* __restrict__ C = p.C + b * p.sC + b2 * p.sC2;
 
-    const int m0 = ti * GPK_TILE, n0 = tj * GPK_TILE;
+    const int m0 = ti * TS, n0 = tj * TS;
 
-    acc_t acc[4][4];
+    acc_t acc[FR][FR];
     if (p.has_beta) {
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
+        for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-            for (int fj = 0; fj < 4; ++fj)
+            for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * 64 + fi * 16 + Traits<T>::crow(lane, i);
-                    const int col = n0 + wn * 64 + fj * 16 + lr;
+                    const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
+                    const int col = n0 + wn * WT + fj * 16 + lr;
                     T v = T(0);
                     if (!EDGE || (row < p.M && col < p.N)) v = C[(int64_t)row * p.ldc + col];
                     acc[fi][fj][i] = v * p.beta_over_alpha;
                 }
     } else {
 #pragma unroll
-        for (int fi = 0; fi < 4; ++fi)
+        for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-            for (int fj = 0; fj < 4; ++fj)
+            for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[fi][fj][i] = T(0);
     }
 
     const int nk = (p.K + BK - 1) / BK;
-    vec_t ra[4], rb[4];
+    vec_t ra[FR], rb[FR];
 
-    gload<T, A_KMAJ, EDGE>(ra, A, p.lda, m0, 0, p.M, p.K, tid);
-    gload<T, B_KMAJ, EDGE>(rb, B, p.ldb, n0, 0, p.N, p.K, tid);
-    sstore<T, A_KMAJ>(smem, ra, tid);
-    sstore<T, B_KMAJ>(smem + OP_BYTES, rb, tid);
+    gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, 0, p.M, p.K, tid);
+    gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, 0, p.N, p.K, tid);
+    sstore<T, TS, A_KMAJ>(smem, ra, tid);
+    sstore<T, TS, B_KMAJ>(smem + OPB, rb, tid);
     __syncthreads();
 
     for (int kc = 0; kc < nk; ++kc) {
-        const char* sA = smem + (kc & 1) * STAGE_BYTES;
-        const char* sB = sA + OP_BYTES;
+        const char* sA = smem + (kc & 1) * STAGE;
+        const char* sB = sA + OPB;
         const bool more = (kc + 1 < nk);
         if (more) {
-            gload<T, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid);
-            gload<T, B_KMAJ, EDGE>(rb, B, p.ldb, n0, (kc + 1) * BK, p.N, p.K, tid);
+            gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid);
+            gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, (kc + 1) * BK, p.N, p.K, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            T a[4], bb[4];
+            T a[FR], bb[FR];
             const int k = kk * 4 + kq;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                a[f] = fragread<T, A_KMAJ>(sA, wm * 64 + f * 16, lr, k, swz);
-                bb[f] = fragread<T, B_KMAJ>(sB, wn * 64 + f * 16, lr, k, swz);
+            for (int f = 0; f < FR; ++f) {
+                a[f] = fragread<T, TS, A_KMAJ>(sA, wm * WT + f * 16, lr, k, swz);
+                bb[f] = fragread<T, TS, B_KMAJ>(sB, wn * WT + f * 16, lr, k, swz);
             }
 #pragma unroll
-            for (int fi = 0; fi < 4; ++fi)
+            for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-                for (int fj = 0; fj < 4; ++fj)
+                for (int fj = 0; fj < FR; ++fj)
                     acc[fi][fj] = Traits<T>::mfma(a[fi], bb[fj], acc[fi][fj]);
         }
         if (more) {
-            char* dA = smem + ((kc + 1) & 1) * STAGE_BYTES;
-            sstore<T, A_KMAJ>(dA, ra, tid);
-            sstore<T, B_KMAJ>(dA + OP_BYTES, rb, tid);
+            char* dA = smem + ((kc + 1) & 1) * STAGE;
+            sstore<T, TS, A_KMAJ>(dA, ra, tid);
+            sstore<T, TS, B_KMAJ>(dA + OPB, rb, tid);
         }
         __syncthreads();
     }
 
 #pragma unroll
-    for (int fi = 0; fi < 4; ++fi)
+    for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-        for (int fj = 0; fj < 4; ++fj)
+        for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int row = m0 + wm * 64 + fi * 16 + Traits<T>::crow(lane, i);
-                const int col = n0 + wn * 64 + fj * 16 + lr;
+                const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
+                const int col = n0 + wn * WT + fj * 16 + lr;
                 if (!EDGE || (row < p.M && col < p.N))
                     C[(int64_t)row * p.ldc + col] = p.alpha * acc[fi][fj][i];
             }
 }
 
-template <typename T, bool EDGE>
+template <typename T, int TS, bool EDGE>
 void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, const GemmArgs<T>& args) {
     if (a_kmaj && b_kmaj)
-        hipLaunchKernelGGL((gemm_kernel<T, true, true, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, true, true, EDGE>), grid, dim3(256), 0, stream, args);
     else if (a_kmaj && !b_kmaj)
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, true, false, EDGE>), grid, dim3(256), 0, stream, args);
     else if (!a_kmaj && b_kmaj)
-        hipLaunchKernelGGL((gemm_kernel<T, false, true, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, false, true, EDGE>), grid, dim3(256), 0, stream, args);
     else
-        hipLaunchKernelGGL((gemm_kernel<T, false, false, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, false, false, EDGE>), grid, dim3(256), 0, stream, args);
 }
 
 // ---- measurement hook: HIP events around every GEMM launch (opt-in, see gpk.h) ----
@@ -309,7 +312,16 @@ struct Prof {
 };
 Prof g_prof;
 
+int64_t g_small_tile_below = 256;   // tuning knob (gpk_debug_set(1, v))
+int g_swizzle_from = 1024;          // tuning knob (gpk_debug_set(2, v))
+
 }  // namespace
+
+// Development aid (not in include/gpk.h): runtime tuning knobs for A/B runs on the GPU box.
+extern "C" void gpk_debug_set(int key, int64_t value) {
+    if (key == 1) g_small_tile_below = value;
+    if (key == 2) g_swizzle_from = (int)value;
+}
 
 extern "C" int gpk_prof_start(void) {
     for (auto& s : g_prof.used) g_prof.pool.push_back(s);
@@ -318,7 +330,7 @@ extern "C" int gpk_prof_start(void) {
     return GPK_OK;
 }
 
-// variant: 8*(f64) + 4*(A k-major) + 2*(B k-major) + 1*(edge-checked kernel), or -1 for all
+// variant: 16*(64x64 tiles) + 8*(f64) + 4*(A k-major) + 2*(B k-major) + 1*(edge-checked kernel), or -1 for all
 extern "C" int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops) {
     g_prof.on = false;
     double ms = 0, fl = 0;
@@ -359,15 +371,23 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.alpha = alpha;
     g.has_beta = (beta != T(0)) ? 1 : 0;
     g.beta_over_alpha = g.has_beta ? beta / alpha : T(0);
-    g.tiles_m = (int)gpk_cdiv(M, GPK_TILE);
-    g.tiles_n = (int)gpk_cdiv(N, GPK_TILE);
+    // Tile choice: 128x128 unless that grid cannot even give every CU one workgroup; then
+    // 64x64 tiles (4x the workgroups) -- the narrow panel/merge/solve GEMMs of the path.
+    int ts = 128;
+    {
+        const int64_t tm = gpk_cdiv(M, 128), tn = gpk_cdiv(N, 128);
+        const int64_t t128 = (lower_only && tm == tn ? tm * (tm + 1) / 2 : tm * tn) * batch * batch2;
+        if (t128 < g_small_tile_below) ts = 64;
+    }
+    g.tiles_m = (int)gpk_cdiv(M, ts);
+    g.tiles_n = (int)gpk_cdiv(N, ts);
     g.lower_only = lower_only ? 1 : 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
                                      : (int64_t)g.tiles_m * g.tiles_n;
     int64_t gridx;
-    g.swizzle = (total >= 1024) ? 1 : 0;
+    g.swizzle = (total >= g_swizzle_from) ? 1 : 0;
     g.n_super = 0;
     g.SN = 1;
     if (g.swizzle) {
@@ -382,19 +402,26 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&
                          (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
                          (sA2 % VEC == 0) && (sB2 % VEC == 0);
-    const bool edge = !aligned || (M % GPK_TILE) || (N % GPK_TILE) || (K % BK);
+    const bool edge = !aligned || (M % ts) || (N % ts) || (K % BK);
 
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
     ProfSlot* slot = nullptr;
     if (g_prof.on) {
         // useful (algorithmic) flops: a lower-only update counts the symmetric half
         const double fl = (lower_only ? 1.0 : 2.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
-        slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0), fl, stream);
+        slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), fl, stream);
     }
-    if (edge)
-        launch_layout<T, true>(a_kmaj, b_kmaj, grid, stream, g);
-    else
-        launch_layout<T, false>(a_kmaj, b_kmaj, grid, stream, g);
+    if (ts == 128) {
+        if (edge)
+            launch_layout<T, 128, true>(a_kmaj, b_kmaj, grid, stream, g);
+        else
+            launch_layout<T, 128, false>(a_kmaj, b_kmaj, grid, stream, g);
+    } else {
+        if (edge)
+            launch_layout<T, 64, true>(a_kmaj, b_kmaj, grid, stream, g);
+        else
+            launch_layout<T, 64, false>(a_kmaj, b_kmaj, grid, stream, g);
+    }
     if (slot) g_prof.end(slot, stream);
     GPK_CHECK_LAUNCH();
     return GPK_OK;

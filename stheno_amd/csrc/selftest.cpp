@@ -119,7 +119,7 @@ static void test_gemm_case(bool ak, bool bk, int M, int N, int K, double alpha, 
     for (int b = 0; b < batch; ++b)
         for (int m = 0; m < M; ++m)
             for (int n = 0; n < N; ++n) {
-                if (lower && (n / 128) > (m / 128)) continue;   // tile not computed
+                if (lower && n > m) { ref[b * sC + m * ldc + n] = (double)got[b * sC + m * ldc + n]; continue; }   // above the diagonal: unspecified
                 double s = 0;
                 for (int k = 0; k < K; ++k) {
                     const double a = ak ? A[b * sA + m * lda + k] : A[b * sA + k * lda + m];
@@ -548,6 +548,7 @@ static void profile_one(int n, int nbo, int reps) {
 }
 
 extern "C" void gpk_debug_diag_prof(long long* dev_buf);
+extern "C" void gpk_debug_set(int key, int64_t value);
 template <typename T>
 static void diag_phase_profile(int n) {
     const int nblk = (n + 127) / 128;
@@ -585,7 +586,11 @@ int main(int argc, char** argv) {
     printf("device: %s  arch=%s  CUs=%d  clock=%d MHz  gpk_version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, gpk_version());
     if (!only_perf) {
         test_probe<double>(); test_probe<float>();
+        gpk_debug_set(1, 0);                 // force the 128x128-tile kernels
         test_gemm<double>(); test_gemm<float>();
+        gpk_debug_set(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
+        test_gemm<double>(); test_gemm<float>();
+        gpk_debug_set(1, 256);               // library default
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_misc<double>(); test_misc<float>();

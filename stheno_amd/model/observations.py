@@ -6,7 +6,7 @@ import torch
 
 from .. import kernels as _k
 from .. import ops
-from ..matrix import AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, config
+from ..matrix import AbstractMatrix, ChainChol, Chol, Dense, Diagonal, FactoredDense, KernelDense, Zero, config
 from .fdd import FDD, take
 
 __all__ = [
@@ -108,14 +108,6 @@ class Observations(AbstractObservations):
         )
 
 
-class _FactoredDense(Dense):
-    """A ``Dense`` whose Cholesky factor is already known."""
-
-    def __init__(self, mat, chol):
-        super().__init__(mat)
-        self._chol = chol
-
-
 class AbstractPseudoObservations(AbstractObservations):
     """Observations through inducing points ``u`` (``observations.py:171-336``)."""
 
@@ -152,15 +144,23 @@ class AbstractPseudoObservations(AbstractObservations):
         return self._mu[id(measure)]
 
     def A(self, measure):
-        """``L_z A L_z^T`` (``observations.py:239-253,323``) as a ``Dense``."""
+        """``L_z A L_z^T`` (``observations.py:239-253,323``).  Its Cholesky factor is
+        ``L_z L_A`` -- already known -- so the returned ``Dense`` carries that factor in
+        product form and only forms the M x M product if its entries are asked for."""
         if id(measure) not in self._A:
             self.elbo(measure)
             be = ops.get_backend()
             p = self._parts[id(measure)]
-            l_z = p["K_z"].chol().lower()
-            a_full = be.symmetrize_(be.copy(p["A"]))
-            w = be.gemm(a_full, l_z, a_kmajor=True, b_kmajor=True)          # A L_z^T
-            self._A[id(measure)] = Dense(be.gemm(l_z, w, a_kmajor=True, b_kmajor=False))
+            chol_z = p["K_z"].chol()
+
+            def build():
+                l_z = chol_z.lower()
+                a_full = be.symmetrize_(be.copy(p["A"]))
+                w = be.gemm(a_full, l_z, a_kmajor=True, b_kmajor=True)          # A L_z^T
+                return be.gemm(l_z, w, a_kmajor=True, b_kmajor=False)           # L_z (A L_z^T)
+
+            a = p["A"]
+            self._A[id(measure)] = FactoredDense(build, ChainChol(chol_z, p["chol_A"]), a.shape, a.dtype, a.device)
         return self._A[id(measure)]
 
     def posterior_kernel(self, measure, p_i, p_j):
