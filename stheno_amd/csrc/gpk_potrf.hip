@@ -39,7 +39,7 @@ struct DiagArgs {
 #define PROF_MARK(i)                                                            \
     do {                                                                        \
         if (p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0)           \
-            p.prof[(p.off / GPK_DB) * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
+            p.prof[(p.off / GPK_DB) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
 
 // sqrt(d) and 1/sqrt(d) together, Goldschmidt from the hardware rsq estimate:
@@ -96,6 +96,163 @@ __device__ __forceinline__ typename Traits<T>::acc_t lds_mm_nn(const T* S, int a
         acc = Traits<T>::mfma(a, b, acc);
     }
     return acc;
+}
+
+// ---- pieces of the in-LDS factorisation of the 128x128 block (S: [128][LDP]) ----
+
+// 16x16 Cholesky of the micro-block at (c0, c0) by ONE wave: lane lr owns row lr (the four
+// 16-lane groups compute redundantly), pivots and multipliers travel through v_readlane.
+template <typename T>
+__device__ __forceinline__ void micro_chol(T* S, T* rdiag, int c0, int lane, int lr, int* info, int off) {
+    T a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = S[(c0 + lr) * LDP + c0 + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const T d = lane_bcast(a[j], j);
+        if (!(d > T(0)) && lane == 0) atomicCAS(info, 0, off + c0 + j + 1);
+        T ljj, rinv;
+        sqrt_rsqrt(d, ljj, rinv);
+        if (lr == j)
+            a[j] = ljj;
+        else
+            a[j] *= rinv;
+        if (lane == j) rdiag[c0 + j] = rinv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            const T lcj = lane_bcast(a[j], c);
+            a[c] -= a[j] * lcj;
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[(c0 + lr) * LDP + c0 + c] = a[c];
+    }
+}
+
+// micro-panel TRSM: one thread per row below the micro-block at (c0, c0); right-looking, so
+// the 15 - j updates after each pivot are independent (dependency chain of 16, not 120)
+template <typename T>
+__device__ __forceinline__ void micro_trsm(T* S, const T* rdiag, int c0, int tid) {
+    const int row = c0 + 16 + tid;
+    if (row < GPK_DB) {
+        T x[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) x[c] = S[row * LDP + c0 + c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            x[j] *= rdiag[c0 + j];
+#pragma unroll
+            for (int c = j + 1; c < 16; ++c) x[c] -= x[j] * S[(c0 + c) * LDP + c0 + j];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[row * LDP + c0 + c] = x[c];
+    }
+}
+
+// One level of the recursive-doubling inversion, pair size 2H (H = 16, 32, 64), both passes.
+// Each wave owns PER = (128 / 2H) * (H/16)^2 / 4 output tiles and advances them together:
+// per 16-wide k-block all operands are read first, then the 4 * PER MFMAs are issued.
+template <typename T, int H>
+__device__ __forceinline__ void invert_level(T* S, int wave, int lane, int lr, int kq) {
+    typedef typename Traits<T>::acc_t acc_t;
+    constexpr int HB = H / 16, TPP = HB * HB, NPAIR = GPK_DB / (2 * H), PER = NPAIR * TPP / 4;
+    int ti[PER], tj[PER], o[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int item = wave * PER + q;
+        const int t = item % TPP;
+        ti[q] = t / HB;
+        tj[q] = t % HB;
+        o[q] = (item / TPP) * 2 * H;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        acc_t acc[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = T(0);
+#pragma unroll
+        for (int kb = 0; kb < HB; ++kb) {
+            T av[PER][4], bv[PER][4];
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 16 * kb + 4 * kk + kq;
+                    if (pass == 0) {   // T = C * Ainv
+                        av[q][kk] = S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + k];
+                        bv[q][kk] = S[(o[q] + k) * LDP + o[q] + 16 * tj[q] + lr];
+                    } else {           // C' = -Dinv * T
+                        av[q][kk] = -S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + H + k];
+                        bv[q][kk] = S[(o[q] + H + k) * LDP + o[q] + 16 * tj[q] + lr];
+                    }
+                }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < PER; ++q) acc[q] = Traits<T>::mfma(av[q][kk], bv[q][kk], acc[q]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                S[(o[q] + H + 16 * ti[q] + Traits<T>::crow(lane, i)) * LDP + o[q] + 16 * tj[q] + lr] = acc[q][i];
+        __syncthreads();
+    }
+}
+
+// tile t of an update list after micro-step s: mode 0 = micro-column s+1 (bi = s+1+t),
+// mode 1 = lower triangle of the tiles with s+2 <= bj <= bi <= 7
+__device__ __forceinline__ void tile_of(int mode, int s, int t, int& bi, int& bj) {
+    if (mode == 0) {
+        bi = s + 1 + t;
+        bj = s + 1;
+    } else {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        bi = s + 2 + i;
+        bj = s + 2 + (t - i * (i + 1) / 2);
+    }
+}
+
+// rank-16 MFMA update  S[bi][bj] -= X_bi X_bj^T  (X_b = S[16b.., c0..c0+15]) of the tiles
+// start, start + stride, ... of a list; two tiles are advanced together.
+template <typename T>
+__device__ __forceinline__ void rank16_update(T* S, int c0, int mode, int s, int ntile, int start, int stride,
+                                              int lane, int lr, int kq) {
+    typedef typename Traits<T>::acc_t acc_t;
+    for (int t = start; t < ntile; t += 2 * stride) {
+        int bi0, bj0, bi1, bj1;
+        tile_of(mode, s, t, bi0, bj0);
+        const bool two = (t + stride < ntile);
+        tile_of(mode, s, two ? t + stride : t, bi1, bj1);
+        acc_t a0, a1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0[q] = S[(16 * bi0 + Traits<T>::crow(lane, q)) * LDP + 16 * bj0 + lr];
+            a1[q] = S[(16 * bi1 + Traits<T>::crow(lane, q)) * LDP + 16 * bj1 + lr];
+        }
+        T av0[4], bv0[4], av1[4], bv1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            av0[kk] = -S[(16 * bi0 + lr) * LDP + c0 + 4 * kk + kq];
+            bv0[kk] = S[(16 * bj0 + lr) * LDP + c0 + 4 * kk + kq];
+            av1[kk] = -S[(16 * bi1 + lr) * LDP + c0 + 4 * kk + kq];
+            bv1[kk] = S[(16 * bj1 + lr) * LDP + c0 + 4 * kk + kq];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a0 = Traits<T>::mfma(av0[kk], bv0[kk], a0);
+            a1 = Traits<T>::mfma(av1[kk], bv1[kk], a1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[(16 * bi0 + Traits<T>::crow(lane, q)) * LDP + 16 * bj0 + lr] = a0[q];
+        if (two) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(16 * bi1 + Traits<T>::crow(lane, q)) * LDP + 16 * bj1 + lr] = a1[q];
+        }
+    }
 }
 
 template <typename T>
@@ -161,101 +318,59 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
     __syncthreads();
     PROF_MARK(1);
 
-    // ---- phase 1: factorise, 16-column micro-panels ----
+    // ---- phase 1: factorise, 16-column micro-panels, software-pipelined ----
+    //   (b)_s  micro-TRSM of panel s                       all threads
+    //   (c1)_s rank-16 update of micro-column s+1           all waves
+    //   (a)_{s+1} 16x16 Cholesky of the next micro-block    wave 0   } concurrently
+    //   (c2)_s rank-16 update of the remaining tiles        waves 1-3}
+    long long t_b = 0, t_c1 = 0, t_a = 0, t0 = 0;
+    const bool prof = (p.prof != nullptr && blockIdx.x == 0);
+    if (wave == 0) micro_chol<T>(S, rdiag, 0, lane, lr, p.info + b, (int)p.off);
+    __syncthreads();
     for (int s = 0; s < 8; ++s) {
         const int c0 = 16 * s;
-        // (a) 16x16 diagonal micro-block: lane lr of wave 0 owns row lr.
-        if (wave == 0) {
-            T a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = S[(c0 + lr) * LDP + c0 + c];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const T d = lane_bcast(a[j], j);
-                if (!(d > T(0)) && lane == 0) atomicCAS(p.info + b, 0, (int)p.off + c0 + j + 1);
-                T ljj, rinv;
-                sqrt_rsqrt(d, ljj, rinv);
-                if (lr == j)
-                    a[j] = ljj;
-                else
-                    a[j] *= rinv;
-                if (lane == j) rdiag[c0 + j] = rinv;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) {
-                    const T lcj = lane_bcast(a[j], c);
-                    a[c] -= a[j] * lcj;
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) S[(c0 + lr) * LDP + c0 + c] = a[c];
-            }
-        }
+        if (prof) t0 = (long long)__builtin_readcyclecounter();
+        micro_trsm<T>(S, rdiag, c0, tid);
         __syncthreads();
-        // (b) micro-panel TRSM: one thread per row below the micro-block.
-        {
-            const int row = c0 + 16 + tid;
-            if (row < GPK_DB) {
-                T x[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = S[row * LDP + c0 + c];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    T v = x[j];
-#pragma unroll
-                    for (int c = 0; c < j; ++c) v -= x[c] * S[(c0 + j) * LDP + c0 + c];
-                    x[j] = v * rdiag[c0 + j];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) S[row * LDP + c0 + c] = x[c];
-            }
-        }
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); t_b += t1 - t0; t0 = t1; }
+        if (s == 7) break;
+        rank16_update<T>(S, c0, 0, s, 7 - s, wave, 4, lane, lr, kq);
         __syncthreads();
-        // (c) rank-16 update of the remaining lower 16x16 tiles on MFMA.
-        {
-            const int m = 7 - s;                 // tiles bi, bj in (s, 7]
-            const int ntile = m * (m + 1) / 2;
-            for (int t = wave; t < ntile; t += 4) {
-                int i = 0;
-                while ((i + 1) * (i + 2) / 2 <= t) ++i;
-                const int j = t - i * (i + 1) / 2;
-                const int bi = s + 1 + i, bj = s + 1 + j;
-                acc_t acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[q] = S[(16 * bi + Traits<T>::crow(lane, q)) * LDP + 16 * bj + lr];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const T av = -S[(16 * bi + lr) * LDP + c0 + 4 * kk + kq];
-                    const T bv = S[(16 * bj + lr) * LDP + c0 + 4 * kk + kq];
-                    acc = Traits<T>::mfma(av, bv, acc);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    S[(16 * bi + Traits<T>::crow(lane, q)) * LDP + 16 * bj + lr] = acc[q];
-            }
-        }
+        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); t_c1 += t1 - t0; t0 = t1; }
+        if (wave == 0)
+            micro_chol<T>(S, rdiag, c0 + 16, lane, lr, p.info + b, (int)p.off);
+        else
+            rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - 1, 3, lane, lr, kq);
+        if (prof && tid == 0) t_a += (long long)__builtin_readcyclecounter() - t0;
         __syncthreads();
+    }
+    if (prof && tid == 0) {
+        p.prof[(p.off / GPK_DB) * 16 + 8] = t_b;
+        p.prof[(p.off / GPK_DB) * 16 + 9] = t_c1;
+        p.prof[(p.off / GPK_DB) * 16 + 10] = t_a;
     }
 
     PROF_MARK(2);
     // ---- phase 2: write L (lower triangle only; the upper triangle is never touched) ----
     if (vec_io) {
+        vec_t wbuf[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int id = tid + 256 * i;
             const int r = id / CPR, c = (id % CPR) * VEC;
-            if (c <= r) {
-                if (c + VEC - 1 <= r) {
-                    vec_t w;
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) w[v] = S[r * LDP + c + v];
-                    *reinterpret_cast<vec_t*>(A + (int64_t)r * p.ld + c) = w;
-                } else {
+            for (int v = 0; v < VEC; ++v) wbuf[i][v] = S[r * LDP + c + v];
+        }
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v)
-                        if (c + v <= r) A[(int64_t)r * p.ld + c + v] = S[r * LDP + c + v];
-                }
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = (id % CPR) * VEC;
+            if (c + VEC - 1 <= r) {
+                *reinterpret_cast<vec_t*>(A + (int64_t)r * p.ld + c) = wbuf[i];
+            } else if (c <= r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (c + v <= r) A[(int64_t)r * p.ld + c + v] = wbuf[i][v];
             }
         }
     } else {
@@ -286,45 +401,11 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
         for (int i = 0; i < 16; ++i) S[(c0 + i) * LDP + c0 + lr] = x[i];   // zeros above the diagonal
     }
     __syncthreads();
+    PROF_MARK(6);
     // II. recursive doubling: [A 0; C D]^-1 = [Ai 0; -Di C Ai, Di].
-    for (int h = 16; h < GPK_DB; h *= 2) {
-        const int tpp = (h / 16) * (h / 16);          // 16x16 tiles per pair
-        const int npair = GPK_DB / (2 * h);
-        const int nitem = npair * tpp;                 // 4, 8, 16
-        const int per = nitem / 4;                     // items per wave: 1, 2, 4
-        acc_t acc[4];
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < per) {
-                    const int item = wave * per + q;
-                    const int pr = item / tpp, t = item % tpp;
-                    const int ti = t / (h / 16), tj = t % (h / 16);
-                    const int o = pr * 2 * h;
-                    acc_t z;
-                    z[0] = z[1] = z[2] = z[3] = T(0);
-                    if (pass == 0)   // T = C * Ainv
-                        acc[q] = lds_mm_nn<T>(S, o + h + 16 * ti, o, o, o + 16 * tj, h, lr, kq, false, z);
-                    else             // C' = -Dinv * T
-                        acc[q] = lds_mm_nn<T>(S, o + h + 16 * ti, o + h, o + h, o + 16 * tj, h, lr, kq, true, z);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < per) {
-                    const int item = wave * per + q;
-                    const int pr = item / tpp, t = item % tpp;
-                    const int ti = t / (h / 16), tj = t % (h / 16);
-                    const int o = pr * 2 * h;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        S[(o + h + 16 * ti + Traits<T>::crow(lane, i)) * LDP + o + 16 * tj + lr] = acc[q][i];
-                }
-            }
-            __syncthreads();
-        }
-    }
+    invert_level<T, 16>(S, wave, lane, lr, kq);
+    invert_level<T, 32>(S, wave, lane, lr, kq);
+    invert_level<T, 64>(S, wave, lane, lr, kq);
 
     PROF_MARK(4);
     // ---- phase 4: write inv(L) (identity-padded, zeros above the diagonal) ----

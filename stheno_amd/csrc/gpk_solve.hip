@@ -109,22 +109,32 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs<T> p) {
             }
         }
 
+        // the wave's RPW rows advance together: RPW independent 16-byte loads in flight per lane
+        const T* __restrict__ ar[RPW];
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
-            const int row = row0 + wave + 4 * q;
-            if (row < p.M) {
-                const T* __restrict__ a = A + (int64_t)row * p.lda + kc;
-                if (p.vec_ok) {
-                    for (int k = lane * VEC; k < kb; k += 64 * VEC) {
-                        const vec_t av = *reinterpret_cast<const vec_t*>(a + k);
+            int row = row0 + wave + 4 * q;
+            if (row >= p.M) row = p.M > 0 ? p.M - 1 : 0;   // clamp: result discarded below
+            ar[q] = A + (int64_t)row * p.lda + kc;
+        }
+        if (p.M > 0) {
+            if (p.vec_ok) {
+                for (int k = lane * VEC; k < kb; k += 64 * VEC) {
+                    vec_t av[RPW];
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q) av[q] = *reinterpret_cast<const vec_t*>(ar[q] + k);
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v)
 #pragma unroll
-                            for (int c = 0; c < NR; ++c) acc[q][c] += av[v] * xs[(k + v) * NR + c];
-                    }
-                } else {
-                    for (int k = lane; k < kb; k += 64) {
-                        const T av = a[k];
+                            for (int c = 0; c < NR; ++c) acc[q][c] += av[q][v] * xs[(k + v) * NR + c];
+                }
+            } else {
+                for (int k = lane; k < kb; k += 64) {
+#pragma unroll
+                    for (int q = 0; q < RPW; ++q) {
+                        const T av = ar[q][k];
 #pragma unroll
                         for (int c = 0; c < NR; ++c) acc[q][c] += av * xs[k * NR + c];
                     }

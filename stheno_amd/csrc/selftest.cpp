@@ -5,6 +5,7 @@
 //     ./gpk_selftest --perf     + timings (HIP events) of the hot kernels
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -547,28 +548,246 @@ static void profile_one(int n, int nbo, int reps) {
     }
 }
 
-extern "C" void gpk_debug_diag_prof(long long* dev_buf);
+__global__ void rsq_probe(const double* x, double* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = __builtin_amdgcn_rsq(x[i]);
+}
+static void rsq_precision() {
+    const int n = 1 << 16;
+    std::vector<double> x(n);
+    std::uniform_real_distribution<double> u(0.01, 100.0);
+    for (auto& v : x) v = u(rng);
+    Dev<double> dx(n), dy(n);
+    dx.up(x);
+    hipLaunchKernelGGL(rsq_probe, dim3(n / 256), dim3(256), 0, 0, dx.p, dy.p, n);
+    HIPCHK(hipDeviceSynchronize());
+    auto y = dy.down();
+    double worst = 0;
+    for (int i = 0; i < n; ++i) worst = std::max(worst, std::fabs(y[i] * std::sqrt(x[i]) - 1.0));
+    printf("RSQ_F64 max relative error of v_rsq_f64: %.3e (= 2^%.1f)\n", worst, std::log2(worst));
+}
+
 extern "C" void gpk_debug_set(int key, int64_t value);
+
+// pure-register MFMA ceiling: every wave runs `iters` x 16 independent v_mfma (no memory)
+__global__ __launch_bounds__(256) void mfma_peak64(double* out, int iters, long long* clk) {
+    d4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = d4{0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    const long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    const long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+__global__ __launch_bounds__(256) void mfma_peak32(float* out, int iters, long long* clk) {
+    f4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f4{0, 0, 0, 0};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    const long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    const long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+}
+static void mfma_peak() {
+    Timer tm;
+    Dev<double> o64((size_t)512 * 256);
+    Dev<float> o32((size_t)512 * 256);
+    Dev<long long> clk(2);
+    int wallrate = 0;
+    hipDeviceGetAttribute(&wallrate, hipDeviceAttributeWallClockRate, 0);
+    for (int blocks : {256, 512}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            const int iters = 4000;
+            tm.start();
+            hipLaunchKernelGGL(mfma_peak64, dim3(blocks), dim3(256), 0, 0, o64.p, iters, clk.p);
+            float ms = tm.stop();
+            auto c = clk.down();
+            double tf = (double)blocks * 4 * iters * 16 * 2048.0 / ms * 1e-9;
+            if (rep) printf("MFMAPEAK f64 blocks=%d: %.3f ms  %.2f TFLOP/s  cycles=%lld wall_ticks=%lld (wall clock %d kHz) -> shader clock %.0f MHz, %.1f cycles/MFMA/SIMD\n", blocks, ms, tf,
+                            c[0], c[1], wallrate, (double)c[0] / ((double)c[1] / wallrate) * 1e-3, (double)c[0] / (iters * 16.0 * (blocks / 256)));
+            tm.start();
+            hipLaunchKernelGGL(mfma_peak32, dim3(blocks), dim3(256), 0, 0, o32.p, iters, clk.p);
+            ms = tm.stop();
+            c = clk.down();
+            tf = (double)blocks * 4 * iters * 16 * 2048.0 / ms * 1e-9;
+            if (rep) printf("MFMAPEAK f32 blocks=%d: %.3f ms  %.2f TFLOP/s  shader clock %.0f MHz\n", blocks, ms, tf, (double)c[0] / ((double)c[1] / wallrate) * 1e-3);
+        }
+    }
+}
+
+template <int BYTES>
+__global__ __launch_bounds__(256) void lds_hog(double* out, int iters) {
+    __shared__ double buf[BYTES / 8];
+    for (int i = threadIdx.x; i < BYTES / 8; i += 256) buf[i] = i;
+    __syncthreads();
+    double acc = 0;
+    for (int it = 0; it < iters; ++it) acc += buf[(threadIdx.x * 17 + it * 31) % (BYTES / 8)];
+    out[threadIdx.x] = acc;
+}
+
+// experiment: CU-masked streams (does a reserved CU let a small kernel overlap a big GEMM?)
+static void cumask_experiment() {
+    const int n = 8192;
+    Dev<double> A((size_t)n * n), Bm((size_t)n * n), C((size_t)n * n), D((size_t)2048 * 2048), dinv(gpk_dinv_elems(2048));
+    Dev<int> info(1);
+    auto h = randv<double>((size_t)n * n);
+    A.up(h); Bm.up(h); C.zero();
+    auto spd = make_spd<double>(2048, 1, 2048);
+    hipStream_t s_def, s_m8, s_half, s_small;
+    HIPCHK(hipStreamCreate(&s_def));
+    HIPCHK(hipStreamCreate(&s_small));
+    uint32_t m8[8], mh[8];
+    for (int i = 0; i < 8; ++i) { m8[i] = 0xFFFFFFFFu; mh[i] = 0x0000FFFFu; }
+    m8[0] = 0xFFFFFF00u;   // bits 0..7: one CU per XCC if bit i <-> XCC i % 8
+    hipError_t e1 = hipExtStreamCreateWithCUMask(&s_m8, 8, m8), e2 = hipExtStreamCreateWithCUMask(&s_half, 8, mh);
+    printf("CUMASK create: %s %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    auto time_gemm = [&](hipStream_t st, const char* nm) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(a, st);
+            gpk_gemm(GPK_F64, 1, 1, n, n, n, -1.0, A.p, n, 0, Bm.p, n, 0, 1.0, C.p, n, 0, 1, 0, st);
+            hipEventRecord(b, st);
+            hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (rep) printf("CUMASK gemm 8192^3 on %-10s %.3f ms\n", nm, ms);
+        }
+    };
+    time_gemm(s_def, "default");
+    if (e1 == hipSuccess) time_gemm(s_m8, "mask-8");
+    if (e2 == hipSuccess) time_gemm(s_half, "mask-half");
+    // overlap: big GEMM on X, potrf(2048) chain on s_small; wall time of both
+    auto overlap = [&](hipStream_t big, const char* nm) {
+        for (int rep = 0; rep < 2; ++rep) {
+            D.up(spd); info.zero();
+            HIPCHK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            gpk_gemm(GPK_F64, 1, 1, n, n, n, -1.0, A.p, n, 0, Bm.p, n, 0, 1.0, C.p, n, 0, 1, 0, big);
+            gpk_potrf(GPK_F64, D.p, 2048, 2048, 0, 1, dinv.p, info.p, 0, s_small);
+            hipEventRecord(b, s_small);
+            hipEventSynchronize(b);
+            auto t1 = std::chrono::high_resolution_clock::now();
+            HIPCHK(hipDeviceSynchronize());
+            auto t2 = std::chrono::high_resolution_clock::now();
+            if (rep) printf("CUMASK overlap big=%-10s potrf(2048) done after %.3f ms, everything after %.3f ms\n", nm,
+                            std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t0).count());
+        }
+    };
+    {   // mask-layout sweep: which bits cost the least?
+        struct M { const char* nm; std::vector<int> clear; };
+        std::vector<M> ms = {{"clr{0}", {0}}, {"clr{0,4..28}", {0, 4, 8, 12, 16, 20, 24, 28}}, {"clr{0..7}", {0, 1, 2, 3, 4, 5, 6, 7}},
+                             {"clr{0,32..224}", {0, 32, 64, 96, 128, 160, 192, 224}}, {"clr{0,1,2,3}", {0, 1, 2, 3}},
+                             {"clr{0,8..56}", {0, 8, 16, 24, 32, 40, 48, 56}}, {"clr{0..31}", {0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31}}};
+        for (auto& m : ms) {
+            uint32_t w[8];
+            for (int i = 0; i < 8; ++i) w[i] = 0xFFFFFFFFu;
+            for (int bit : m.clear) w[bit / 32] &= ~(1u << (bit % 32));
+            hipStream_t st;
+            if (hipExtStreamCreateWithCUMask(&st, 8, w) == hipSuccess) {
+                time_gemm(st, m.nm);
+                gpk_debug_set(2, 1 << 30);
+                time_gemm(st, (std::string(m.nm) + " noswz").c_str());
+                gpk_debug_set(2, 1024);
+                hipStreamDestroy(st);
+            }
+        }
+        gpk_debug_set(2, 1 << 30);
+        time_gemm(s_def, "default noswz");
+        gpk_debug_set(2, 1024);
+    }
+    overlap(s_def, "default");
+    if (e1 == hipSuccess) overlap(s_m8, "mask-8");
+    // diag-kernel-only chain (20 x potrf of one 128 block) beside the big GEMM
+    auto overlap_diag = [&](hipStream_t big, const char* nm, bool with_big) {
+        for (int rep = 0; rep < 2; ++rep) {
+            D.up(spd); info.zero();
+            HIPCHK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            if (with_big) gpk_gemm(GPK_F64, 1, 1, n, n, n, -1.0, A.p, n, 0, Bm.p, n, 0, 1.0, C.p, n, 0, 1, 0, big);
+            for (int q = 0; q < 20; ++q) gpk_potrf(GPK_F64, D.p + (size_t)q * 128 * 2049 * 0, 128, 2048, 0, 1, dinv.p, info.p, 0, s_small);
+            hipEventRecord(b, s_small);
+            hipEventSynchronize(b);
+            auto t1 = std::chrono::high_resolution_clock::now();
+            HIPCHK(hipDeviceSynchronize());
+            auto t2 = std::chrono::high_resolution_clock::now();
+            if (rep) printf("CUMASK diag-chain big=%-10s 20 diag kernels done after %.3f ms, everything after %.3f ms\n", nm,
+                            std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t0).count());
+        }
+    };
+    {   // can an 80 KB / 20 KB workgroup on a HIGH-PRIORITY stream get in beside the big GEMM?
+        int lo, hi;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipStream_t s_hi;
+        HIPCHK(hipStreamCreateWithPriority(&s_hi, hipStreamNonBlocking, hi));
+        Dev<double> o(256);
+        auto hog = [&](int kb, bool with_big, hipStream_t st, const char* nm) {
+            for (int rep = 0; rep < 2; ++rep) {
+                HIPCHK(hipDeviceSynchronize());
+                auto t0 = std::chrono::high_resolution_clock::now();
+                if (with_big) gpk_gemm(GPK_F64, 1, 1, n, n, n, -1.0, A.p, n, 0, Bm.p, n, 0, 1.0, C.p, n, 0, 1, 0, s_def);
+                for (int q = 0; q < 20; ++q) {
+                    if (kb == 80) hipLaunchKernelGGL(lds_hog<81920>, dim3(1), dim3(256), 0, st, o.p, 20000);
+                    else if (kb == 134) hipLaunchKernelGGL(lds_hog<137216>, dim3(1), dim3(256), 0, st, o.p, 20000);
+                    else hipLaunchKernelGGL(lds_hog<20480>, dim3(1), dim3(256), 0, st, o.p, 20000);
+                }
+                hipEventRecord(b, st);
+                hipEventSynchronize(b);
+                auto t1 = std::chrono::high_resolution_clock::now();
+                HIPCHK(hipDeviceSynchronize());
+                if (rep) printf("PRIO hog %3d KB x20 on %-8s stream, big GEMM %s: done after %.3f ms\n", kb, nm, with_big ? "yes" : "no ",
+                                std::chrono::duration<double, std::milli>(t1 - t0).count());
+            }
+        };
+        printf("PRIO priority range lo=%d hi=%d\n", lo, hi);
+        for (int kb : {20, 80, 134}) {
+            hog(kb, false, s_hi, "hi-prio");
+            hog(kb, true, s_hi, "hi-prio");
+            hog(kb, true, s_small, "normal");
+        }
+    }
+    overlap_diag(s_def, "none", false);
+    overlap_diag(s_def, "default", true);
+    if (e1 == hipSuccess) overlap_diag(s_m8, "mask-8", true);
+}
+
+extern "C" void gpk_debug_diag_prof(long long* dev_buf);
 template <typename T>
 static void diag_phase_profile(int n) {
     const int nblk = (n + 127) / 128;
-    Dev<long long> prof((size_t)nblk * 8);
+    Dev<long long> prof((size_t)nblk * 16);
     prof.zero();
     gpk_debug_diag_prof(prof.p);
     profile_one<T>(n, 0, 1);
     gpk_debug_diag_prof(nullptr);
     auto h = prof.down();
     for (int blk : {0, nblk / 2, nblk - 1}) {
-        printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld  storeL %lld  invert %lld  storeW %lld  total %lld\n", DT<T>::name(), blk,
-               h[blk * 8 + 1] - h[blk * 8 + 0], h[blk * 8 + 2] - h[blk * 8 + 1], h[blk * 8 + 3] - h[blk * 8 + 2],
-               h[blk * 8 + 4] - h[blk * 8 + 3], h[blk * 8 + 5] - h[blk * 8 + 4], h[blk * 8 + 5] - h[blk * 8 + 0]);
+        const long long* q = &h[(size_t)blk * 16];
+        printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld [trsm %lld  c1 %lld  chol(wave0) %lld]  storeL %lld  invert %lld [16x16 %lld]  storeW %lld  total %lld\n",
+               DT<T>::name(), blk, q[1] - q[0], q[2] - q[1], q[8], q[9], q[10], q[3] - q[2], q[4] - q[3], q[6] - q[3], q[5] - q[4], q[5] - q[0]);
     }
 }
 
 int main(int argc, char** argv) {
     bool do_perf = false, only_perf = false;
     for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--cumask")) { cumask_experiment(); return 0; }
+        if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
+            rsq_precision();
             diag_phase_profile<double>(atoi(argv[i + 1]));
             diag_phase_profile<float>(atoi(argv[i + 1]));
             return 0;
