@@ -116,6 +116,21 @@ def make_step(name, w, t):
     return step
 
 
+def pmc_traffic(name, w):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` run separately on this same
+    command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC
+    collection cannot run inside the timed process, so the figure is read from
+    ``profiles/``; ``None`` if no pass exists for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % name)
+    if not os.path.exists(path) or w["n"] != WORKLOADS[name]["n"]:
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    k = d["kernels"].get("gemm_kernel<%s, 128, true, true, false>" % ("double" if w["dtype"] == "f64" else "float"))
+    return None if k is None else k["hbm_bytes_per_launch"]
+
+
 def cpu_baseline(name):
     """The oracle (NumPy/SciPy restatement of Stheno's NumPy path) on the host cores, on a
     bounded sample of the same workload."""
@@ -224,7 +239,7 @@ def main():
         roofline = {
             "kernel": f"gemm_kernel<{'double' if w['dtype'] == 'f64' else 'float'}, true, true, false>",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": None,
+            "traffic": pmc_traffic(name, w),
             "launches_per_step": nl.value // prof_steps,
             "avg_launch_us": ms.value * 1e3 / nl.value,
             "algorithmic_flops_per_step": fl.value / prof_steps,
