@@ -13,7 +13,7 @@ A single large dense GP does not shard (one coupled N x N factorisation): replic
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "sharded_logpdf", "sharded_logpdf_sum"]
+__all__ = ["shard_bounds", "sharded_logpdf", "sharded_logpdf_sum", "sharded_elbo"]
 
 
 def shard_bounds(total, world_size, rank):
@@ -62,3 +62,25 @@ def sharded_logpdf_sum(process, x_local, noise, y_local, group=None):
     if world > 1:
         dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     return s[0]
+
+
+def sharded_elbo(obs, measure, group=None):
+    """Pseudo-point ELBO with the N observations sharded over the ranks.
+
+    ``obs`` is a ``PseudoObs`` / ``PseudoObsFITC`` / ``PseudoObsDTC`` built on every rank from
+    the SAME inducing points ``u`` and that rank's shard of the observations
+    ``(f(x_local, noise_local), y_local)``.  Each rank builds ``K_z`` and its Cholesky factor
+    redundantly (M x M, cheap), computes ``V_g = L_z^{-1} K_{z, x_g}`` for its own columns and
+    the sums over its observations; ONE all-reduce (sum) of an ``M x (M + 2)`` buffer -- the
+    only exchange step of the path: 67 MB in fp32 at M = 4096, ring time about
+    2 * (7/8) * 67 MB / 153 GB/s = 0.8 ms, per-link bound on xGMI -- then every rank finishes the
+    M x M solve and holds the same ELBO (``stheno/model/observations.py:279-336`` with the
+    sums over observations distributed)."""
+    world, _ = _world(group)
+
+    def reduce(stats):
+        if world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+
+    obs._compute(measure, reduce=reduce)
+    return obs.elbo(measure)

