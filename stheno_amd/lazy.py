@@ -15,6 +15,11 @@ class _LazyStore:
     def __init__(self):
         self._store = {}
 
+    def purge(self, index):
+        """Drop every cached entry that involves ``index`` (the id of a process that died)."""
+        for k in [k for k in self._store if index in k]:
+            del self._store[k]
+
     def _key(self, key):
         if isinstance(key, tuple):
             return tuple(_index(k) for k in key)

@@ -38,24 +38,26 @@ class FDD(Normal):
         xr = _k.uprank(x)
         self.x = x
         self._xr = xr
-        self.noise = _noise_as_matrix(noise, xr, p.kernel.num_outputs(xr))
+        # NB: the constructors below must not capture ``self`` -- a reference cycle would keep
+        # the (multi-GB) kernel matrix / Cholesky factor alive until Python's cyclic GC runs.
+        nz = self.noise = _noise_as_matrix(noise, xr, p.kernel.num_outputs(xr))
 
         def var_diag():
-            return p.kernel.elwise(xr)[..., 0] + self.noise.diag()
+            return p.kernel.elwise(xr)[..., 0] + nz.diag()
 
         def mean_var():
             mean, var = _k.mean_var(p.mean, p.kernel, xr)
-            return mean, var + self.noise
+            return mean, var + nz
 
         def mean_var_diag():
             mean, vd = _k.mean_var_diag(p.mean, p.kernel, xr)
-            return mean, vd[..., 0] + self.noise.diag()
+            return mean, vd[..., 0] + nz.diag()
 
         def var():
             k = p.kernel
             if k.terms() is not None:
-                return KernelDense(k, xr, self.noise)      # K + noise fused, factorised in place
-            return k(xr) + self.noise
+                return KernelDense(k, xr, nz)      # K + noise fused, factorised in place
+            return k(xr) + nz
 
         Normal.__init__(self, lambda: p.mean(xr), var, var_diag=var_diag, mean_var=mean_var,
                         mean_var_diag=mean_var_diag)

@@ -1,4 +1,5 @@
 """``GP``: a handle on a process registered in a ``Measure`` (``stheno/model/gp.py``)."""
+import weakref
 from types import FunctionType
 
 import torch
@@ -35,7 +36,12 @@ class GP(RandomProcess):
     def __init__(self, *args, measure=None, name=None):
         from .measure import Measure
 
-        self._measures = []
+        # The measure the GP was created under is held strongly; measures that merely know the
+        # GP (posteriors conditioned later) are back-referenced WEAKLY, so an old posterior --
+        # and the Cholesky factor it owns -- dies with its last user handle, not with the prior GP.
+        self._measure0 = None
+        self._backrefs = weakref.WeakSet()
+        self._parents = ()      # processes this one is derived from (kept alive: rules refer to their ids)
         if len(args) == 0:
             return
         if len(args) == 1:
@@ -55,10 +61,20 @@ class GP(RandomProcess):
             measure.name(self, name)
 
     @property
+    def _measures(self):
+        return ([self._measure0] if self._measure0 is not None else []) + list(self._backrefs)
+
+    def _attach(self, measure):
+        if self._measure0 is None:
+            self._measure0 = measure
+        elif measure is not self._measure0:
+            self._backrefs.add(measure)
+
+    @property
     def measure(self):
-        if len(self._measures) == 0:
+        if self._measure0 is None:
             raise RuntimeError("GP is not associated to a measure.")
-        return self._measures[0]
+        return self._measure0
 
     @property
     def kernel(self):
@@ -92,9 +108,11 @@ class GP(RandomProcess):
     def __add__(self, other):
         res = GP()
         if isinstance(other, GP):
+            res._parents = (self, other)
             for measure in intersection_measure_group(self, other):
                 measure.sum(res, self, other)
         else:
+            res._parents = (self,)
             for measure in self._measures:
                 measure.sum(res, self, other)
         return res
@@ -103,6 +121,7 @@ class GP(RandomProcess):
         if isinstance(other, GP) or isinstance(other, FunctionType):
             raise NotImplementedError("products with processes/functions are outside the accelerated path")
         res = GP()
+        res._parents = (self,)
         for measure in self._measures:
             measure.mul(res, self, other)
         return res

@@ -1,6 +1,8 @@
 """``Measure``: a joint model over processes (``stheno/model/measure.py``), reduced to the
 bookkeeping the dense inference path needs: registering processes, lazy (cross-)kernels
 and means, conditioning, re-binding a GP / FDD under a posterior, ``logpdf`` and ``sample``."""
+import weakref
+
 import torch
 
 from .. import kernels as _k
@@ -19,13 +21,38 @@ class Measure:
     default = None
 
     def __init__(self):
-        self.ps = []
+        # Processes are held WEAKLY (a GP holds its measure strongly): no GP <-> Measure cycle,
+        # so dropping the user's handles frees a posterior and its factor immediately.  When a
+        # process dies its id is purged from this measure (ids may be recycled by CPython).
+        self._ps = []
         self._pids = set()
         self.means = LazyVector()
         self.kernels = LazyMatrix()
         self._gps_by_name = {}
         self._names_by_gp = {}
         self._prev_default = None
+
+    @property
+    def ps(self):
+        """The (live) processes of the measure."""
+        return [p for p in (r() for r in self._ps) if p is not None]
+
+    @staticmethod
+    def _purge(wself, pid):
+        self = wself()
+        if self is not None:
+            self._pids.discard(pid)
+            self.means.purge(pid)
+            self.kernels.purge(pid)
+            name = self._names_by_gp.pop(pid, None)
+            if name is not None:
+                self._gps_by_name.pop(name, None)
+
+    def _register(self, p):
+        self._ps.append(weakref.ref(p))
+        self._pids.add(id(p))
+        p._attach(self)
+        weakref.finalize(p, Measure._purge, weakref.ref(self), id(p))
 
     def __enter__(self):
         self._prev_default = Measure.default
@@ -58,18 +85,19 @@ class Measure:
 
     # -- registering processes ---------------------------------------------------
     def _add_p(self, p):
-        self.ps.append(p)
-        self._pids.add(id(p))
-        p._measures.append(self)
+        self._register(p)
 
     def _update(self, p, mean, kernel, left_rule, right_rule=None):
+        # rules live inside this measure's own stores: they refer to it weakly and to processes
+        # by id, or the measure would be a reference cycle on its own
         self.means[p] = mean
         self.kernels[p] = kernel
-        self.kernels.add_left_rule(id(p), self._pids, left_rule)
+        wself, pid = weakref.ref(self), id(p)
+        self.kernels.add_left_rule(pid, self._pids, left_rule)
         if right_rule:
-            self.kernels.add_right_rule(id(p), self._pids, right_rule)
+            self.kernels.add_right_rule(pid, self._pids, right_rule)
         else:
-            self.kernels.add_right_rule(id(p), self._pids, lambda i: reversed(self.kernels[p, i]))
+            self.kernels.add_right_rule(pid, self._pids, lambda i: reversed(wself().kernels[pid, i]))
         self._add_p(p)
         return p
 
@@ -88,24 +116,29 @@ class Measure:
         if isinstance(p, FDD):
             return self(p.p)(p.x, p.noise)
         p_copy = GP()
-        return self._update(p_copy, self.means[p], self.kernels[p], lambda j: self.kernels[p, j],
-                            lambda i: self.kernels[i, p])
+        p_copy._parents = (p,)
+        wself, pid = weakref.ref(self), id(p)
+        return self._update(p_copy, self.means[p], self.kernels[p], lambda j: wself().kernels[pid, j],
+                            lambda i: wself().kernels[i, pid])
 
     # -- bookkeeping-only algebra (measure.py:180-239) ---------------------------
     def sum(self, p_sum, p, other):
         if isinstance(other, GP):
             assert_same_measure(p, other)
             p1, p2 = p, other
+            wself, i1, i2 = weakref.ref(self), id(p1), id(p2)
             return self._update(
                 p_sum, self.means[p1] + self.means[p2],
                 self.kernels[p1] + self.kernels[p2] + self.kernels[p1, p2] + self.kernels[p2, p1],
-                lambda j: self.kernels[p1, j] + self.kernels[p2, j],
+                lambda j: wself().kernels[i1, j] + wself().kernels[i2, j],
             )
-        return self._update(p_sum, self.means[p] + other, self.kernels[p], lambda j: self.kernels[p, j])
+        wself, pid = weakref.ref(self), id(p)
+        return self._update(p_sum, self.means[p] + other, self.kernels[p], lambda j: wself().kernels[pid, j])
 
     def mul(self, p_mul, p, other):
         v = float(other)
-        return self._update(p_mul, self.means[p] * v, self.kernels[p] * v**2, lambda j: self.kernels[p, j] * v)
+        wself, pid = weakref.ref(self), id(p)
+        return self._update(p_mul, self.means[p] * v, self.kernels[p] * v**2, lambda j: wself().kernels[pid, j] * v)
 
     # -- conditioning (measure.py:362-401) --------------------------------------
     def condition(self, *args):
@@ -120,12 +153,12 @@ class Measure:
         else:
             obs = Observations(*args)
         posterior = Measure()
-        posterior.ps = list(self.ps)
-        posterior._pids = set(self._pids)
+        live = self.ps
+        posterior._pids = {id(p) for p in live}
         posterior.means.add_rule(posterior._pids, lambda i: obs.posterior_mean(self, i))
         posterior.kernels.add_rule(posterior._pids, lambda i, j: obs.posterior_kernel(self, i, j))
-        for p in posterior.ps:
-            p._measures.append(posterior)
+        for p in live:
+            posterior._register(p)          # (weak) back-reference, measure.py:381-383
         return posterior
 
     def __or__(self, args):

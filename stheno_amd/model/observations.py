@@ -27,6 +27,23 @@ def combine(*args):
     )
 
 
+def _syrk_splits(m, n):
+    """Number of K-splits for the M x M (lower) product ``V V^T`` with contraction length
+    ``n``: 128x128 output tiles on 512 workgroup slots (2 per CU); pick the split whose tile
+    count fills whole rounds best, with chunks that stay multiples of 64 columns."""
+    tiles = ((m + 127) // 128) * ((m + 127) // 128 + 1) // 2
+    if tiles >= 2048 or n < 16384:
+        return 1
+    best, best_eff = 1, tiles / (-(-tiles // 512) * 512)
+    for s in range(2, 33):
+        if n % s or (n // s) % 64 or n // s < 4096:
+            continue
+        eff = tiles * s / (-(-tiles * s // 512) * 512)
+        if eff > best_eff + 0.02:
+            best, best_eff = s, eff
+    return best
+
+
 def _kernel_matrix(kernel, x, noise):
     """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``)."""
     if kernel.terms() is not None:
@@ -219,7 +236,18 @@ class AbstractPseudoObservations(AbstractObservations):
         # stats: [ V K_n^{-1} V^T (lower) | V K_n^{-1} y | logdet(2 pi K_n), y^T K_n^{-1} y, trace ]
         stats = torch.zeros(v.shape[:-2] + (m, m + 2), dtype=x.dtype, device=x.device)
         A = stats[..., :, :m]
-        be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=A, lower_only=True)   # :322 (lower)
+        n_obs = v.shape[-1]
+        splits = _syrk_splits(m, n_obs) if v.dim() == 2 else 1
+        if splits > 1:
+            # M x M output = few tiles, N huge: split the contraction over the observations into
+            # `splits` batch entries (strided views of V, no copy) so the MFMA grid fills the GPU,
+            # then add the partial products (deterministic, unlike atomics).
+            vs = v.view(m, splits, n_obs // splits).permute(1, 0, 2)          # (S, M, N/S), strides (N/S, N, 1)
+            parts = torch.zeros((splits, m, m), dtype=x.dtype, device=x.device)
+            be.gemm(vs, vs, a_kmajor=True, b_kmajor=True, out=parts, lower_only=True)
+            A.copy_(parts.sum(0))
+        else:
+            be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=A, lower_only=True)   # :322 (lower)
         y_bar = self.y - measure.means[p_x](x)                                # :326
         be.gemv(v, y_bar * s[..., None], out=stats[..., :, m : m + 1])        # :327
         stats[..., 0, m + 1] = torch.log(2 * math.pi * K_n).sum(-1)

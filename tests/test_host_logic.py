@@ -344,3 +344,43 @@ def test_epsilon_is_read_at_factorisation_time():    # README.md:820-831
     finally:
         B.epsilon = 1e-12
     assert abs(float(mean8[2, 0]) - 8.4825932) > 1e-3
+
+
+def test_big_buffers_are_released_without_the_cyclic_gc():
+    """Kernel matrices / Cholesky factors are multi-GB on the device: the object graph
+    (GP <-> Measure, FDD constructors, posterior back-references) must not contain reference
+    cycles that keep them alive until Python's cyclic garbage collector happens to run."""
+    import gc
+    import weakref
+
+    x, y, xs = t(np.linspace(0, 5, 20)), t(np.random.randn(20, 1)), t(np.linspace(0, 5, 7))
+    gc.collect()
+    gc.disable()
+    try:
+        def once():
+            f = st.GP(st.EQ())
+            fdd = f(x, 0.1)
+            fdd.logpdf(y)
+            post = f | (fdd, y)
+            post(xs).marginals()
+            return [weakref.ref(o) for o in (fdd.var, fdd.var.chol(), f, post, f.measure)]
+
+        assert all(r() is None for r in once())
+        # a long-lived prior GP must not accumulate its posteriors
+        f = st.GP(st.EQ())
+        refs = []
+        for _ in range(3):
+            fdd = f(x, 0.1)
+            post = f | (fdd, y)
+            post(xs).marginals()
+            refs.append(weakref.ref(fdd.var))
+        del fdd, post
+        assert all(r() is None for r in refs) and len(f._measures) == 1
+    finally:
+        gc.enable()
+    # derived processes keep what their rules refer to alive
+    m = st.Measure()
+    p_sum = st.GP(st.EQ(), measure=m) + st.GP(2 * st.EQ(), measure=m)     # parents only referenced by p_sum
+    approx(p_sum(t([0.0, 1.0])).var, 3 * O.kernel_matrix([("eq", 1, 1)], np.array([0.0, 1.0])))
+    q = (m | (p_sum(x, 0.1), y))(p_sum)                                   # prior handle dropped, posterior used
+    assert torch.isfinite(q(xs).mean).all()
