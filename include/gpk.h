@@ -151,6 +151,19 @@ int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha,
              int64_t sa, const void* x, int64_t ldx, int64_t sx, double beta, void* y, int64_t ldy, int64_t sy,
              int64_t batch, void* stream);
 
+/* Kernel-hyperparameter VJP of the GP log-density (hyper-parameter learning through
+ * `f(x, noise).logpdf(y)`: readme_example13_optimisation_torch.py:47-53).  With
+ *   G = d logpdf / dK = 1/2 (A diag(g) A^T - sum(g) K^{-1}),  A = K^{-1} (y - m)  (n x ncols <= 8),
+ * one pass over the LOWER triangle of `kinv` accumulates per workgroup
+ *   partial[b][2t] = sum_ij G_ij kappa_t,  partial[b][2t+1] = sum_ij G_ij kappa_t'(q) q,
+ *   partial[b][2*GPK_MAX_TERMS] = trace(G)   (row stride 2*GPK_MAX_TERMS + 1; sum over b),
+ * and writes diag_g[i] = G_ii.  d logpdf/d variance_t = S1_t; d logpdf/d scale_t = -2 v_t S2_t / l_t;
+ * d logpdf / d noise_i = G_ii.  `g` (host): upstream gradient per column. */
+int64_t gpk_kmat_vjp_blocks(int64_t n);
+int gpk_kmat_vjp(int dtype, const int* kinds, const double* inv_ls, int nterms, const void* x, int64_t n,
+                 int64_t ldx, int d, const void* kinv, int64_t ldk, const void* alpha, int ncols, int64_t lda,
+                 const double* g, void* partial, void* diag_g, void* stream);
+
 /* Measurement hooks (bench.py's live roofline figure).  Between gpk_prof_start and
  * gpk_prof_stop every MFMA GEMM launch of this process is bracketed by HIP events on its
  * launch stream; gpk_prof_stop synchronises those events and returns the summed duration,

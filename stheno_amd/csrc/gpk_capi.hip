@@ -119,4 +119,13 @@ int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha,
                                  (T*)y, ldy, sy, batch, (hipStream_t)stream));
 }
 
+int64_t gpk_kmat_vjp_blocks(int64_t n) { return gpk_kmat_vjp_blocks_impl(n); }
+
+int gpk_kmat_vjp(int dtype, const int* kinds, const double* inv_ls, int nterms, const void* x, int64_t n,
+                 int64_t ldx, int d, const void* kinv, int64_t ldk, const void* alpha, int ncols, int64_t lda,
+                 const double* g, void* partial, void* diag_g, void* stream) {
+    D1(dtype, gpk_kmat_vjp_launch<T>(kinds, inv_ls, nterms, (const T*)x, n, ldx, d, (const T*)kinv, ldk,
+                                     (const T*)alpha, ncols, lda, g, (T*)partial, (T*)diag_g, (hipStream_t)stream));
+}
+
 }  // extern "C"

@@ -142,3 +142,8 @@ template <typename T>
 int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda, int64_t sA,
                     const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy,
                     int64_t batch, hipStream_t stream);
+int64_t gpk_kmat_vjp_blocks_impl(int64_t n);
+template <typename T>
+int gpk_kmat_vjp_launch(const int* kinds, const double* inv_ls, int nterms, const T* X, int64_t n, int64_t ldx,
+                        int d, const T* Kinv, int64_t ldk, const T* A, int C, int64_t lda, const double* g,
+                        T* partial, T* diag_g, hipStream_t stream);

@@ -47,7 +47,17 @@ def _as_float(v):
     if torch.is_tensor(v):
         if v.numel() != 1:
             raise ValueError("kernel hyper-parameters must be scalars")
-        return float(v)
+        return float(v.detach())
+    return float(v)
+
+
+def _as_param(v):
+    """Keep scalar tensors (they may carry an autograd graph: learnable hyper-parameters),
+    turn everything else into a float."""
+    if torch.is_tensor(v):
+        if v.numel() != 1:
+            raise ValueError("kernel hyper-parameters must be scalars")
+        return v.reshape(())
     return float(v)
 
 
@@ -63,6 +73,11 @@ class Kernel:
 
     def terms(self):
         return None
+
+    def tensor_terms(self):
+        """Like ``terms()`` but variances / scales stay scalar tensors where the user gave
+        tensors (so gradients can flow back to them)."""
+        return self.terms()
 
     def num_outputs(self, x):
         return num_elements(x)
@@ -112,15 +127,15 @@ class Kernel:
     def __mul__(self, other):
         if isinstance(other, Kernel):
             raise NotImplementedError("products of kernels are outside the accelerated path")
-        v = _as_float(other)
-        if v == 0:
+        v = _as_param(other)
+        if not torch.is_tensor(v) and v == 0:
             return ZeroKernel()
         return Scaled(self, v)
 
     __rmul__ = __mul__
 
     def stretch(self, scale):
-        return Stretched(self, _as_float(scale))
+        return Stretched(self, _as_param(scale))
 
     def __reversed__(self):
         return Reversed(self)
@@ -205,19 +220,23 @@ class Scaled(Kernel):
 
     def terms(self):
         t = self.k.terms()
+        return None if t is None else [(kind, var * _as_float(self.v), s) for kind, var, s in t]
+
+    def tensor_terms(self):
+        t = self.k.tensor_terms()
         return None if t is None else [(kind, var * self.v, s) for kind, var, s in t]
 
     def pairwise(self, x, y=None, **kw):
         if self.terms() is not None:
             return super().pairwise(x, y, **kw)
         da, dv = kw.pop("diag_add", 0.0), kw.pop("diag_vec", None)
-        out = self.v * self.k.pairwise(x, y, **kw)
+        out = _as_float(self.v) * self.k.pairwise(x, y, **kw)
         return _add_diag(out, da, dv) if y is None else out
 
     def elwise(self, x, y=None, **kw):
         if self.terms() is not None:
             return super().elwise(x, y, **kw)
-        return self.v * self.k.elwise(x, y, **kw)
+        return _as_float(self.v) * self.k.elwise(x, y, **kw)
 
     def __repr__(self):
         return f"{self.v} * {self.k!r}"
@@ -231,7 +250,10 @@ class Stretched(Kernel):
         self.stationary = k.stationary
 
     def terms(self):
-        return [(kind, var, s * self.scale) for kind, var, s in self.k.terms()]
+        return [(kind, var, s * _as_float(self.scale)) for kind, var, s in self.k.terms()]
+
+    def tensor_terms(self):
+        return [(kind, var, s * self.scale) for kind, var, s in self.k.tensor_terms()]
 
     def __repr__(self):
         return f"({self.k!r} > {self.scale})"
@@ -244,6 +266,12 @@ class Sum(Kernel):
 
     def terms(self):
         ta, tb = self.a.terms(), self.b.terms()
+        if ta is None or tb is None:
+            return None
+        return ta + tb
+
+    def tensor_terms(self):
+        ta, tb = self.a.tensor_terms(), self.b.tensor_terms()
         if ta is None or tb is None:
             return None
         return ta + tb
@@ -273,6 +301,9 @@ class Reversed(Kernel):
 
     def terms(self):
         return self.k.terms()   # sums of primitives are symmetric
+
+    def tensor_terms(self):
+        return self.k.tensor_terms()
 
     def pairwise(self, x, y=None, **kw):
         if self.terms() is not None or y is None:

@@ -333,6 +333,15 @@ class KernelDense(Dense):
             return 0.0, None, noise.mat
         raise TypeError(f"unsupported noise type {type(noise).__name__}")
 
+    def differentiable_noise(self):
+        """The noise as a vector (n,) (or ``None``) if it is diagonal, else ``NotImplemented``."""
+        noise = self.noise
+        if noise is None or isinstance(noise, Zero):
+            return None
+        if isinstance(noise, Diagonal) and noise.diag().dim() == 1:
+            return noise.diag()
+        return NotImplemented
+
     def _build(self, lower, jitter):
         _, dvec, dense_noise = self._noise_parts()
         out = self.kernel.pairwise(self.x, None, lower=lower and dense_noise is None, diag_add=jitter, diag_vec=dvec)

@@ -287,6 +287,27 @@ class HipBackend:
             ss = ss.reshape(bshape + (C,))
         return dot, ss
 
+    def kmat_vjp(self, terms, x, kinv, alpha, g):
+        """Sums for the hyper-parameter gradient of the log-density (see gpk_kmat_vjp):
+        returns ``(S, trace_G, diag_G)`` with ``S[t] = (sum G kappa_t, sum G kappa_t' q)``.
+        ``x`` (n, d), ``kinv`` (n, n; lower triangle read), ``alpha`` (n, C <= 8), ``g``: C floats."""
+        self._check(x, kinv, alpha)
+        n, d = x.shape
+        C = alpha.shape[1]
+        kinds, _, ils, nt = terms.c_arrays()
+        nb = int(self.lib.gpk_kmat_vjp_blocks(n))
+        width = 2 * _native.MAX_TERMS + 1
+        partial = torch.zeros((nb, width), dtype=x.dtype, device=x.device)
+        diag_g = torch.empty((n,), dtype=x.dtype, device=x.device)
+        gs = (ctypes.c_double * max(C, 1))(*[float(v) for v in g])
+        alpha = alpha.contiguous()
+        code = self.lib.gpk_kmat_vjp(_dtype_id(x), kinds, ils, nt, self._ptr(x), n, x.stride(0), d, self._ptr(kinv),
+                                     kinv.stride(0), self._ptr(alpha), C, alpha.stride(0), gs, self._ptr(partial),
+                                     self._ptr(diag_g), self._stream())
+        self._st(code, "gpk_kmat_vjp")
+        tot = partial.sum(0)
+        return tot[: 2 * nt].reshape(nt, 2), tot[2 * _native.MAX_TERMS], diag_g
+
     # -- in-place odds and ends ------------------------------------------------
     def tril_(self, a):
         a3, _ = _as3(a)

@@ -12,7 +12,7 @@ import types
 import torch
 
 from . import ops
-from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, Zero, to_matrix
+from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, to_matrix
 
 __all__ = ["Random", "RandomProcess", "RandomVector", "Normal"]
 
@@ -222,6 +222,15 @@ class Normal(RandomVector):
         var = self.var
         n = self.dim
         r = x - self.mean
+        # hyper-parameter learning: differentiable path for a kernel-matrix variance
+        if isinstance(var, KernelDense) and r.dim() == 2:
+            from . import autograd as _ag
+
+            noise_vec = var.differentiable_noise()
+            tt = var.kernel.tensor_terms()
+            if noise_vec is not NotImplemented and tt is not None and _ag.needs_grad(tt, noise_vec, r):
+                lp = _ag.gp_logpdf(var.kernel, var.x, noise_vec, r)
+                return lp[0] if lp.shape[0] == 1 else lp
         if isinstance(var, Zero):
             raise torch.linalg.LinAlgError("the variance is identically zero")
         logdet = var.logdet()

@@ -120,6 +120,35 @@ class OracleBackend:
             ss = (v * v).sum(-2)
         return dot, ss
 
+    def kmat_vjp(self, terms, x, kinv, alpha, g):
+        xs = _np(x)
+        ki = np.tril(_np(kinv)) + np.tril(_np(kinv), -1).T
+        A = _np(alpha)
+        gv = np.asarray(g, dtype=np.float64)
+        G = 0.5 * ((A * gv) @ A.T - gv.sum() * ki)
+        S = []
+        for kind, _, scale in terms.terms:
+            if kind == "linear":
+                q = (xs / scale) @ (xs / scale).T
+            else:
+                q = O.pw_dists2(xs / scale, xs / scale)
+            eps = 1e-300
+            if kind == "eq":
+                k, dkq = np.exp(-0.5 * q), -0.5 * q * np.exp(-0.5 * q)
+            elif kind == "matern12":
+                r = np.sqrt(q); k, dkq = np.exp(-r), -0.5 * r * np.exp(-r)
+            elif kind == "matern32":
+                s = np.sqrt(3 * q); k, dkq = (1 + s) * np.exp(-s), -0.5 * s * s * np.exp(-s)
+            elif kind == "matern52":
+                s = np.sqrt(5 * q); k, dkq = (1 + s + s * s / 3) * np.exp(-s), -(s * s / 6) * (1 + s) * np.exp(-s)
+            elif kind == "linear":
+                k, dkq = q, q
+            else:
+                k, dkq = np.ones_like(q), np.zeros_like(q)
+            S.append([np.sum(G * k), np.sum(G * dkq)])
+        return (self._t(np.array(S).reshape(len(terms), 2), x), self._t(np.trace(G), x),
+                self._t(np.diag(G).copy(), x))
+
     def tril_(self, a):
         a.copy_(torch.tril(a))
         return a

@@ -1,0 +1,127 @@
+"""Gradients of ``f(x, noise).logpdf(y)`` w.r.t. kernel hyper-parameters, the noise and
+``y`` (reference usage ``readme_example13_optimisation_torch.py:20-52``),
+checked against central finite differences of the CPU oracle's log-density.
+
+The CPU variant runs the autograd.Function's host logic on the test-only oracle backend; the
+GPU variant runs it through libgpk.so (TRSM on the identity, lower SYRK, gpk_kmat_vjp).
+"""
+import numpy as np
+import pytest
+import torch
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+
+KINDS = {"eq": st.EQ, "matern12": st.Matern12, "matern32": st.Matern32, "matern52": st.Matern52, "linear": st.Linear}
+
+
+def logpdf_direct(terms, x, noise, y):
+    """The oracle's log-density with DIRECT-difference distances.  Upstream's (and the
+    oracle's) ``|a|^2 + |b|^2 - 2ab`` leaves ~1e-15 rounding noise in the zero distances on the
+    diagonal; under the square root of the Matern kernels that noise is 3e-8 and makes finite
+    differences in the length scale meaningless (error ~1e-2).  Values agree to 1e-7."""
+    n = x.shape[0]
+    d2 = ((x[:, None, :] - x[None, :, :]) ** 2).sum(-1)
+    dot = x @ x.T
+    k = sum(v * O._kappa(kind, d2 / s**2, dot / s**2) for kind, v, s in terms)
+    return O.normal_logpdf(None, k + noise * np.eye(n), y)
+
+
+def fd_grad(fun, p, h=1e-6):
+    g = np.zeros_like(p)
+    for i in range(p.size):
+        e = np.zeros_like(p); e.flat[i] = h
+        g.flat[i] = (fun(p + e) - fun(p - e)) / (2 * h)
+    return g
+
+
+def run_case(dev, dtype, kinds, n, d, c, seed, tol):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d))
+    y = rng.standard_normal((n, c))
+    var0 = rng.uniform(0.5, 1.5, len(kinds))
+    sc0 = rng.uniform(0.7, 1.6, len(kinds))
+    noise0 = 0.3
+    wts = rng.uniform(0.5, 1.5, c)           # upstream weights of the C log-densities
+
+    def oracle(params):
+        v, s, nz = params[: len(kinds)], params[len(kinds): 2 * len(kinds)], params[-1]
+        terms = [(k, v[i], s[i]) for i, k in enumerate(kinds)]
+        return float(np.sum(wts * np.atleast_1d(logpdf_direct(terms, x, nz, y))))
+
+    p0 = np.concatenate([var0, sc0, [noise0]])
+    t0 = [(k, var0[i], sc0[i]) for i, k in enumerate(kinds)]
+    assert abs(oracle(p0) - float(np.sum(wts * np.atleast_1d(O.gp_logpdf(t0, x, noise0, y))))) <= 1e-7 * abs(oracle(p0))
+    ref = fd_grad(oracle, p0)
+    ref_y = fd_grad(lambda yy: float(np.sum(wts * np.atleast_1d(logpdf_direct(t0, x, noise0, yy.reshape(n, c))))),
+                    y.copy().ravel(), h=1e-5)
+
+    vs = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in var0]
+    ss = [torch.tensor(s, dtype=torch.float64, requires_grad=True) for s in sc0]
+    nz = torch.tensor(noise0, dtype=torch.float64, requires_grad=True)
+    ty = torch.tensor(y, dtype=dtype, device=dev, requires_grad=True)
+    kernel = sum(v * KINDS[k]().stretch(s) for v, k, s in zip(vs, kinds, ss))
+    f = st.GP(kernel)
+    lp = f(torch.tensor(x, dtype=dtype, device=dev), nz.to(dtype=dtype, device=dev)).logpdf(ty)
+    assert lp.shape == (() if c == 1 else (c,))
+    assert abs(float((lp.reshape(-1).double().cpu() * torch.tensor(wts)).sum()) - oracle(p0)) <= tol * abs(oracle(p0))
+    (lp.reshape(-1) * torch.tensor(wts, dtype=dtype, device=dev)).sum().backward()
+    got = np.array([float(v.grad) for v in vs] + [float(s.grad) for s in ss] + [float(nz.grad)])
+    assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1.0), (got, ref)
+    gy = ty.grad.double().cpu().numpy().ravel()
+    assert np.max(np.abs(gy - ref_y)) <= tol * max(np.max(np.abs(ref_y)), 1.0)
+
+
+CASES = [(("eq",), 40, 3, 1), (("eq", "linear"), 37, 2, 1), (("matern32",), 50, 1, 3), (("matern52", "matern12"), 45, 4, 2)]
+
+
+@pytest.mark.parametrize("kinds,n,d,c", CASES)
+def test_logpdf_gradients_host_logic(oracle_backend, kinds, n, d, c):
+    run_case("cpu", torch.float64, kinds, n, d, c, seed=len(kinds) + n, tol=2e-6)
+
+
+def test_no_grad_path_is_untouched(oracle_backend):
+    x = torch.linspace(0, 3, 20, dtype=torch.float64)
+    y = torch.randn(20, 1, dtype=torch.float64)
+    v = torch.tensor(1.3, dtype=torch.float64, requires_grad=True)
+    f = st.GP(v * st.EQ())
+    with torch.no_grad():
+        lp = f(x, 0.1).logpdf(y)
+    assert not lp.requires_grad
+    lp2 = f(x, 0.1).logpdf(y)
+    assert lp2.requires_grad and abs(float(lp2) - float(lp)) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kinds,n,d,c", CASES + [(("eq",), 700, 8, 1), (("eq", "linear"), 300, 4, 2)])
+def test_logpdf_gradients_gpu(hip_backend, kinds, n, d, c):
+    run_case("cuda", torch.float64, kinds, n, d, c, seed=len(kinds) + n, tol=5e-6)
+
+
+@pytest.mark.gpu
+def test_logpdf_gradients_gpu_fp32(hip_backend):
+    st.B.epsilon = 1e-6
+    try:
+        run_case("cuda", torch.float32, ("eq",), 200, 3, 1, seed=7, tol=5e-3)
+    finally:
+        st.B.epsilon = 1e-12
+
+
+@pytest.mark.gpu
+def test_gradient_descent_step_improves_the_fit(hip_backend):
+    """One Adam-free gradient step on (variance, scale, noise) raises the log-density."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.linspace(0, 10, 400, dtype=torch.float64)
+    ytrue = torch.sin(x)[:, None] + 0.1 * torch.randn(400, 1, generator=g, dtype=torch.float64)
+    params = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in (0.5, 0.3, 0.5)]
+
+    def logpdf():
+        f = st.GP(params[0] * st.EQ().stretch(params[1]))
+        return f(x.cuda(), params[2].cuda()).logpdf(ytrue.cuda())
+
+    lp0 = logpdf()
+    lp0.backward()
+    with torch.no_grad():
+        for p in params:
+            p += 1e-4 * p.grad / p.grad.abs().max()
+    assert float(logpdf()) > float(lp0)
