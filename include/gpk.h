@@ -44,6 +44,9 @@ extern "C" {
 #define GPK_K_CONST 5     /* 1                                  mlkernels.OneKernel */
 #define GPK_MAX_TERMS 8
 
+#define GPK_GEMM_LOWER 1
+#define GPK_GEMM_TRI_K 2
+
 #define GPK_DIAG_BLOCK 128 /* order of the diagonal blocks whose inverses gpk_potrf leaves in `dinv` */
 
 int gpk_version(void);
@@ -105,12 +108,14 @@ int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, 
 /* C = alpha * op(A) op(B)^T-style contraction + beta * C on MFMA:
  *   C[m][n] = alpha * sum_k a(m,k) b(n,k) + beta * C[m][n]
  * a_kmajor != 0: A stored M x K (k contiguous); else stored K x M.  Same for B (N x K / K x N).
- * lower_only: only tiles on/below the diagonal (SYRK).  Replaces the dense products
+ * flags: GPK_GEMM_LOWER = only tiles on/below the diagonal (SYRK); GPK_GEMM_TRI_K = both operands
+ * vanish for k < their row index (lower-triangular factors stored K x M, e.g. W^T W with W = L^{-1}):
+ * all-zero k-chunks are skipped.  Replaces the dense products
  * `B.mm` / `B.matmul` / `B.iqf` outer products: stheno/model/observations.py:322-323,
  * mlkernels.PosteriorKernel (full covariance), `B.sample` (L xi): stheno/random.py:351. */
 int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
              const void* a, int64_t lda, int64_t sa, const void* b, int64_t ldb, int64_t sb, double beta,
-             void* c, int64_t ldc, int64_t sc, int64_t batch, int lower_only, void* stream);
+             void* c, int64_t ldc, int64_t sc, int64_t batch, int flags, void* stream);
 
 /* out[b] = 2 * sum_i log L[i][i].  Replaces `B.logdet`: stheno/random.py:274,
  * stheno/model/observations.py:334. */
@@ -150,6 +155,12 @@ int gpk_symmetrize(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_
 int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha, const void* a, int64_t lda,
              int64_t sa, const void* x, int64_t ldx, int64_t sx, double beta, void* y, int64_t ldy, int64_t sy,
              int64_t batch, void* stream);
+
+/* W <- L^{-1}: the full lower-triangular inverse (n x n, ldw), N^3/3 flops on the MFMA GEMM.
+ * dinv_sb as for gpk_trsm_lower (unbatched); tmp: sb * n elements.  With gpk_gemm(K x M storage,
+ * GPK_GEMM_LOWER | GPK_GEMM_TRI_K) it gives K^{-1} = W^T W for the log-density gradient. */
+int gpk_trtri_lower(int dtype, const void* l, int64_t n, int64_t ld, const void* dinv_sb, int sb, void* w,
+                    int64_t ldw, void* tmp, void* stream);
 
 /* Kernel-hyperparameter VJP of the GP log-density (hyper-parameter learning through
  * `f(x, noise).logpdf(y)`: readme_example13_optimisation_torch.py:47-53).  With

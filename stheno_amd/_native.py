@@ -70,6 +70,7 @@ SIGNATURES = {
         [_c_int, _c_int, _c_i64, _c_i64, _c_int, _c_dbl, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64,
          _c_dbl, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr],
     ),
+    "gpk_trtri_lower": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr]),
     "gpk_kmat_vjp_blocks": (_c_i64, [_c_i64]),
     "gpk_kmat_vjp": (
         _c_int,

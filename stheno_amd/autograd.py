@@ -49,10 +49,8 @@ class _GPLogpdf(torch.autograd.Function):
             raise NotImplementedError("backward through logpdf supports at most 8 columns of y")
         g = [float(v) for v in grad_out.reshape(-1).tolist()]    # host sync: C scalars
         # W = L^{-1} (lower triangular), K^{-1} = W^T W, A = K^{-1} r = W^T w
-        W = torch.zeros((n, n), dtype=x.dtype, device=x.device)
-        be.add_diag_(W, 1.0)
-        chol.solve_(W)
-        kinv = be.gemm(W, W, a_kmajor=False, b_kmajor=False, lower_only=True)
+        W = chol.inverse_lower()                                              # N^3/3 flops
+        kinv = be.gemm(W, W, a_kmajor=False, b_kmajor=False, lower_only=True, tri_k=True)   # N^3/3 flops
         alpha = torch.stack([be.colreduce(W, w[:, c], want_dot=True, want_ss=False)[0] for c in range(C)], dim=1)
         S, trace_g, diag_g = be.kmat_vjp(terms, x, kinv, alpha, g)
         variances, scales = ctx.values

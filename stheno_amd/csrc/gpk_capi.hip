@@ -69,9 +69,9 @@ int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, 
 
 int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
              const void* a, int64_t lda, int64_t sa, const void* b, int64_t ldb, int64_t sb, double beta,
-             void* c, int64_t ldc, int64_t sc, int64_t batch, int lower_only, void* stream) {
+             void* c, int64_t ldc, int64_t sc, int64_t batch, int flags, void* stream) {
     D1(dtype, gpk_gemm_launch<T>(a_kmajor != 0, b_kmajor != 0, m, n, k, (T)alpha, (const T*)a, lda, sa,
-                                 (const T*)b, ldb, sb, (T)beta, (T*)c, ldc, sc, batch, lower_only != 0,
+                                 (const T*)b, ldb, sb, (T)beta, (T*)c, ldc, sc, batch, flags,
                                  (hipStream_t)stream));
 }
 
@@ -117,6 +117,11 @@ int gpk_gemv(int dtype, int trans, int64_t m, int64_t k, int nrhs, double alpha,
     if (trans != 0) return -2;   // A^T x is gpk_colreduce (nrhs = 1) or gpk_gemm
     D1(dtype, gpk_gemv_launch<T>(m, k, nrhs, (T)alpha, (const T*)a, lda, sa, (const T*)x, ldx, sx, (T)beta,
                                  (T*)y, ldy, sy, batch, (hipStream_t)stream));
+}
+
+int gpk_trtri_lower(int dtype, const void* l, int64_t n, int64_t ld, const void* dinv_sb, int sb, void* w,
+                    int64_t ldw, void* tmp, void* stream) {
+    D1(dtype, gpk_trtri_launch<T>((const T*)l, n, ld, (const T*)dinv_sb, sb, (T*)w, ldw, (T*)tmp, (hipStream_t)stream));
 }
 
 int64_t gpk_kmat_vjp_blocks(int64_t n) { return gpk_kmat_vjp_blocks_impl(n); }

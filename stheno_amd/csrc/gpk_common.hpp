@@ -75,11 +75,13 @@ static inline int64_t gpk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 //   C[m][n] = alpha * sum_k a(m,k) b(n,k) + beta * C[m][n]
 // a_kmaj: A stored M x K row-major (k contiguous), else stored K x M (m contiguous).
 // b_kmaj: B stored N x K row-major (k contiguous), else stored K x N (n contiguous).
-// lower_only: compute only tiles with tile_col <= tile_row (SYRK-style; M == N).
+// flags bit 0 (lower_only): compute only tiles with tile_col <= tile_row (SYRK-style).
+// flags bit 1 (tri_k): both operands vanish for k < their row index (lower-triangular
+//   factors stored K x M): the k loop of tile row m0 starts at k = m0.
 template <typename T>
 int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                     const T* A, int64_t lda, int64_t sA, const T* B, int64_t ldb, int64_t sB,
-                    T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, bool lower_only,
+                    T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, int flags,
                     hipStream_t stream);
 
 // Same with a second batch level (blockIdx.z) -- used to batch over regularly strided
@@ -88,7 +90,7 @@ template <typename T>
 int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                      const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
-                     int64_t batch, int64_t batch2, bool lower_only, hipStream_t stream);
+                     int64_t batch, int64_t batch2, int flags, hipStream_t stream);
 
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
@@ -147,3 +149,6 @@ template <typename T>
 int gpk_kmat_vjp_launch(const int* kinds, const double* inv_ls, int nterms, const T* X, int64_t n, int64_t ldx,
                         int d, const T* Kinv, int64_t ldk, const T* A, int C, int64_t lda, const double* g,
                         T* partial, T* diag_g, hipStream_t stream);
+template <typename T>
+int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb, T* W, int64_t ldw, T* tmp,
+                     hipStream_t stream);

@@ -50,6 +50,7 @@ struct GemmArgs {
     int has_beta;
     int tiles_m, tiles_n;
     int lower_only;
+    int tri_k;        // operands are lower-triangular in k (zero for k < row index): start at k = m0
     int swizzle;
     int n_super;
     int SN;
@@ -221,16 +222,18 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs
     }
 
     const int nk = (p.K + BK - 1) / BK;
+    int kc0 = p.tri_k ? m0 / BK : 0;            // all-zero k-chunks of triangular operands are skipped
+    if (kc0 > nk - 1) kc0 = nk > 0 ? nk - 1 : 0;
     vec_t ra[FR], rb[FR];
 
-    gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, 0, p.M, p.K, tid);
-    gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, 0, p.N, p.K, tid);
+    gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, kc0 * BK, p.M, p.K, tid);
+    gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, kc0 * BK, p.N, p.K, tid);
     sstore<T, TS, A_KMAJ>(smem, ra, tid);
     sstore<T, TS, B_KMAJ>(smem + OPB, rb, tid);
     __syncthreads();
 
-    for (int kc = 0; kc < nk; ++kc) {
-        const char* sA = smem + (kc & 1) * STAGE;
+    for (int kc = kc0; kc < nk; ++kc) {
+        const char* sA = smem + ((kc - kc0) & 1) * STAGE;
         const char* sB = sA + OPB;
         const bool more = (kc + 1 < nk);
         if (more) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs
                     acc[fi][fj] = Traits<T>::mfma(a[fi], bb[fj], acc[fi][fj]);
         }
         if (more) {
-            char* dA = smem + ((kc + 1) & 1) * STAGE;
+            char* dA = smem + ((kc + 1 - kc0) & 1) * STAGE;
             sstore<T, TS, A_KMAJ>(dA, ra, tid);
             sstore<T, TS, B_KMAJ>(dA + OPB, rb, tid);
         }
@@ -354,7 +357,8 @@ template <typename T>
 int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                      const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
-                     int64_t batch, int64_t batch2, bool lower_only, hipStream_t stream) {
+                     int64_t batch, int64_t batch2, int flags, hipStream_t stream) {
+    const bool lower_only = (flags & 1) != 0;
     if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return GPK_OK;
     if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || batch > 65535 || batch2 > 65535)
         return GPK_ERR_ARG(3);
@@ -382,6 +386,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.tiles_m = (int)gpk_cdiv(M, ts);
     g.tiles_n = (int)gpk_cdiv(N, ts);
     g.lower_only = lower_only ? 1 : 0;
+    g.tri_k = (flags & 2) ? 1 : 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
@@ -430,18 +435,18 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
 template <typename T>
 int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                     const T* A, int64_t lda, int64_t sA, const T* B, int64_t ldb, int64_t sB,
-                    T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, bool lower_only,
+                    T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, int flags,
                     hipStream_t stream) {
     return gpk_gemm_launch2<T>(a_kmaj, b_kmaj, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C,
-                               ldc, sC, 0, batch, 1, lower_only, stream);
+                               ldc, sC, 0, batch, 1, flags, stream);
 }
 
 #define GPK_INST(T)                                                                                  \
     template int gpk_gemm_launch2<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,    \
                                      int64_t, int64_t, const T*, int64_t, int64_t, int64_t, T, T*,   \
-                                     int64_t, int64_t, int64_t, int64_t, int64_t, bool, hipStream_t); \
+                                     int64_t, int64_t, int64_t, int64_t, int64_t, int, hipStream_t); \
     template int gpk_gemm_launch<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,     \
                                     int64_t, const T*, int64_t, int64_t, T, T*, int64_t, int64_t,    \
-                                    int64_t, bool, hipStream_t);
+                                    int64_t, int, hipStream_t);
 GPK_INST(double)
 GPK_INST(float)

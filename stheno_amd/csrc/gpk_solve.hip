@@ -340,7 +340,41 @@ int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv
     return GPK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// W <- L^{-1} (full lower-triangular inverse, n x n): the TRSM sweep on the identity,
+// restricted at block row q to the columns that can be non-zero (0 .. end of block q),
+// i.e. N^3/3 flops instead of N^3.  tmp: sb * n elements.
+// ---------------------------------------------------------------------------
+template <typename T>
+int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb, T* W, int64_t ldw, T* tmp,
+                     hipStream_t stream) {
+    if (n <= 0) return GPK_OK;
+    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(6);
+    int st = gpk_set_identity_launch<T>(W, n, ldw, 0, 1, stream);
+    if (st) return st;
+    const int nsb = (int)gpk_cdiv(n, sb);
+    const int64_t per = (int64_t)sb * sb;
+    for (int q = 0; q < nsb; ++q) {
+        const int64_t r0 = (int64_t)q * sb;
+        const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
+        const int64_t nc = r0 + rq;          // columns that can be non-zero in block row q
+        st = gpk_gemm_launch<T>(true, false, rq, nc, rq, T(1), dinv_sb + q * per, sb, 0, W + r0 * ldw, ldw, 0, T(0),
+                                tmp, nc, 0, 1, 0, stream);
+        if (st) return st;
+        st = gpk_copy2d_launch<T>(tmp, nc, 0, W + r0 * ldw, ldw, 0, rq, nc, 1, stream);
+        if (st) return st;
+        const int64_t r1 = r0 + rq;
+        if (r1 < n) {
+            st = gpk_gemm_launch<T>(true, false, n - r1, nc, rq, T(-1), L + r1 * ld + r0, ld, 0, tmp, nc, 0, T(1),
+                                    W + r1 * ldw, ldw, 0, 1, 0, stream);
+            if (st) return st;
+        }
+    }
+    return GPK_OK;
+}
+
 #define GPK_INST(T)                                                                                 \
+    template int gpk_trtri_launch<T>(const T*, int64_t, int64_t, const T*, int, T*, int64_t, T*, hipStream_t); \
     template int gpk_gemv_launch<T>(int64_t, int64_t, int, T, const T*, int64_t, int64_t, const T*,  \
                                     int64_t, int64_t, T, T*, int64_t, int64_t, int64_t, hipStream_t); \
     template int gpk_trtri_merge_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,  \

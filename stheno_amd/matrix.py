@@ -110,6 +110,13 @@ class Chol:
         _, ss = ops.get_backend().colreduce(v, want_ss=True)
         return ss
 
+    def inverse_lower(self):
+        """``W = L^{-1}`` as a full lower-triangular (n, n) matrix (unbatched; N^3/3 flops)."""
+        if self.l.dim() != 2:
+            raise NotImplementedError("inverse_lower is implemented for unbatched factors")
+        sb, dsb = self._blocks(self.n)
+        return ops.get_backend().trtri(self.l, dsb, sb)
+
     def lower(self):
         """The clean lower-triangular factor (zeros above the diagonal)."""
         if not self._clean:

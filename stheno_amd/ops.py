@@ -209,7 +209,19 @@ class HipBackend:
         return b
 
     # -- products ------------------------------------------------------------
-    def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False):
+    def trtri(self, l, dinv_sb, sb):
+        """``L^{-1}`` of an unbatched factor as a full (n, n) lower-triangular matrix."""
+        self._check(l, dinv_sb)
+        n = l.shape[-1]
+        w = torch.empty((n, n), dtype=l.dtype, device=l.device)
+        tmp = torch.empty((sb * n,), dtype=l.dtype, device=l.device)
+        code = self.lib.gpk_trtri_lower(_dtype_id(l), self._ptr(l), n, l.stride(0), self._ptr(dinv_sb), sb,
+                                        self._ptr(w), n, self._ptr(tmp), self._stream())
+        self._st(code, "gpk_trtri_lower")
+        return w
+
+    def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False,
+             tri_k=False):
         """``out[m, n] = alpha * sum_k a(m, k) b(n, k) + beta * out``.
 
         ``a_kmajor``: ``a`` is stored (M, K); otherwise (K, M).  ``b_kmajor``: ``b`` is stored
@@ -230,7 +242,7 @@ class HipBackend:
         o3, _ = _as3(out)
         code = self.lib.gpk_gemm(_dtype_id(a3), int(a_kmajor), int(b_kmajor), M, N, K, float(alpha), self._ptr(a3),
                                  _ld(a3), _bs(a3), self._ptr(b3), _ld(b3), _bs(b3), float(beta), self._ptr(o3),
-                                 _ld(o3), _bs(o3), B, int(lower_only), self._stream())
+                                 _ld(o3), _bs(o3), B, int(lower_only) | (2 if tri_k else 0), self._stream())
         self._st(code, "gpk_gemm")
         return out
 

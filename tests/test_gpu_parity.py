@@ -241,3 +241,23 @@ def test_marginals_efficiency_10000_points():
     p(xs, 0.2).marginal_credible_bounds()
     torch.cuda.synchronize()
     assert time.time() - t0 < 1
+
+
+@pytest.mark.parametrize("n", [1000, 3000, 4096 + 37])
+def test_triangular_inverse_and_k_inverse(n):
+    """Pieces of the log-density backward at sizes that reach the 128-tile kernels: W = L^{-1}
+    (TRSM sweep on the identity with a growing column range) and K^{-1} = W^T W (lower SYRK that
+    skips the all-zero k-chunks of the triangular factor)."""
+    rng = np.random.default_rng(n)
+    x = dev(rng.standard_normal((n, 3)))
+    be = ops.get_backend()
+    k_full = be.kmat(ops.KTerms([("eq", 1.0, 1.0)]), x, None, diag_add=0.5)
+    c = Chol.factor_(k_full.clone())
+    W = c.inverse_lower()
+    L = c.lower()
+    eye = torch.eye(n, dtype=torch.float64, device=DEV)
+    assert float((W @ L - eye).abs().max()) < 1e-10
+    assert float(torch.triu(W, 1).abs().max()) == 0.0
+    kinv = be.gemm(W, W, a_kmajor=False, b_kmajor=False, lower_only=True, tri_k=True)
+    ref = torch.linalg.inv(k_full)
+    assert float((torch.tril(kinv) - torch.tril(ref)).abs().max()) < 1e-9 * float(ref.abs().max())
