@@ -72,13 +72,12 @@ int gpk_kdiag(int dtype, const int* kinds, const double* variances, const double
 /* Number of elements of the `dinv` workspace gpk_potrf needs per batch entry. */
 int64_t gpk_dinv_elems(int64_t n);
 
-/* In-place lower Cholesky  A = L L^T  (strict upper triangle of the diagonal
- * blocks is zeroed, the rest of the upper triangle is left untouched: use
- * gpk_tril for a clean factor).  `dinv` receives inv(L_cc) of every 128x128
+/* In-place lower Cholesky  A = L L^T  (only the lower triangle is read and written; the
+ * strict upper triangle is left untouched: use gpk_tril for a clean factor).  `dinv` receives inv(L_cc) of every 128x128
  * diagonal block ([batch][ceil(n/128)][128][128], identity-padded); `info`
  * (int per batch entry, MUST be zeroed by the caller) receives the LAPACK-style
- * order of the first non-positive pivot, 0 if none.  nbo: outer block (multiple
- * of 128; <= 0 selects the default).
+ * order of the first non-positive pivot, 0 if none.  nbo: outer block of the right-looking
+ * sweep (128 * 2^k; <= 0 selects the default: 1024 for n >= 8192).
  * Replaces `B.cholesky(B.reg(K))` (LAPACK potrf): implicit under B.logdet / B.iqf_diag at
  * stheno/random.py:274-276, explicit at stheno/model/observations.py:300. */
 int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,
