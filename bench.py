@@ -17,7 +17,7 @@ independent replica ("replicas only"); ``batched_f32`` shards its 512 GPs over t
 and all-gathers the log-densities (stheno_amd/dist.py).
 
 Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel (the MFMA GEMM that
-performs the Cholesky trailing update, ``gemm_kernel<double, true, true, false>``):
+performs the Cholesky trailing update, ``gemm_kernel<double, 128, true, true, false>``):
 algorithmic flops of its launches in one step / their summed duration, measured with HIP
 events on the launch stream (gpk_prof_* hooks) in extra, untimed steps right after the
 timed region.  ``cpu_baseline`` is the NumPy/SciPy oracle (a restatement of Stheno's
@@ -237,7 +237,7 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         peak = PEAK_TFLOPS[w["dtype"]]
         roofline = {
-            "kernel": f"gemm_kernel<{'double' if w['dtype'] == 'f64' else 'float'}, true, true, false>",
+            "kernel": f"gemm_kernel<{'double' if w['dtype'] == 'f64' else 'float'}, 128, true, true, false>",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": pmc_traffic(name, w),
             "launches_per_step": nl.value // prof_steps,
