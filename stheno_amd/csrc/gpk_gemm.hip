@@ -50,6 +50,7 @@ struct GemmArgs {
     int has_beta;
     int tiles_m, tiles_n;
     int lower_only;
+    int vec_ok;       // pointers / leading dimensions allow 16-byte loads
     int tri_k;        // operands are lower-triangular in k (zero for k < row index): start at k = m0
     int swizzle;
     int n_super;
@@ -92,9 +93,11 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
 }
 
 // ---- global -> registers ---------------------------------------------------
+// `fast`: (EDGE kernels only) this tile's rows and this k-chunk lie fully inside the operand and
+// 16-byte loads are legal -- interior tiles of a ragged problem take the vector path too.
 template <typename T, int TS, bool KMAJ, bool EDGE>
 __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], const T* __restrict__ base,
-                                      int64_t ld, int r0, int k0, int R, int K, int tid) {
+                                      int64_t ld, int r0, int k0, int R, int K, int tid, bool fast) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
     if (KMAJ) {
@@ -104,7 +107,7 @@ __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], c
             const int row = r0 + rr0 + 32 * i;
             const int k = k0 + c * VEC;
             const T* p = base + (int64_t)row * ld + k;
-            if (!EDGE) {
+            if (!EDGE || fast) {
                 r[i] = *reinterpret_cast<const vec_t*>(p);
             } else {
 #pragma unroll
@@ -120,7 +123,7 @@ __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], c
             const int k = k0 + krow;
             const int row = r0 + cc * VEC;
             const T* p = base + (int64_t)k * ld + row;
-            if (!EDGE) {
+            if (!EDGE || fast) {
                 r[i] = *reinterpret_cast<const vec_t*>(p);
             } else {
 #pragma unroll
@@ -226,8 +229,9 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs
     if (kc0 > nk - 1) kc0 = nk > 0 ? nk - 1 : 0;
     vec_t ra[FR], rb[FR];
 
-    gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, kc0 * BK, p.M, p.K, tid);
-    gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, kc0 * BK, p.N, p.K, tid);
+    const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS <= p.N);
+    gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, kc0 * BK, p.M, p.K, tid, a_in && (kc0 + 1) * BK <= p.K);
+    gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, kc0 * BK, p.N, p.K, tid, b_in && (kc0 + 1) * BK <= p.K);
     sstore<T, TS, A_KMAJ>(smem, ra, tid);
     sstore<T, TS, B_KMAJ>(smem + OPB, rb, tid);
     __syncthreads();
@@ -237,8 +241,9 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs
         const char* sB = sA + OPB;
         const bool more = (kc + 1 < nk);
         if (more) {
-            gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid);
-            gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, (kc + 1) * BK, p.N, p.K, tid);
+            const bool k_in = (kc + 2) * BK <= p.K;
+            gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid, a_in && k_in);
+            gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, (kc + 1) * BK, p.N, p.K, tid, b_in && k_in);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
@@ -408,6 +413,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
                          (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
                          (sA2 % VEC == 0) && (sB2 % VEC == 0);
     const bool edge = !aligned || (M % ts) || (N % ts) || (K % BK);
+    g.vec_ok = aligned ? 1 : 0;
 
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
     ProfSlot* slot = nullptr;

@@ -237,7 +237,7 @@ class AbstractPseudoObservations(AbstractObservations):
         stats = torch.zeros(v.shape[:-2] + (m, m + 2), dtype=x.dtype, device=x.device)
         A = stats[..., :, :m]
         n_obs = v.shape[-1]
-        splits = _syrk_splits(m, n_obs) if v.dim() == 2 else 1
+        splits = _syrk_splits(m, n_obs) if (v.dim() == 2 and v.is_contiguous()) else 1
         if splits > 1:
             # M x M output = few tiles, N huge: split the contraction over the observations into
             # `splits` batch entries (strided views of V, no copy) so the MFMA grid fills the GPU,

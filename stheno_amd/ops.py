@@ -76,6 +76,16 @@ def _as3(t):
     return t, bshape
 
 
+def _alloc(bshape, rows, cols, dtype, device):
+    """An uninitialised (..., rows, cols) matrix whose leading dimension is padded to a multiple
+    of 16 elements when ``cols`` is not one: rows stay 16-byte aligned, so the kernels keep their
+    vector loads for odd sizes.  Returned as a view (unit inner stride, stride(-2) = padded ld)."""
+    if cols >= 64 and cols % 16:
+        ldp = (cols + 15) // 16 * 16
+        return torch.empty(tuple(bshape) + (rows, ldp), dtype=dtype, device=device)[..., :cols]
+    return torch.empty(tuple(bshape) + (rows, cols), dtype=dtype, device=device)
+
+
 def _ld(t3):
     # leading dimension of the (R, C) slices of a (B, R, C) tensor
     return t3.stride(1) if t3.shape[1] > 1 else max(t3.shape[2], 1)
@@ -131,7 +141,7 @@ class HipBackend:
         if y3.shape[0] != B or y3.shape[2] != d:
             raise ValueError("x and y must agree in batch size and input dimension")
         if out is None:
-            out = torch.empty(bshape + (n, m), dtype=x.dtype, device=x.device)
+            out = _alloc(bshape, n, m, x.dtype, x.device)
         o3, _ = _as3(out)
         dv = None
         if diag_vec is not None:
@@ -213,10 +223,10 @@ class HipBackend:
         """``L^{-1}`` of an unbatched factor as a full (n, n) lower-triangular matrix."""
         self._check(l, dinv_sb)
         n = l.shape[-1]
-        w = torch.empty((n, n), dtype=l.dtype, device=l.device)
+        w = _alloc((), n, n, l.dtype, l.device)
         tmp = torch.empty((sb * n,), dtype=l.dtype, device=l.device)
         code = self.lib.gpk_trtri_lower(_dtype_id(l), self._ptr(l), n, l.stride(0), self._ptr(dinv_sb), sb,
-                                        self._ptr(w), n, self._ptr(tmp), self._stream())
+                                        self._ptr(w), w.stride(0), self._ptr(tmp), self._stream())
         self._st(code, "gpk_trtri_lower")
         return w
 
@@ -237,8 +247,7 @@ class HipBackend:
         if out is None:
             if beta != 0.0:
                 raise ValueError("beta != 0 requires `out`")
-            shape = (bshape if a3.shape[0] >= b3.shape[0] else tuple(b.shape[:-2])) + (M, N)
-            out = torch.empty(shape, dtype=a.dtype, device=a.device)
+            out = _alloc(bshape if a3.shape[0] >= b3.shape[0] else tuple(b.shape[:-2]), M, N, a.dtype, a.device)
         o3, _ = _as3(out)
         code = self.lib.gpk_gemm(_dtype_id(a3), int(a_kmajor), int(b_kmajor), M, N, K, float(alpha), self._ptr(a3),
                                  _ld(a3), _bs(a3), self._ptr(b3), _ld(b3), _bs(b3), float(beta), self._ptr(o3),
@@ -355,11 +364,11 @@ class HipBackend:
         return v
 
     def copy(self, src):
-        """Fresh contiguous copy of a (..., R, C) tensor (strided 2-D copy kernel)."""
+        """Fresh copy of a (..., R, C) tensor (strided 2-D copy kernel; rows 16-byte aligned)."""
         s3, bshape = _as3(src)
         self._check(s3)
         B, R, C = s3.shape
-        out = torch.empty(bshape + (R, C), dtype=src.dtype, device=src.device)
+        out = _alloc(bshape, R, C, src.dtype, src.device)
         o3, _ = _as3(out)
         self._st(self.lib.gpk_copy2d(_dtype_id(s3), self._ptr(s3), _ld(s3), _bs(s3), self._ptr(o3), _ld(o3), _bs(o3),
                                      R, C, B, self._stream()), "gpk_copy2d")
