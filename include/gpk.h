@@ -77,7 +77,7 @@ int64_t gpk_dinv_elems(int64_t n);
  * diagonal block ([batch][ceil(n/128)][128][128], identity-padded); `info`
  * (int per batch entry, MUST be zeroed by the caller) receives the LAPACK-style
  * order of the first non-positive pivot, 0 if none.  nbo: outer block of the right-looking
- * sweep (128 * 2^k; <= 0 selects the default: 1024 for n >= 8192).
+ * sweep (128 * 2^k; <= 0 selects the default: 1024 for n >= 8192, 512 for n >= 2048, else 256).
  * Replaces `B.cholesky(B.reg(K))` (LAPACK potrf): implicit under B.logdet / B.iqf_diag at
  * stheno/random.py:274-276, explicit at stheno/model/observations.py:300. */
 int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,

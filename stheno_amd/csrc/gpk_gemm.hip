@@ -320,8 +320,10 @@ struct Prof {
 };
 Prof g_prof;
 
-int64_t g_small_tile_below = 256;   // tuning knob (gpk_debug_set(1, v))
-int g_swizzle_from = 1024;          // tuning knob (gpk_debug_set(2, v))
+int64_t g_small_tile_below = 1024;  // tuning knob (gpk_debug_set(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
+int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_debug_set(2, v)); r01 sweep: the 8x8 XCD supertile order
+                                    // loses 4 % to plain row-major order (ragged supertiles on the diagonal
+                                    // unbalance the XCDs), so it is off unless asked for
 
 }  // namespace
 

@@ -482,7 +482,7 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
     if (n <= 0 || batch <= 0) return GPK_OK;
     if (n > INT32_MAX) return GPK_ERR_ARG(2);
     if (ld < n) return GPK_ERR_ARG(3);
-    if (nbo <= 0) nbo = (n >= 8192) ? 1024 : (n >= 4096 ? 512 : 256);
+    if (nbo <= 0) nbo = (n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256);
     if (nbo < GPK_DB || (nbo & (nbo - 1))) return GPK_ERR_ARG(9);   // 128 * 2^k
     if (info == nullptr) return GPK_ERR_ARG(7);
     if (dinv == nullptr && n > GPK_DB) return GPK_ERR_ARG(6);

@@ -783,7 +783,28 @@ static void diag_phase_profile(int n) {
 
 int main(int argc, char** argv) {
     bool do_perf = false, only_perf = false;
+    for (int i = 1; i + 2 < argc; ++i)     // --set KEY VALUE: tuning knobs (gpk_debug_set)
+        if (!strcmp(argv[i], "--set")) gpk_debug_set(atoi(argv[i + 1]), atoll(argv[i + 2]));
     for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--batched") && i + 1 < argc) {   // 512 x 2048 f32 potrf with outer block NBO
+            const int nbo = atoi(argv[i + 1]);
+            const int n = 2048, d = 3, batch = 512;
+            auto hx = randv<float>((size_t)batch * n * d);
+            Dev<float> X(hx.size()), K((size_t)batch * n * n), dinv((size_t)batch * gpk_dinv_elems(n));
+            Dev<int> info(batch);
+            X.up(hx);
+            int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+            Timer tm;
+            for (int rep = 0; rep < 3; ++rep) {
+                info.zero();
+                gpk_kmat(GPK_F32, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, X.p, n, d, (int64_t)n * d, d, K.p, n, (int64_t)n * n, batch, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+                tm.start();
+                gpk_potrf(GPK_F32, K.p, n, n, (int64_t)n * n, batch, dinv.p, info.p, nbo, nullptr);
+                const float ms = tm.stop();
+                if (rep) printf("BATCHED potrf_f32 512x2048 nbo=%d  %.3f ms  %.2f TFLOP/s\n", nbo, ms, batch * (double)n * n * n / 3.0 / ms * 1e-9);
+            }
+            return 0;
+        }
         if (!strcmp(argv[i], "--cumask")) { cumask_experiment(); return 0; }
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
@@ -809,7 +830,7 @@ int main(int argc, char** argv) {
         test_gemm<double>(); test_gemm<float>();
         gpk_debug_set(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
         test_gemm<double>(); test_gemm<float>();
-        gpk_debug_set(1, 256);               // library default
+        gpk_debug_set(1, 1024);              // library default
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_misc<double>(); test_misc<float>();
