@@ -23,11 +23,57 @@ __all__ = [
     "Kernel", "EQ", "Exp", "Matern12", "Matern32", "Matern52", "Linear", "OneKernel", "ZeroKernel",
     "Mean", "ZeroMean", "OneMean", "PosteriorKernel", "PosteriorMean", "SubspaceKernel",
     "mean_var", "mean_var_diag", "uprank", "num_elements",
+    "MultiInput", "MultiOutputKernel", "MultiOutputMean",
 ]
+
+
+class MultiInput:
+    """Inputs of a Cartesian product of processes (``cross(f1, f2)((f1(x1), f2(x2)))``): the
+    role of the reference's tuple-of-FDDs input (``stheno/mo/input.py:7-36``,
+    ``stheno/model/observations.py:28-47``).  ``parts`` is a list of ``(process, x_i)`` with
+    ``x_i`` upranked; the object quacks like an ``(N_1 + ... + N_k, .)`` input where the host
+    code only asks for ``dtype`` / ``device`` / the number of rows."""
+
+    def __init__(self, parts):
+        self.parts = [(p, uprank(x)) for p, x in parts]
+        if not self.parts:
+            raise ValueError("a multi-input needs at least one part")
+        if any(x.dim() != 2 for _, x in self.parts):
+            raise NotImplementedError("multi-process inputs with batch dimensions are outside the accelerated path")
+
+    dtype = property(lambda self: self.parts[0][1].dtype)
+    device = property(lambda self: self.parts[0][1].device)
+    sizes = property(lambda self: [x.shape[0] for _, x in self.parts])
+    shape = property(lambda self: (sum(self.sizes), 1))
+
+    def dim(self):
+        return 2
+
+    def offsets(self):
+        out, o = [], 0
+        for n in self.sizes:
+            out.append((o, o + n))
+            o += n
+        return out
+
+    def __getitem__(self, idx):
+        """Row selection by a sorted index vector (``B.take`` on the observations, ``fdd.py:125-132``)."""
+        if not (torch.is_tensor(idx) and idx.dim() == 1 and idx.dtype == torch.long):
+            raise TypeError("a multi-input is sub-selected by an index vector")
+        parts = []
+        for (p, x), (a, b) in zip(self.parts, self.offsets()):
+            sel = idx[(idx >= a) & (idx < b)] - a
+            parts.append((p, x[sel]))
+        return MultiInput(parts)
+
+    def __repr__(self):
+        return "MultiInput(" + ", ".join(f"{tuple(x.shape)}" for _, x in self.parts) + ")"
 
 
 def uprank(x):
     """``B.uprank``: scalars and vectors become column matrices."""
+    if isinstance(x, MultiInput):
+        return x
     if not torch.is_tensor(x):
         x = torch.as_tensor(x)
     if x.dim() == 0:
@@ -83,15 +129,18 @@ class Kernel:
         return num_elements(x)
 
     # -- evaluation ------------------------------------------------------------
-    def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None):
+    def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None, out=None):
         """``k(x, y)`` as a tensor (..., N, M); ``y is None``: symmetric case, where
-        ``diag_add`` / ``diag_vec`` are added to the diagonal in the same pass."""
+        ``diag_add`` / ``diag_vec`` are added to the diagonal in the same pass.  ``out``: a
+        (strided) matrix view to write into (blocks of a multi-output kernel matrix)."""
         t = self.terms()
         if t is None:
             raise NotImplementedError(f"pairwise evaluation is not implemented for {type(self).__name__}")
         x = uprank(x)
         y = None if y is None else uprank(y)
-        return ops.get_backend().kmat(ops.KTerms(t), x, y, lower=lower, diag_add=diag_add, diag_vec=diag_vec)
+        if isinstance(x, MultiInput) or isinstance(y, MultiInput):
+            raise ValueError(f"{type(self).__name__} is a single-output kernel; it cannot take multi-process inputs")
+        return ops.get_backend().kmat(ops.KTerms(t), x, y, lower=lower, diag_add=diag_add, diag_vec=diag_vec, out=out)
 
     def elwise(self, x, y=None, *, cache=None):
         """``k(x_i, x_i)`` as a column (..., N, 1)."""
@@ -314,6 +363,111 @@ class Reversed(Kernel):
         return self.k.elwise(x, y, **kw)
 
 
+# ---------------------------------------------------------------------------
+# Cartesian products of processes (stheno/mo/kernel.py, stheno/mo/mean.py, measure.py:404-423)
+# ---------------------------------------------------------------------------
+def _eval_into(k, x, y, view, lower=False):
+    """Write ``k(x, y)`` (``y is None``: symmetric) into the matrix view ``view``: a sum of
+    primitives goes straight into the block (one fused launch, no temporary)."""
+    if isinstance(k, ZeroKernel):
+        view.zero_()
+    elif k.terms() is not None and not isinstance(y, MultiInput):
+        k.pairwise(x, y, lower=lower, out=view)
+    else:
+        view.copy_(k.pairwise(x, y))
+
+
+class MultiOutputKernel(Kernel):
+    """Kernel of the Cartesian product of the processes ``ps`` of a measure: block ``(i, j)``
+    of ``k(X, Y)`` is ``measure.kernels[p_i, p_j](x_i, y_j)`` (``stheno/mo/kernel.py:39-76``,
+    ``stheno/mo/input.py:7-9``).  A plain input stands for "every process at these inputs".
+    The block matrix is assembled in ONE buffer (each block is written in place through its
+    leading dimension); in the symmetric ``lower`` mode the blocks above the diagonal are skipped,
+    so the buffer can be Cholesky-factorised in place like a single-process kernel matrix.
+
+    The measure is referenced weakly and the processes by id (the kernel lives in the measure's
+    own store); a ``MultiInput`` keeps its processes alive."""
+
+    def __init__(self, measure, ps):
+        import weakref
+
+        self._measure = weakref.ref(measure)
+        self.pids = tuple(id(p) for p in ps)
+
+    @property
+    def kernels(self):
+        return self._measure().kernels
+
+    def _split(self, x):
+        x = uprank(x)
+        if isinstance(x, MultiInput):
+            return [(id(p), xi) for p, xi in x.parts]
+        if x.dim() != 2:
+            raise NotImplementedError("multi-process inputs with batch dimensions are outside the accelerated path")
+        return [(pid, x) for pid in self.pids]
+
+    def num_outputs(self, x):
+        return sum(xi.shape[0] for _, xi in self._split(x))
+
+    def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None, out=None):
+        kernels = self.kernels
+        sym = y is None
+        X = self._split(x)
+        Y = X if sym else self._split(y)
+        nx, ny = sum(xi.shape[0] for _, xi in X), sum(yj.shape[0] for _, yj in Y)
+        if out is None:
+            out = ops._alloc((), nx, ny, X[0][1].dtype, X[0][1].device)
+        r0 = 0
+        for i, (pi, xi) in enumerate(X):
+            r1, c0 = r0 + xi.shape[0], 0
+            for j, (pj, yj) in enumerate(Y):
+                c1 = c0 + yj.shape[0]
+                if not (sym and lower and j > i) and r1 > r0 and c1 > c0:
+                    if sym and i == j:
+                        _eval_into(kernels[pi], xi, None, out[r0:r1, c0:c1], lower=lower)
+                    else:
+                        _eval_into(kernels[pi, pj], xi, yj, out[r0:r1, c0:c1])
+                c0 = c1
+            r0 = r1
+        return _add_diag(out, diag_add, diag_vec) if sym else out
+
+    def elwise(self, x, y=None, *, cache=None):
+        if y is not None and y is not x:
+            raise NotImplementedError("elwise is implemented for identical inputs")
+        kernels = self.kernels
+        return torch.cat([kernels[pi].elwise(xi) for pi, xi in self._split(x)], dim=-2)
+
+    def __repr__(self):
+        return "MultiOutputKernel(" + ", ".join(repr(self.kernels[pid]) for pid in self.pids) + ")"
+
+
+class _CrossKernel(Kernel):
+    """``k(p_cross, p_j)``: rows follow the multi-input of the product process, columns the
+    inputs of process ``j`` (the left rule of ``Measure.cross``, ``measure.py:419-422``)."""
+
+    def __init__(self, mok, j):
+        self.mok, self.j = mok, j
+
+    def pairwise(self, x, y=None, *, cache=None, **kw):
+        if y is None:
+            raise ValueError("a cross-kernel between a product process and another process needs both inputs")
+        kernels = self.mok.kernels
+        X = self.mok._split(x)
+        y = uprank(y)
+        nx, ny = sum(xi.shape[0] for _, xi in X), y.shape[-2]
+        out = ops._alloc((), nx, ny, X[0][1].dtype, X[0][1].device)
+        r0 = 0
+        for pi, xi in X:
+            r1 = r0 + xi.shape[0]
+            if r1 > r0 and ny > 0:
+                _eval_into(kernels[pi, self.j], xi, y, out[r0:r1])
+            r0 = r1
+        return out
+
+    def elwise(self, x, y=None, **kw):
+        raise ValueError('Unclear combination of arguments given to "elwise".')    # mo/kernel.py:63-70
+
+
 def _add_diag(out, diag_add, diag_vec):
     if diag_add or diag_vec is not None:
         ops.get_backend().add_diag_(out, diag_add, diag_vec)
@@ -391,6 +545,22 @@ def _wrap_mean(m):
         return FunctionMean(m)
     v = _as_float(m)
     return ZeroMean() if v == 0 else ScaledMean(OneMean(), v)
+
+
+class MultiOutputMean(Mean):
+    """Mean of the Cartesian product: the per-process means stacked (``stheno/mo/mean.py``)."""
+
+    def __init__(self, measure, ps):
+        import weakref
+
+        self._measure = weakref.ref(measure)
+        self.pids = tuple(id(p) for p in ps)
+
+    def __call__(self, x, cache=None):
+        means = self._measure().means
+        x = uprank(x)
+        parts = [(id(p), xi) for p, xi in x.parts] if isinstance(x, MultiInput) else [(pid, x) for pid in self.pids]
+        return torch.cat([_call_mean(means[pi], xi, cache) for pi, xi in parts], dim=-2)
 
 
 # ---------------------------------------------------------------------------

@@ -35,6 +35,8 @@ class FDD(Normal):
             self.x = x
             self.noise = None
             return
+        if isinstance(x, (tuple, list)) and len(x) and all(isinstance(e, FDD) for e in x):
+            x = _k.MultiInput([(e.p, e.x) for e in x])     # inputs of a product process
         xr = _k.uprank(x)
         self.x = x
         self._xr = xr
@@ -55,7 +57,7 @@ class FDD(Normal):
 
         def var():
             k = p.kernel
-            if k.terms() is not None:
+            if k.terms() is not None or isinstance(k, _k.MultiOutputKernel):
                 return KernelDense(k, xr, nz)      # K + noise fused, factorised in place
             return k(xr) + nz
 

@@ -8,7 +8,7 @@ from .. import kernels as _k
 from ..random import RandomProcess
 from .fdd import FDD
 
-__all__ = ["GP", "assert_same_measure", "intersection_measure_group"]
+__all__ = ["GP", "cross", "assert_same_measure", "intersection_measure_group"]
 
 
 def assert_same_measure(*ps):
@@ -23,6 +23,16 @@ def intersection_measure_group(*ps):
     for p in ps[1:]:
         inter &= set(p._measures)
     return inter
+
+
+def cross(*ps):
+    """Cartesian product of processes (``gp.py:43-55``): a process over multi-process inputs
+    ``(f1(x1), f2(x2), ...)``, used to observe / sample several processes jointly."""
+    p_cross = GP()
+    p_cross._parents = tuple(ps)
+    for measure in intersection_measure_group(*ps):
+        measure.cross(p_cross, *ps)
+    return p_cross
 
 
 def _is_numeric(v):

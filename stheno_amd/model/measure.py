@@ -140,6 +140,12 @@ class Measure:
         wself, pid = weakref.ref(self), id(p)
         return self._update(p_mul, self.means[p] * v, self.kernels[p] * v**2, lambda j: wself().kernels[pid, j] * v)
 
+    def cross(self, p_cross, *ps):
+        """Register ``p_cross`` as the Cartesian product of ``ps`` (``measure.py:404-423``): its
+        kernel / mean are the block kernel matrix / stacked mean over multi-process inputs."""
+        mok = _k.MultiOutputKernel(self, ps)
+        return self._update(p_cross, _k.MultiOutputMean(self, ps), mok, lambda j: _k._CrossKernel(mok, j))
+
     # -- conditioning (measure.py:362-401) --------------------------------------
     def condition(self, *args):
         if len(args) == 1 and isinstance(args[0], AbstractObservations):
@@ -170,7 +176,16 @@ class Measure:
         if args and isinstance(args[0], int):
             n, args = args[0], args[1:]
         fdd = combine(*args)
-        return self(fdd).sample(n, generator=generator)
+        sample = self(fdd).sample(n, generator=generator)
+        if len(args) == 1:
+            return sample
+        # several FDDs are sampled jointly and handed back one by one (measure.py:440-447)
+        out, i = [], 0
+        for a in args:
+            m = _k.num_elements(a.x)
+            out.append(sample[..., i:i + m, :])
+            i += m
+        return tuple(out)
 
     def logpdf(self, *args):
         if len(args) == 1 and isinstance(args[0], AbstractPseudoObservations):

@@ -8,6 +8,7 @@ from .. import kernels as _k
 from .. import ops
 from ..matrix import AbstractMatrix, ChainChol, Chol, Dense, Diagonal, FactoredDense, KernelDense, Zero, config
 from .fdd import FDD, take
+from .gp import cross
 
 __all__ = [
     "combine", "AbstractObservations", "AbstractPseudoObservations", "Observations", "Obs",
@@ -16,15 +17,31 @@ __all__ = [
 ]
 
 
+def _block_diag_noise(fdds):
+    """``B.block_diag`` of the FDDs' noises (``observations.py:38``), kept diagonal when every
+    block is."""
+    noises = [f.noise for f in fdds]
+    if all(isinstance(nz, Zero) for nz in noises):
+        return None
+    if all(isinstance(nz, (Zero, Diagonal)) for nz in noises):
+        return Diagonal(torch.cat([nz.diag() for nz in noises], dim=-1))
+    return Dense(torch.block_diag(*[nz.dense() for nz in noises]))
+
+
 def combine(*args):
-    """Combine FDDs / (FDD, y) pairs into one (``observations.py:28-47``).  Only the
-    single-process case lies on the accelerated path."""
+    """Combine FDDs, or ``(FDD, y)`` pairs, into one FDD of the Cartesian product of their
+    processes (``observations.py:28-47``)."""
     if len(args) == 1:
         return args[0]
-    raise NotImplementedError(
-        "combining observations of several processes (multi-output block kernels) is not on the "
-        "accelerated path yet"
-    )
+    if all(isinstance(a, FDD) for a in args):
+        return cross(*[f.p for f in args])(args, _block_diag_noise(args))
+    if all(isinstance(a, tuple) and len(a) == 2 and isinstance(a[0], FDD) for a in args):
+        fdds, ys = zip(*args)
+        fdd = combine(*fdds)
+        dev = _k.uprank(fdd.x).device
+        ys = [y if torch.is_tensor(y) else torch.as_tensor(y, dtype=fdd.dtype, device=dev) for y in ys]
+        return fdd, torch.cat([_k.uprank(y) for y in ys], dim=-2)
+    raise TypeError("combine(fdd, ...) or combine((fdd, y), ...)")
 
 
 def _syrk_splits(m, n):
@@ -46,7 +63,7 @@ def _syrk_splits(m, n):
 
 def _kernel_matrix(kernel, x, noise):
     """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``)."""
-    if kernel.terms() is not None:
+    if kernel.terms() is not None or isinstance(kernel, _k.MultiOutputKernel):
         return KernelDense(kernel, x, noise)
     return kernel(x) + noise
 

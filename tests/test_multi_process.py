@@ -1,0 +1,180 @@
+"""Several processes observed / sampled jointly: ``cross``, ``combine``, multi-process
+``Obs`` and the additive decomposition (``stheno/model/observations.py:28-47``,
+``stheno/model/gp.py:43-55``, ``stheno/model/measure.py:404-461``, ``stheno/mo/*.py``;
+reference tests: ``tests/model/test_model.py`` multi-conditioning / sampling cases,
+``README.md:1085-1119`` decomposition example).
+
+Every scenario is checked against a direct NumPy / SciPy computation on the joint Gaussian
+(written here from the model definition, not through the package).  The CPU run uses the
+TEST-ONLY OracleBackend; the ``gpu`` run goes through libgpk.so.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.stats import multivariate_normal
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+from stheno_amd import B, ops
+
+f64 = torch.float64
+
+
+def _dev():
+    return "cuda" if ops.get_backend().name == "hip" else "cpu"
+
+
+def t(a):
+    return torch.as_tensor(np.asarray(a), dtype=f64, device=_dev())
+
+
+def n(a):
+    return B.to_numpy(a)
+
+
+K1 = [("eq", 1.0, 1.0)]
+K2 = [("matern32", 0.5, 2.0)]
+
+
+def _model():
+    """f1 ~ GP(EQ), f2 ~ GP(0.5 * Matern32 > 2), f = f1 + f2; data on f (noise .1) and f1 (noise .05)."""
+    rng = np.random.default_rng(11)
+    xa, xb, xs = rng.normal(size=(37, 2)), rng.normal(size=(23, 2)), rng.normal(size=(9, 2))
+    ya, yb = rng.normal(size=(37, 1)), rng.normal(size=(23, 1))
+    return xa, xb, xs, ya, yb
+
+
+def _joint(xa, xb):
+    k1 = lambda u, v: O.kernel_matrix(K1, u, v)
+    k2 = lambda u, v: O.kernel_matrix(K2, u, v)
+    K = np.block([[k1(xa, xa) + k2(xa, xa) + 0.1 * np.eye(len(xa)), k1(xa, xb)],
+                  [k1(xb, xa), k1(xb, xb) + 0.05 * np.eye(len(xb))]])
+    return K, k1, k2
+
+
+def _scenario(check_tol):
+    xa, xb, xs, ya, yb = _model()
+    with st.Measure() as prior:
+        f1 = st.GP(st.EQ())
+        f2 = st.GP(0.5 * st.Matern32().stretch(2.0))
+        f = f1 + f2
+    K, k1, k2 = _joint(xa, xb)
+    y = np.concatenate([ya, yb])
+    Ki = np.linalg.inv(K)
+
+    # joint log-density of the two observation sets (measure.py:463-489 with several pairs)
+    lp = prior.logpdf((f(t(xa), 0.1), t(ya)), (f1(t(xb), 0.05), t(yb)))
+    want = multivariate_normal(np.zeros(len(y)), K).logpdf(y[:, 0])
+    np.testing.assert_allclose(float(lp), want, rtol=check_tol)
+
+    # conditioning on both, predicting every process (observations.py:143-168 with a product process)
+    post = prior | ((f(t(xa), 0.1), t(ya)), (f1(t(xb), 0.05), t(yb)))
+    cases = {
+        "f": (f, np.vstack([k1(xa, xs) + k2(xa, xs), k1(xb, xs)]), k1(xs, xs) + k2(xs, xs)),
+        "f1": (f1, np.vstack([k1(xa, xs), k1(xb, xs)]), k1(xs, xs)),
+        "f2": (f2, np.vstack([k2(xa, xs), np.zeros((len(xb), len(xs)))]), k2(xs, xs)),
+    }
+    for name, (proc, kzs, kss) in cases.items():
+        fdd = post(proc)(t(xs))
+        mean, var = fdd.marginals()
+        np.testing.assert_allclose(n(mean), (kzs.T @ Ki @ y)[:, 0], rtol=check_tol, atol=check_tol, err_msg=name)
+        full = kss - kzs.T @ Ki @ kzs
+        np.testing.assert_allclose(n(var), np.diag(full), rtol=check_tol, atol=check_tol, err_msg=name)
+        np.testing.assert_allclose(n(B.dense(fdd.var)), full, rtol=check_tol, atol=check_tol, err_msg=name)
+
+    # the product process under the posterior: joint covariance of (f1(xs), f2(xs))
+    joint = post(st.cross(f1, f2))((f1(t(xs)), f2(t(xs))))
+    kz = np.hstack([cases["f1"][1], cases["f2"][1]])
+    kss = np.block([[k1(xs, xs), np.zeros((9, 9))], [np.zeros((9, 9)), k2(xs, xs)]])
+    np.testing.assert_allclose(n(B.dense(joint.var)), kss - kz.T @ Ki @ kz, rtol=check_tol, atol=check_tol)
+    np.testing.assert_allclose(n(joint.mean)[:, 0], (kz.T @ Ki @ y)[:, 0], rtol=check_tol, atol=check_tol)
+
+    # chain rule across processes: p(ya, yb) = p(ya) p(yb | ya)   (test_model.py:391-398)
+    lp_a = f(t(xa), 0.1).logpdf(t(ya))
+    post_a = prior | (f(t(xa), 0.1), t(ya))
+    lp_b = post_a(f1)(t(xb), 0.05).logpdf(t(yb))
+    np.testing.assert_allclose(float(lp_a + lp_b), want, rtol=check_tol)
+
+
+def _decomposition(check_tol):
+    """Observe the sum, recover the components (README.md:1085-1119)."""
+    xa, _, xs, ya, _ = _model()
+    with st.Measure() as prior:
+        f1 = st.GP(st.EQ())
+        f2 = st.GP(0.5 * st.Matern32().stretch(2.0))
+        f = f1 + f2
+    post = prior | (f(t(xa), 0.1), t(ya))
+    k1 = lambda u, v: O.kernel_matrix(K1, u, v)
+    k2 = lambda u, v: O.kernel_matrix(K2, u, v)
+    Ki = np.linalg.inv(k1(xa, xa) + k2(xa, xa) + 0.1 * np.eye(len(xa)))
+    m1, v1 = post(f1)(t(xs)).marginals()
+    m2, v2 = post(f2)(t(xs)).marginals()
+    m, _ = post(f)(t(xs)).marginals()
+    np.testing.assert_allclose(n(m1), (k1(xs, xa) @ Ki @ ya)[:, 0], rtol=check_tol, atol=check_tol)
+    np.testing.assert_allclose(n(m2), (k2(xs, xa) @ Ki @ ya)[:, 0], rtol=check_tol, atol=check_tol)
+    np.testing.assert_allclose(n(m1) + n(m2), n(m), rtol=check_tol, atol=check_tol)
+    np.testing.assert_allclose(n(v1), np.diag(k1(xs, xs) - k1(xs, xa) @ Ki @ k1(xa, xs)), rtol=check_tol, atol=check_tol)
+    np.testing.assert_allclose(n(v2), np.diag(k2(xs, xs) - k2(xs, xa) @ Ki @ k2(xa, xs)), rtol=check_tol, atol=check_tol)
+
+
+def _sampling_and_errors():
+    xa, xb, _, ya, _ = _model()
+    with st.Measure() as prior:
+        f1 = st.GP(st.EQ())
+        f2 = st.GP(st.Matern52())
+        f = f1 + f2
+    g = torch.Generator(device=_dev()).manual_seed(3)
+    s1, s2, s = prior.sample(4, f1(t(xa)), f2(t(xa)), f(t(xa)), generator=g)
+    assert s1.shape == s2.shape == s.shape == (37, 4)
+    # f = f1 + f2 holds sample by sample (a joint sample, not three independent ones); the
+    # jitter B.epsilon on the 111 x 111 singular covariance bounds the mismatch
+    np.testing.assert_allclose(n(s1 + s2), n(s), atol=5e-4)
+    single = prior.sample(f1(t(xb)), generator=g)
+    assert single.shape == (23, 1)
+
+    # missing values are dropped across the stacked observations (observations.py:73-76)
+    ya_nan = ya.copy()
+    ya_nan[[3, 17]] = np.nan
+    obs = st.Obs((f(t(xa), 0.1), t(ya_nan)), (f1(t(xb), 0.05), t(np.zeros((23, 1)))))
+    assert st.kernels.num_elements(obs.fdd.x) == 37 + 23 - 2
+    assert obs.fdd.x.sizes == [35, 23]
+
+    # a single-output kernel refuses a multi-process input; unattached mixes are rejected
+    with pytest.raises(ValueError):
+        st.EQ().pairwise(obs.fdd.x)
+    other = st.GP(st.EQ(), measure=st.Measure())
+    with pytest.raises(AssertionError):
+        st.cross(f1, other)
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_multi_process_conditioning_cpu():
+    _scenario(1e-7)
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_additive_decomposition_cpu():
+    _decomposition(1e-8)
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_joint_sampling_and_errors_cpu():
+    _sampling_and_errors()
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_multi_process_conditioning_gpu():
+    _scenario(1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_additive_decomposition_gpu():
+    _decomposition(1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_joint_sampling_and_errors_gpu():
+    _sampling_and_errors()
