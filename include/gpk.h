@@ -174,6 +174,23 @@ int gpk_kmat_vjp(int dtype, const int* kinds, const double* inv_ls, int nterms, 
                  int64_t ldx, int d, const void* kinv, int64_t ldk, const void* alpha, int ncols, int64_t lda,
                  const double* g, void* partial, void* diag_g, void* stream);
 
+/* Kernel VJP with an explicit cotangent (gradient of the pseudo-point ELBO w.r.t. kernel
+ * hyper-parameters, observation noise and inducing inputs: the learning loop that
+ * readme_example10_sparse.py:8-29 / stheno/model/observations.py:279-336 feed when `stheno.torch`
+ * tensors carry gradients).  For K = k(x, y) (n x m, never formed) and
+ *   Geff_ij = g[i][j] * colscale[j] + w[i] * b[j]      (colscale and the pair (w, b) may be NULL),
+ * one pass over g writes, per workgroup (rowtiles x nchunks of them, see gpk_kmat_vjp_dense_grid),
+ *   partial[wg][2t] = sum Geff kappa_t,  partial[wg][2t+1] = sum Geff kappa_t'(q) q   (row stride
+ *   2*GPK_MAX_TERMS + 1; sum over wg; d/dvariance_t = S1_t, d/dscale_t = -2 v_t S2_t / l_t),
+ *   colsum[rowtile][j] = sum_{i in tile} Geff_ij K_ij        (NULL to skip; sum over row tiles),
+ *   gradx[chunk][i][0..d) = sum_{j in chunk} Geff_ij dK_ij/dx_i   (NULL to skip; needs d <= 8; sum over chunks).
+ * Deterministic (no atomics). */
+int gpk_kmat_vjp_dense_grid(int64_t n, int64_t m, int64_t* rowtiles, int64_t* nchunks);
+int gpk_kmat_vjp_dense(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                       const void* x, int64_t n, int64_t ldx, const void* y, int64_t m, int64_t ldy, int d,
+                       const void* g, int64_t ldg, const void* colscale, const void* w, const void* b,
+                       void* partial, void* colsum, void* gradx, void* stream);
+
 /* Measurement hooks (bench.py's live roofline figure).  Between gpk_prof_start and
  * gpk_prof_stop every MFMA GEMM launch of this process is bracketed by HIP events on its
  * launch stream; gpk_prof_stop synchronises those events and returns the summed duration,

@@ -77,6 +77,12 @@ SIGNATURES = {
         [_c_int, _p_int, _p_dbl, _c_int, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_ptr, _c_int, _c_i64,
          _p_dbl, _c_ptr, _c_ptr, _c_ptr],
     ),
+    "gpk_kmat_vjp_dense_grid": (_c_int, [_c_i64, _c_i64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "gpk_kmat_vjp_dense": (
+        _c_int,
+        [_c_int, _p_int, _p_dbl, _p_dbl, _c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_int, _c_ptr,
+         _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
+    ),
     "gpk_prof_start": (_c_int, []),
     "gpk_prof_stop": (_c_int, [_c_int, _p_dbl, ctypes.POINTER(ctypes.c_int64), _p_dbl]),
     "gpk_copy2d": (

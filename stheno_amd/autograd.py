@@ -11,12 +11,14 @@ MFMA GEMM), then ONE pass over the lower triangle of ``K^{-1}`` (``gpk_kmat_vjp`
 gradients w.r.t. every variance, length scale and the noise; ``d/d(y - m) = -A g``.
 Gradients w.r.t. the inputs ``x`` are not provided.
 """
+import math
+
 import torch
 
 from . import ops
 from .matrix import LOG_2_PI, Chol, config
 
-__all__ = ["gp_logpdf"]
+__all__ = ["gp_logpdf", "sparse_elbo"]
 
 
 class _GPLogpdf(torch.autograd.Function):
@@ -82,3 +84,127 @@ def gp_logpdf(kernel, x, noise_vec, r):
     as_t = lambda v: v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64)  # noqa: E731
     params = [as_t(v) for _, v, _ in tt] + [as_t(s) for _, _, s in tt]
     return _GPLogpdf.apply(x, r, noise_vec, kinds, *params)
+
+
+# ---------------------------------------------------------------------------------------------
+# Pseudo-point ELBO (VFE / DTC), stheno/model/observations.py:279-336, differentiable w.r.t. the
+# kernel variances / length scales, the (diagonal) observation noise, the inducing inputs z and
+# the residual r = y - m(x).
+#
+# With K_z = L L^T, V = L^{-1} K_zx, D = diag(noise), A = I + V D^{-1} V^T, c = A^{-1} V D^{-1} r,
+# beta = r - V^T c (so Sigma^{-1} r = D^{-1} beta), tau = 1 (VFE) or 0 (DTC):
+#     dELBO/dK_zx = L^{-T} [ (tau I - A^{-1}) V + c beta^T ] D^{-1}                  (M x N)
+#     dELBO/dK_z  = -1/2 L^{-T} [ tau A - (tau + 1) I + A^{-1} + c c^T ] L^{-1}      (M x M)
+#     dELBO/dD_j  = -1/2 [ 1/d_j - ((V^T A^{-1} V)_jj + beta_j^2 + tau (k_jj - q_jj)) / d_j^2 ]
+#     dELBO/dk_jj = -tau / (2 d_j),      dELBO/dr = -D^{-1} beta
+# The M x N cotangent costs ONE extra MFMA GEMM (2 M^2 N flops) on the stored, whitened and scaled
+# V; gpk_kmat_vjp_dense then reads it once and returns the per-term sums, the column sums that
+# give (V^T A^{-1} V)_jj without another TRSM, and d/dz.  Everything else is M x M.
+# ---------------------------------------------------------------------------------------------
+class _SparseELBO(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, z, r, noise_vec, tau, kinds, *params):
+        from .model.observations import _syrk_lower
+
+        be = ops.get_backend()
+        nt = len(kinds)
+        variances, scales = params[:nt], params[nt:]
+        terms = ops.KTerms([(k, float(v), float(s)) for k, v, s in zip(kinds, variances, scales)])
+        n, m = x.shape[0], z.shape[0]
+        d = noise_vec.detach()
+        v = be.kmat(terms, z, x)                                               # K_zx
+        chol_z = Chol.factor_(be.kmat(terms, z, None, lower=True, diag_add=config.epsilon))
+        chol_z.solve_(v)                                                       # V
+        _, q = be.colreduce(v, want_ss=True)
+        corr = be.kdiag(terms, x) - q
+        s = torch.rsqrt(d)
+        be.scale_cols_(v, s)                                                   # V D^{-1/2}
+        a = torch.zeros((m, m), dtype=x.dtype, device=x.device)
+        _syrk_lower(be, v, a)
+        be.add_diag_(a, 1.0)
+        p = be.gemv(v, r * s[:, None])
+        a_fac = be.copy(a)
+        if config.epsilon:
+            be.add_diag_(a_fac, config.epsilon)
+        chol_a = Chol.factor_(a_fac)
+        u = chol_a.solve(p)
+        _, uu = be.colreduce(u, want_ss=True)
+        elbo = -0.5 * (torch.log(2 * math.pi * d).sum() + chol_a.logdet() + (r[:, 0] ** 2 / d).sum() - uu[0]
+                       + tau * (corr / d).sum())
+        ctx.saved = dict(x=x, z=z, r=r, d=d, s=s, v=v, q=q, corr=corr, a=a, u=u, chol_z=chol_z, chol_a=chol_a,
+                         terms=terms, tau=tau, nt=nt)
+        ctx.param_meta = [(p_.device, p_.dtype) for p_ in params]
+        ctx.values = ([float(v_) for v_ in variances], [float(s_) for s_ in scales])
+        ctx.kinds = kinds
+        return elbo
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        be = ops.get_backend()
+        sv = ctx.saved
+        x, z, r, d, s, v, q, corr = sv["x"], sv["z"], sv["r"], sv["d"], sv["s"], sv["v"], sv["q"], sv["corr"]
+        terms, tau, nt = sv["terms"], sv["tau"], sv["nt"]
+        m = z.shape[0]
+        eye = torch.eye(m, dtype=x.dtype, device=x.device)
+        w_a = sv["chol_a"].inverse_lower()                                     # L_A^{-1}
+        a_inv = be.symmetrize_(be.gemm(w_a, w_a, a_kmajor=False, b_kmajor=False, lower_only=True, tri_k=True))
+        c = be.colreduce(w_a, sv["u"][:, 0], want_dot=True, want_ss=False)[0]  # A^{-1} p
+        vtc = be.colreduce(v, c, want_dot=True, want_ss=False)[0] / s          # V^T c
+        beta = r[:, 0] - vtc
+        b = beta / d
+        w_z = sv["chol_z"].inverse_lower()                                     # L^{-1}
+        h = be.gemm(w_z, tau * eye - a_inv, a_kmajor=False, b_kmajor=True)     # L^{-T} (tau I - A^{-1})
+        w = be.colreduce(w_z, c, want_dot=True, want_ss=False)[0]              # L^{-T} c
+        g_k = be.gemm(h, v, a_kmajor=True, b_kmajor=False)                     # M x N, the one big GEMM
+        need_z = ctx.needs_input_grad[1]
+        s_k, colsum, gz_k = be.kmat_vjp_dense(terms, z, x, g_k, colscale=s, w=w, b=b, want_colsum=True,
+                                              want_gradx=need_z)
+        del g_k
+        vav = tau * q - d * colsum + vtc * beta                                # (V^T A^{-1} V)_jj
+        g_d = -0.5 * (1.0 / d - (vav + beta * beta + tau * corr) / (d * d))
+        a_full = be.symmetrize_(be.copy(sv["a"]))
+        mid = tau * a_full - (tau + 1.0) * eye + a_inv + c[:, None] * c[None, :]
+        t1 = be.gemm(mid, w_z, a_kmajor=True, b_kmajor=False)
+        g_kz = be.gemm(w_z, t1, a_kmajor=False, b_kmajor=False, alpha=-0.5)
+        s_kz, _, gz_kz = be.kmat_vjp_dense(terms, z, z, g_kz, want_gradx=need_z)
+        S = s_k + s_kz
+        # through k(x_j, x_j) (VFE only): stationary terms are constant on the diagonal
+        g_kd = -0.5 * tau / d
+        variances, scales = ctx.values
+        go = grad_out.to(x.dtype)
+        grads_v, grads_s = [], []
+        for t in range(nt):
+            gv, gs = S[t, 0], -2.0 * variances[t] / scales[t] * S[t, 1]
+            if tau:
+                if ctx.kinds[t] == "linear":
+                    xx = ((x * x).sum(-1) * g_kd).sum() / scales[t] ** 2
+                    gv, gs = gv + xx, gs - 2.0 * variances[t] / scales[t] * xx
+                else:
+                    gv = gv + g_kd.sum()
+            grads_v.append(gv * go)
+            grads_s.append(gs * go)
+        grads = [g_.to(device=dev, dtype=dt) for g_, (dev, dt) in zip(grads_v + grads_s, ctx.param_meta)]
+        grad_z = (gz_k + 2.0 * gz_kz) * go if need_z else None
+        grad_r = (-b * go)[:, None] if ctx.needs_input_grad[2] else None
+        grad_noise = g_d * go if ctx.needs_input_grad[3] else None
+        return (None, grad_z, grad_r, grad_noise, None, None, *grads)
+
+
+def elbo_needs_grad(tensor_terms, noise_vec, z, r):
+    if not torch.is_grad_enabled():
+        return False
+    for _, v, s in tensor_terms:
+        if (torch.is_tensor(v) and v.requires_grad) or (torch.is_tensor(s) and s.requires_grad):
+            return True
+    return bool(noise_vec.requires_grad or z.requires_grad or r.requires_grad)
+
+
+def sparse_elbo(kernel, x, z, noise_vec, r, method):
+    """Differentiable VFE / DTC bound for ``r = y - m(x)`` with inducing inputs ``z``."""
+    if method not in ("vfe", "dtc"):
+        raise NotImplementedError(f'gradients of the "{method}" bound are not implemented (use VFE or DTC)')
+    tt = kernel.tensor_terms()
+    kinds = tuple(k for k, _, _ in tt)
+    as_t = lambda v: v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64)  # noqa: E731
+    params = [as_t(v) for _, v, _ in tt] + [as_t(s) for _, _, s in tt]
+    return _SparseELBO.apply(x, z, r, noise_vec, 1.0 if method == "vfe" else 0.0, kinds, *params)

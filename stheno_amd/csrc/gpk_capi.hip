@@ -133,4 +133,19 @@ int gpk_kmat_vjp(int dtype, const int* kinds, const double* inv_ls, int nterms, 
                                      (const T*)alpha, ncols, lda, g, (T*)partial, (T*)diag_g, (hipStream_t)stream));
 }
 
+int gpk_kmat_vjp_dense_grid(int64_t n, int64_t m, int64_t* rowtiles, int64_t* nchunks) {
+    if (rowtiles == nullptr || nchunks == nullptr) return GPK_ERR_ARG(3);
+    gpk_kmat_vjp_dense_grid_impl(n, m, rowtiles, nchunks, nullptr);
+    return GPK_OK;
+}
+
+int gpk_kmat_vjp_dense(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                       const void* x, int64_t n, int64_t ldx, const void* y, int64_t m, int64_t ldy, int d,
+                       const void* g, int64_t ldg, const void* colscale, const void* w, const void* b,
+                       void* partial, void* colsum, void* gradx, void* stream) {
+    D1(dtype, gpk_kmat_vjp_dense_launch<T>(kinds, variances, inv_ls, nterms, (const T*)x, n, ldx, (const T*)y, m,
+                                           ldy, d, (const T*)g, ldg, (const T*)colscale, (const T*)w,
+                                           (const T*)b, (T*)partial, (T*)colsum, (T*)gradx, (hipStream_t)stream));
+}
+
 }  // extern "C"

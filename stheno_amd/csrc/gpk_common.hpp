@@ -149,6 +149,12 @@ template <typename T>
 int gpk_kmat_vjp_launch(const int* kinds, const double* inv_ls, int nterms, const T* X, int64_t n, int64_t ldx,
                         int d, const T* Kinv, int64_t ldk, const T* A, int C, int64_t lda, const double* g,
                         T* partial, T* diag_g, hipStream_t stream);
+void gpk_kmat_vjp_dense_grid_impl(int64_t n, int64_t m, int64_t* rowtiles, int64_t* nchunks, int64_t* tiles_per_chunk);
+template <typename T>
+int gpk_kmat_vjp_dense_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms,
+                              const T* X, int64_t n, int64_t ldx, const T* Y, int64_t m, int64_t ldy, int d,
+                              const T* G, int64_t ldg, const T* colscale, const T* w, const T* b, T* partial,
+                              T* colsum, T* gradx, hipStream_t stream);
 template <typename T>
 int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb, T* W, int64_t ldw, T* tmp,
                      hipStream_t stream);

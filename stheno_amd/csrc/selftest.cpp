@@ -405,6 +405,83 @@ static void test_misc() {
 }
 
 // ----------------------------------------------------------------------------
+// kernel VJP with an explicit cotangent (gradient of the pseudo-point ELBO)
+// ----------------------------------------------------------------------------
+static void kappa_all_host(int kind, double q, double& k, double& dkq, double& dk) {
+    switch (kind) {
+        case GPK_K_EQ: k = std::exp(-0.5 * q); dk = -0.5 * k; dkq = dk * q; break;
+        case GPK_K_MATERN12: { double r = std::sqrt(q); k = std::exp(-r); dkq = -0.5 * r * k; dk = r > 0 ? -0.5 * k / r : 0.0; break; }
+        case GPK_K_MATERN32: { double s = std::sqrt(3 * q), e = std::exp(-s); k = (1 + s) * e; dk = -1.5 * e; dkq = dk * q; break; }
+        case GPK_K_MATERN52: { double s = std::sqrt(5 * q), e = std::exp(-s); k = (1 + s + s * s / 3) * e; dk = -(5.0 / 6.0) * (1 + s) * e; dkq = dk * q; break; }
+        case GPK_K_LINEAR: k = q; dkq = q; dk = 1; break;
+        default: k = 1; dkq = 0; dk = 0;
+    }
+}
+template <typename T>
+static void test_vjp_dense_case(std::vector<int> kinds, int n, int m, int d, bool scale_rank1, bool want_gx) {
+    const int nt = (int)kinds.size();
+    std::vector<double> var(nt), il(nt);
+    for (int t = 0; t < nt; ++t) { var[t] = 0.6 + 0.25 * t; il[t] = 1.0 / (0.8 + 0.3 * t); }
+    const int64_t ldg = m + 5;
+    auto X = randv<T>((size_t)n * d), Y = randv<T>((size_t)m * d), G = randv<T>((size_t)n * ldg);
+    auto cs = randv<T>(m), w = randv<T>(n), b = randv<T>(m);
+    int64_t rt = 0, nc = 0;
+    gpk_kmat_vjp_dense_grid(n, m, &rt, &nc);
+    const int W = 2 * GPK_MAX_TERMS + 1;
+    Dev<T> dX(X.size()), dY(Y.size()), dG(G.size()), dcs(m), dw(n), db(m), dP((size_t)rt * nc * W), dC((size_t)rt * m), dGX((size_t)nc * n * d);
+    dX.up(X); dY.up(Y); dG.up(G); dcs.up(cs); dw.up(w); db.up(b);
+    int st = gpk_kmat_vjp_dense(DT<T>::v, kinds.data(), var.data(), il.data(), nt, dX.p, n, d, dY.p, m, d, d, dG.p, ldg,
+                                scale_rank1 ? dcs.p : nullptr, scale_rank1 ? dw.p : nullptr, scale_rank1 ? db.p : nullptr,
+                                dP.p, dC.p, want_gx ? dGX.p : nullptr, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto P = dP.down(), C = dC.down(), GX = dGX.down();
+    std::vector<double> rS(2 * nt, 0.0), rC(m, 0.0), rGX((size_t)n * d, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            double ge = (double)G[(size_t)i * ldg + j];
+            if (scale_rank1) ge = ge * (double)cs[j] + (double)w[i] * (double)b[j];
+            double r2 = 0, dot = 0;
+            for (int k = 0; k < d; ++k) { const double a = X[(size_t)i * d + k], c = Y[(size_t)j * d + k]; r2 += (a - c) * (a - c); dot += a * c; }
+            double kfull = 0;
+            for (int t = 0; t < nt; ++t) {
+                const double q = (kinds[t] == GPK_K_LINEAR ? dot : r2) * il[t] * il[t];
+                double k, dkq, dk;
+                kappa_all_host(kinds[t], q, k, dkq, dk);
+                rS[2 * t] += ge * k; rS[2 * t + 1] += ge * dkq; kfull += var[t] * k;
+                for (int c = 0; c < d; ++c) {
+                    const double a = X[(size_t)i * d + c], y = Y[(size_t)j * d + c];
+                    rGX[(size_t)i * d + c] += kinds[t] == GPK_K_LINEAR ? ge * var[t] * il[t] * il[t] * y
+                                                                       : ge * var[t] * dk * 2 * il[t] * il[t] * (a - y);
+                }
+            }
+            rC[j] += ge * kfull;
+        }
+    std::vector<T> gS(2 * nt, T(0)), gC(m, T(0)), gGX((size_t)n * d, T(0));
+    for (int64_t wg = 0; wg < rt * nc; ++wg) for (int t = 0; t < 2 * nt; ++t) gS[t] += P[(size_t)wg * W + t];
+    for (int64_t r = 0; r < rt; ++r) for (int j = 0; j < m; ++j) gC[j] += C[(size_t)r * m + j];
+    if (want_gx) for (int64_t c = 0; c < nc; ++c) for (size_t e = 0; e < (size_t)n * d; ++e) gGX[e] += GX[(size_t)c * n * d + e];
+    char nm[160];
+    snprintf(nm, sizeof nm, "vjp_dense_%s k%d nt%d n%d m%d d%d sr%d st%d", DT<T>::name(), kinds[0], nt, n, m, d, scale_rank1, st);
+    report(std::string(nm) + " sums", st ? INFINITY : relerr(gS, rS), DT<T>::eps * 2000);
+    report(std::string(nm) + " colsum", st ? INFINITY : relerr(gC, rC), DT<T>::eps * 2000);
+    if (want_gx) report(std::string(nm) + " gradx", st ? INFINITY : relerr(gGX, rGX), DT<T>::eps * 2000);
+}
+template <typename T>
+static void test_vjp_dense() {
+    for (int k = 0; k <= 5; ++k) test_vjp_dense_case<T>({k}, 70, 45, 3, false, true);
+    test_vjp_dense_case<T>({GPK_K_EQ, GPK_K_LINEAR}, 130, 1000, 8, true, true);
+    test_vjp_dense_case<T>({GPK_K_MATERN52, GPK_K_MATERN32, GPK_K_CONST}, 64, 513, 20, true, false);
+    test_vjp_dense_case<T>({GPK_K_EQ}, 300, 9000, 2, true, true);
+    {   // d/dX beyond 8 input dimensions is refused, not silently wrong
+        Dev<T> z(64);
+        std::vector<int> kinds = {GPK_K_EQ};
+        std::vector<double> one = {1.0};
+        int st = gpk_kmat_vjp_dense(DT<T>::v, kinds.data(), one.data(), one.data(), 1, z.p, 2, 9, z.p, 2, 9, 9, z.p, 2, nullptr, nullptr, nullptr, z.p, nullptr, z.p, nullptr);
+        report(std::string("vjp_dense_refuses_gradx_d9_") + DT<T>::name(), st < 0 ? 0.0 : INFINITY, 1.0);
+    }
+}
+
+// ----------------------------------------------------------------------------
 // perf
 // ----------------------------------------------------------------------------
 struct Timer {
@@ -834,6 +911,7 @@ int main(int argc, char** argv) {
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_misc<double>(); test_misc<float>();
+        test_vjp_dense<double>(); test_vjp_dense<float>();
         printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
     }
     if (do_perf) { perf<double>(); perf<float>(); }

@@ -61,6 +61,23 @@ def _syrk_splits(m, n):
     return best
 
 
+def _syrk_lower(be, v, out):
+    """``out = v v^T`` (lower triangle) for ``v`` (..., M, N) on the MFMA GEMM."""
+    m, n_obs = v.shape[-2], v.shape[-1]
+    splits = _syrk_splits(m, n_obs) if (v.dim() == 2 and v.is_contiguous()) else 1
+    if splits > 1:
+        # M x M output = few tiles, N huge: split the contraction over the observations into
+        # `splits` batch entries (strided views of V, no copy) so the MFMA grid fills the GPU,
+        # then add the partial products (deterministic, unlike atomics).
+        vs = v.view(m, splits, n_obs // splits).permute(1, 0, 2)          # (S, M, N/S), strides (N/S, N, 1)
+        parts = torch.zeros((splits, m, m), dtype=v.dtype, device=v.device)
+        be.gemm(vs, vs, a_kmajor=True, b_kmajor=True, out=parts, lower_only=True)
+        out.copy_(parts.sum(0))
+    else:
+        be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=out, lower_only=True)
+    return out
+
+
 def _kernel_matrix(kernel, x, noise):
     """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``)."""
     if kernel.terms() is not None or isinstance(kernel, _k.MultiOutputKernel):
@@ -160,9 +177,39 @@ class AbstractPseudoObservations(AbstractObservations):
         return self._K_z[id(measure)]
 
     def elbo(self, measure):
+        """The evidence lower bound (``observations.py:213-222``).  If a kernel hyper-parameter, the
+        noise, the inducing inputs or ``y`` carries a gradient, the bound is returned as a node of the
+        autograd graph (``stheno_amd.autograd.sparse_elbo``) and is not cached."""
+        diff = self._differentiable(measure)
+        if diff is not None:
+            return diff
         if id(measure) not in self._elbo:
             self._compute(measure)
         return self._elbo[id(measure)]
+
+    def _differentiable(self, measure):
+        from .. import autograd
+
+        if not torch.is_grad_enabled():
+            return None
+        p_x, x, noise_x = self.fdd.p, _k.uprank(self.fdd.x), self.fdd.noise
+        p_z, z, noise_z = self.u.p, _k.uprank(self.u.x), self.u.noise
+        if isinstance(x, _k.MultiInput) or isinstance(z, _k.MultiInput) or not isinstance(noise_x, Diagonal):
+            return None
+        k = measure.kernels[p_z]
+        tt = k.tensor_terms()
+        if tt is None:
+            return None
+        y_bar = self.y - measure.means[p_x](x)
+        if not autograd.elbo_needs_grad(tt, noise_x.diag(), z, y_bar):
+            return None
+        if not (measure.kernels[p_x] is k and measure.kernels[p_z, p_x] is k and isinstance(noise_z, Zero)
+                and x.dim() == 2 and z.dim() == 2):
+            raise NotImplementedError(
+                "gradients of the bound are implemented for noise-free inducing points of the observed "
+                "process itself (one kernel that is a sum of primitives), unbatched"
+            )
+        return autograd.sparse_elbo(k, x, z, noise_x.diag(), y_bar, self.method)
 
     def mu(self, measure):
         """Mean of the optimal approximating distribution (``observations.py:224-237``)."""
@@ -253,18 +300,7 @@ class AbstractPseudoObservations(AbstractObservations):
         # stats: [ V K_n^{-1} V^T (lower) | V K_n^{-1} y | logdet(2 pi K_n), y^T K_n^{-1} y, trace ]
         stats = torch.zeros(v.shape[:-2] + (m, m + 2), dtype=x.dtype, device=x.device)
         A = stats[..., :, :m]
-        n_obs = v.shape[-1]
-        splits = _syrk_splits(m, n_obs) if (v.dim() == 2 and v.is_contiguous()) else 1
-        if splits > 1:
-            # M x M output = few tiles, N huge: split the contraction over the observations into
-            # `splits` batch entries (strided views of V, no copy) so the MFMA grid fills the GPU,
-            # then add the partial products (deterministic, unlike atomics).
-            vs = v.view(m, splits, n_obs // splits).permute(1, 0, 2)          # (S, M, N/S), strides (N/S, N, 1)
-            parts = torch.zeros((splits, m, m), dtype=x.dtype, device=x.device)
-            be.gemm(vs, vs, a_kmajor=True, b_kmajor=True, out=parts, lower_only=True)
-            A.copy_(parts.sum(0))
-        else:
-            be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=A, lower_only=True)   # :322 (lower)
+        _syrk_lower(be, v, A)                                                 # :322 (lower triangle)
         y_bar = self.y - measure.means[p_x](x)                                # :326
         be.gemv(v, y_bar * s[..., None], out=stats[..., :, m : m + 1])        # :327
         stats[..., 0, m + 1] = torch.log(2 * math.pi * K_n).sum(-1)

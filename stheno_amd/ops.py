@@ -329,6 +329,37 @@ class HipBackend:
         tot = partial.sum(0)
         return tot[: 2 * nt].reshape(nt, 2), tot[2 * _native.MAX_TERMS], diag_g
 
+    def kmat_vjp_dense(self, terms, x, y, g, colscale=None, w=None, b=None, want_colsum=False, want_gradx=False):
+        """Sums over an explicit cotangent ``Geff = g * colscale[None, :] + w[:, None] b[None, :]`` of
+        ``K = k(x, y)`` (see gpk_kmat_vjp_dense): returns ``(S, colsum, gradx)`` with
+        ``S[t] = (sum Geff kappa_t, sum Geff kappa_t' q)``, ``colsum[j] = sum_i Geff_ij K_ij`` and
+        ``gradx[i] = sum_j Geff_ij dK_ij/dx_i`` (``None`` unless asked for)."""
+        self._check(x, y, g, colscale, w, b)
+        n, d = x.shape
+        m = y.shape[0]
+        if g.shape != (n, m) or g.stride(1) != 1:
+            raise ValueError("cotangent must be an (n, m) matrix with unit inner stride")
+        rt, nc = ctypes.c_int64(), ctypes.c_int64()
+        self._st(self.lib.gpk_kmat_vjp_dense_grid(n, m, ctypes.byref(rt), ctypes.byref(nc)), "gpk_kmat_vjp_dense_grid")
+        rt, nc = rt.value, nc.value
+        width = 2 * _native.MAX_TERMS + 1
+        partial = torch.zeros((rt * nc, width), dtype=x.dtype, device=x.device)
+        colsum = torch.zeros((rt, m), dtype=x.dtype, device=x.device) if want_colsum else None
+        gradx = torch.zeros((nc, n, d), dtype=x.dtype, device=x.device) if want_gradx else None
+        kinds, var, ils, nt = terms.c_arrays()
+        x, y = x.contiguous(), y.contiguous()
+        cs = colscale.contiguous() if colscale is not None else None
+        w = w.contiguous() if w is not None else None
+        b = b.contiguous() if b is not None else None
+        code = self.lib.gpk_kmat_vjp_dense(_dtype_id(x), kinds, var, ils, nt, self._ptr(x), n, x.stride(0), self._ptr(y),
+                                           m, y.stride(0), d, self._ptr(g), g.stride(0), self._ptr(cs), self._ptr(w),
+                                           self._ptr(b), self._ptr(partial), self._ptr(colsum), self._ptr(gradx),
+                                           self._stream())
+        self._st(code, "gpk_kmat_vjp_dense")
+        tot = partial.sum(0)
+        return (tot[: 2 * nt].reshape(nt, 2), colsum.sum(0) if want_colsum else None,
+                gradx.sum(0) if want_gradx else None)
+
     # -- in-place odds and ends ------------------------------------------------
     def tril_(self, a):
         a3, _ = _as3(a)

@@ -124,6 +124,43 @@ class OracleBackend:
             ss = (v * v).sum(-2)
         return dot, ss
 
+    def kmat_vjp_dense(self, terms, x, y, g, colscale=None, w=None, b=None, want_colsum=False, want_gradx=False):
+        xs, ys, Ge = _np(x), _np(y), _np(g).copy()
+        if colscale is not None:
+            Ge = Ge * _np(colscale)[None, :]
+        if w is not None:
+            Ge = Ge + _np(w)[:, None] * _np(b)[None, :]
+        S, kfull = [], np.zeros_like(Ge)
+        gx = np.zeros_like(xs)
+        for kind, var, scale in terms.terms:
+            diff = xs[:, None, :] - ys[None, :, :]
+            q = (xs @ ys.T if kind == "linear" else (diff ** 2).sum(-1)) / scale ** 2
+            if kind == "eq":
+                k = np.exp(-0.5 * q); dk = -0.5 * k
+            elif kind == "matern12":
+                r = np.sqrt(q); k = np.exp(-r)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    dk = np.where(r > 0, -0.5 * k / r, 0.0)
+            elif kind == "matern32":
+                s_ = np.sqrt(3 * q); k = (1 + s_) * np.exp(-s_); dk = -1.5 * np.exp(-s_)
+            elif kind == "matern52":
+                s_ = np.sqrt(5 * q); k = (1 + s_ + s_ * s_ / 3) * np.exp(-s_); dk = -(5.0 / 6.0) * (1 + s_) * np.exp(-s_)
+            elif kind == "linear":
+                k = q; dk = np.ones_like(q)
+            else:
+                k = np.ones_like(q); dk = np.zeros_like(q)
+            dkq = -0.5 * np.sqrt(q) * k if kind == "matern12" else dk * q
+            S.append([np.sum(Ge * k), np.sum(Ge * dkq)])
+            kfull += var * k
+            if kind == "linear":
+                gx += (Ge * var / scale ** 2) @ ys
+            elif kind != "const":
+                coef = Ge * var * dk * 2 / scale ** 2
+                gx += coef.sum(1)[:, None] * xs - coef @ ys
+        return (self._t(np.array(S).reshape(len(terms), 2), x),
+                self._t((Ge * kfull).sum(0), x) if want_colsum else None,
+                self._t(gx, x) if want_gradx else None)
+
     def kmat_vjp(self, terms, x, kinv, alpha, g):
         xs = _np(x)
         ki = np.tril(_np(kinv)) + np.tril(_np(kinv), -1).T

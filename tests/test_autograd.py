@@ -125,3 +125,120 @@ def test_gradient_descent_step_improves_the_fit(hip_backend):
         for p in params:
             p += 1e-4 * p.grad / p.grad.abs().max()
     assert float(logpdf()) > float(lp0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Gradients of the pseudo-point bound (VFE / DTC): kernel hyper-parameters, per-point noise,
+# inducing inputs z and y, against central finite differences of a direct-distance restatement of
+# the oracle's ELBO (``oracle.pseudo_obs``; same reason for direct distances as above).
+# ---------------------------------------------------------------------------------------------
+def elbo_direct(terms, x, noise_vec, y, z, method, eps):
+    import scipy.linalg as sl
+
+    def km(a, b):
+        d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        return sum(v * O._kappa(kind, d2 / s**2, (a @ b.T) / s**2) for kind, v, s in terms)
+
+    m = z.shape[0]
+    l_z = np.linalg.cholesky(km(z, z) + eps * np.eye(m))
+    v = sl.solve_triangular(l_z, km(z, x), lower=True)
+    a = np.eye(m) + (v / noise_vec) @ v.T
+    l_a = np.linalg.cholesky(a + eps * np.eye(m))
+    u = sl.solve_triangular(l_a, (v / noise_vec) @ y, lower=True)
+    trace = 0.0
+    if method == "vfe":
+        kd = np.array([float(km(x[i:i + 1], x[i:i + 1])[0, 0]) for i in range(x.shape[0])])
+        trace = np.sum((kd - (v * v).sum(0)) / noise_vec)
+    return -0.5 * (np.sum(np.log(2 * np.pi * noise_vec)) + 2 * np.sum(np.log(np.diag(l_a)))
+                   + np.sum(y[:, 0] ** 2 / noise_vec) - np.sum(u**2) + trace)
+
+
+def run_elbo_case(dev, dtype, kinds, n, m, d, method, seed, tol):
+    rng = np.random.default_rng(seed)
+    x, z = rng.standard_normal((n, d)), rng.standard_normal((m, d))
+    y = rng.standard_normal((n, 1))
+    var0, sc0 = rng.uniform(0.5, 1.5, len(kinds)), rng.uniform(0.8, 1.7, len(kinds))
+    nz0 = rng.uniform(0.1, 0.4, n)
+    eps = 1e-10
+    nk = len(kinds)
+    nz_idx, z_idx, y_idx = [0, n // 2, n - 1], [(0, 0), (m // 2, d - 1), (m - 1, 0)], [1, n // 3]
+
+    def unpack(p):
+        terms = [(k, p[i], p[nk + i]) for i, k in enumerate(kinds)]
+        nzv, zz, yy = nz0.copy(), z.copy(), y.copy()
+        o = 2 * nk
+        for i in nz_idx:
+            nzv[i] = p[o]; o += 1
+        for (i, c) in z_idx:
+            zz[i, c] = p[o]; o += 1
+        for i in y_idx:
+            yy[i, 0] = p[o]; o += 1
+        return terms, nzv, zz, yy
+
+    def oracle(p):
+        terms, nzv, zz, yy = unpack(p)
+        return float(elbo_direct(terms, x, nzv, yy, zz, method, eps))
+
+    p0 = np.concatenate([var0, sc0, nz0[nz_idx], [z[i, c] for i, c in z_idx], y[y_idx, 0]])
+    t0 = [(k, var0[i], sc0[i]) for i, k in enumerate(kinds)]
+    want = O.pseudo_obs(t0, x, nz0, y, z, method=method, eps=eps)["elbo"]
+    assert abs(oracle(p0) - want) <= 1e-6 * abs(want)
+    ref = fd_grad(oracle, p0, h=1e-6)
+
+    old = st.B.epsilon
+    st.B.epsilon = eps
+    try:
+        vs = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in var0]
+        ss = [torch.tensor(s, dtype=torch.float64, requires_grad=True) for s in sc0]
+        nz = torch.tensor(nz0, dtype=dtype, device=dev, requires_grad=True)
+        tz = torch.tensor(z, dtype=dtype, device=dev, requires_grad=True)
+        ty = torch.tensor(y, dtype=dtype, device=dev, requires_grad=True)
+        kernel = sum(v * KINDS[k]().stretch(s) for v, k, s in zip(vs, kinds, ss))
+        f = st.GP(kernel)
+        cls = {"vfe": st.PseudoObs, "dtc": st.PseudoObsDTC}[method]
+        obs = cls(f(tz), f(torch.tensor(x, dtype=dtype, device=dev), nz), ty)
+        elbo = obs.elbo(f.measure)
+        assert elbo.requires_grad and abs(float(elbo) - want) <= tol * abs(want)
+        elbo.backward()
+    finally:
+        st.B.epsilon = old
+    got = np.array([float(v.grad) for v in vs] + [float(s.grad) for s in ss]
+                   + [float(nz.grad[i]) for i in nz_idx] + [float(tz.grad[i, c]) for i, c in z_idx]
+                   + [float(ty.grad[i, 0]) for i in y_idx])
+    assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1.0), (got, ref)
+    # without gradients the cached, non-differentiable path is used and agrees
+    with torch.no_grad():
+        plain = cls(f(tz.detach()), f(torch.tensor(x, dtype=dtype, device=dev), nz.detach()), ty.detach())
+        st.B.epsilon = eps
+        try:
+            val = plain.elbo(f.measure)
+        finally:
+            st.B.epsilon = old
+    assert not val.requires_grad and abs(float(val) - float(elbo)) <= 1e-9 * abs(want) + tol * 1e-3
+
+
+ELBO_CASES = [(("eq",), 70, 9, 2, "vfe"), (("eq",), 70, 9, 2, "dtc"), (("matern32", "linear"), 90, 12, 3, "vfe"),
+              (("matern52", "matern12"), 64, 7, 1, "vfe"), (("eq", "const"), 50, 5, 8, "dtc")]
+KINDS["const"] = st.OneKernel
+
+
+@pytest.mark.parametrize("kinds,n,m,d,method", ELBO_CASES)
+def test_elbo_gradients_host_logic(oracle_backend, kinds, n, m, d, method):
+    run_elbo_case("cpu", torch.float64, kinds, n, m, d, method, seed=n + m, tol=5e-6)
+
+
+def test_elbo_gradients_unsupported_cases_are_loud(oracle_backend):
+    x = torch.randn(30, 2, dtype=torch.float64)
+    y = torch.randn(30, 1, dtype=torch.float64)
+    v = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
+    f = st.GP(v * st.EQ())
+    with pytest.raises(NotImplementedError):
+        st.PseudoObsFITC(f(x[:5]), f(x, 0.1), y).elbo(f.measure)
+    with pytest.raises(NotImplementedError):        # noisy inducing points
+        st.PseudoObs(f(x[:5], 0.01), f(x, 0.1), y).elbo(f.measure)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kinds,n,m,d,method", ELBO_CASES + [(("eq",), 1500, 200, 8, "vfe"), (("eq", "linear"), 900, 130, 4, "dtc")])
+def test_elbo_gradients_gpu(hip_backend, kinds, n, m, d, method):
+    run_elbo_case("cuda", torch.float64, kinds, n, m, d, method, seed=n + m, tol=2e-5)
