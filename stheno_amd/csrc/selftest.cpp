@@ -462,9 +462,9 @@ static void test_vjp_dense_case(std::vector<int> kinds, int n, int m, int d, boo
     if (want_gx) for (int64_t c = 0; c < nc; ++c) for (size_t e = 0; e < (size_t)n * d; ++e) gGX[e] += GX[(size_t)c * n * d + e];
     char nm[160];
     snprintf(nm, sizeof nm, "vjp_dense_%s k%d nt%d n%d m%d d%d sr%d st%d", DT<T>::name(), kinds[0], nt, n, m, d, scale_rank1, st);
-    report(std::string(nm) + " sums", st ? INFINITY : relerr(gS, rS), DT<T>::eps * 2000);
-    report(std::string(nm) + " colsum", st ? INFINITY : relerr(gC, rC), DT<T>::eps * 2000);
-    if (want_gx) report(std::string(nm) + " gradx", st ? INFINITY : relerr(gGX, rGX), DT<T>::eps * 2000);
+    report(std::string(nm) + " sums", st ? INFINITY : relerr(gS, rS), DT<T>::eps * 50);
+    report(std::string(nm) + " colsum", st ? INFINITY : relerr(gC, rC), DT<T>::eps * 50);
+    if (want_gx) report(std::string(nm) + " gradx", st ? INFINITY : relerr(gGX, rGX), DT<T>::eps * 50);
 }
 template <typename T>
 static void test_vjp_dense() {
