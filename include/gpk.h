@@ -46,6 +46,7 @@ extern "C" {
 
 #define GPK_GEMM_LOWER 1
 #define GPK_GEMM_TRI_K 2
+#define GPK_GEMM_TRI_K_LOWER 4
 
 #define GPK_DIAG_BLOCK 128 /* order of the diagonal blocks whose inverses gpk_potrf leaves in `dinv` */
 
@@ -84,7 +85,7 @@ int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t bat
               int* info, int nbo, void* stream);
 
 /* Merge the 128-block inverses into inverses of sb x sb diagonal blocks
- * (sb in {128, 256, 512}); dinv_sb: [batch][ceil(n/sb)][sb][sb];
+ * (sb = 128 * 2^k <= 4096); dinv_sb: [batch][ceil(n/sb)][sb][sb];
  * tmp: >= ceil(n/sb) * sb * sb / 4 elements.  Part of the blocked TRSM below. */
 int gpk_trtri_merge(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
                     const void* dinv128, int sb, void* dinv_sb, void* tmp, void* stream);
@@ -109,7 +110,9 @@ int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, 
  * a_kmajor != 0: A stored M x K (k contiguous); else stored K x M.  Same for B (N x K / K x N).
  * flags: GPK_GEMM_LOWER = only tiles on/below the diagonal (SYRK); GPK_GEMM_TRI_K = both operands
  * vanish for k < their row index (lower-triangular factors stored K x M, e.g. W^T W with W = L^{-1}):
- * all-zero k-chunks are skipped.  Replaces the dense products
+ * all-zero k-chunks are skipped; GPK_GEMM_TRI_K_LOWER = A (M x K) is lower triangular (a(m,k) = 0 for
+ * k > m, e.g. an inverted diagonal block times right-hand sides): the k loop stops at the tile's last row.
+ * Replaces the dense products
  * `B.mm` / `B.matmul` / `B.iqf` outer products: stheno/model/observations.py:322-323,
  * mlkernels.PosteriorKernel (full covariance), `B.sample` (L xi): stheno/random.py:351. */
 int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,

@@ -78,6 +78,10 @@ static inline int64_t gpk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // flags bit 0 (lower_only): compute only tiles with tile_col <= tile_row (SYRK-style).
 // flags bit 1 (tri_k): both operands vanish for k < their row index (lower-triangular
 //   factors stored K x M): the k loop of tile row m0 starts at k = m0.
+// flags bit 2 (tri_k_lower): A (M x K) is lower triangular: the k loop of tile row m0 stops at m0 + tile.
+// merged diagonal-block sizes of the solves: 128 * 2^k up to 4096
+static inline bool gpk_valid_sb(int sb) { return sb >= 128 && sb <= 4096 && (sb & (sb - 1)) == 0; }
+
 template <typename T>
 int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                     const T* A, int64_t lda, int64_t sA, const T* B, int64_t ldb, int64_t sB,

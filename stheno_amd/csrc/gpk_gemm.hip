@@ -52,6 +52,8 @@ struct GemmArgs {
     int lower_only;
     int vec_ok;       // pointers / leading dimensions allow 16-byte loads
     int tri_k;        // operands are lower-triangular in k (zero for k < row index): start at k = m0
+    int tri_k_lo;     // A (M x K) is lower triangular (zero for k > row): stop at k = m0 + TS; tile rows run
+                      // longest-first (bottom rows first)
     int swizzle;
     int n_super;
     int SN;
@@ -75,6 +77,7 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
         }
         ti = bid / p.tiles_n;
         tj = bid - ti * p.tiles_n;
+        if (p.tri_k_lo && ti < p.tiles_m) ti = p.tiles_m - 1 - ti;
         return ti < p.tiles_m && (!p.lower_only || tj <= ti);
     }
     const int xcd = bid & 7, local = bid >> 3;
@@ -173,14 +176,16 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
     return *reinterpret_cast<const T*>(lds + off);
 }
 
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE>
-__global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
+// NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
+// Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT = 1>
+__global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
     constexpr int FR = TS / 32;          // 16x16 fragments per wave in each direction
     constexpr int WT = TS / 2;           // wave sub-tile edge
-    constexpr int OPB = op_bytes(TS), STAGE = 2 * OPB;
+    constexpr int OPB = op_bytes(TS), STAGE = (1 + NCT) * OPB;
 
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
@@ -199,41 +204,48 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs
     const T* __restrict__ B = p.B + b * p.sB + b2 * p.sB2;
     T* __restrict__ C = p.C + b * p.sC + b2 * p.sC2;
 
-    const int m0 = ti * TS, n0 = tj * TS;
+    const int m0 = ti * TS, n0 = tj * TS * NCT;
 
-    acc_t acc[FR][FR];
-    if (p.has_beta) {
+    acc_t acc[NCT][FR][FR];
 #pragma unroll
-        for (int fi = 0; fi < FR; ++fi)
+    for (int c = 0; c < NCT; ++c) {
+        if (p.has_beta) {
 #pragma unroll
-            for (int fj = 0; fj < FR; ++fj)
+            for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
-                    const int col = n0 + wn * WT + fj * 16 + lr;
-                    T v = T(0);
-                    if (!EDGE || (row < p.M && col < p.N)) v = C[(int64_t)row * p.ldc + col];
-                    acc[fi][fj][i] = v * p.beta_over_alpha;
-                }
-    } else {
+                for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
-        for (int fi = 0; fi < FR; ++fi)
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
+                        const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
+                        T v = T(0);
+                        if (!EDGE || (row < p.M && col < p.N)) v = C[(int64_t)row * p.ldc + col];
+                        acc[c][fi][fj][i] = v * p.beta_over_alpha;
+                    }
+        } else {
 #pragma unroll
-            for (int fj = 0; fj < FR; ++fj)
+            for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[fi][fj][i] = T(0);
+                for (int fj = 0; fj < FR; ++fj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[c][fi][fj][i] = T(0);
+        }
     }
 
-    const int nk = (p.K + BK - 1) / BK;
+    int nk = (p.K + BK - 1) / BK;
+    if (p.tri_k_lo) nk = min(nk, (m0 + TS + BK - 1) / BK);   // A vanishes right of its diagonal
     int kc0 = p.tri_k ? m0 / BK : 0;            // all-zero k-chunks of triangular operands are skipped
     if (kc0 > nk - 1) kc0 = nk > 0 ? nk - 1 : 0;
-    vec_t ra[FR], rb[FR];
+    vec_t ra[FR], rb[NCT][FR];
 
-    const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS <= p.N);
+    const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS * NCT <= p.N);
     gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, kc0 * BK, p.M, p.K, tid, a_in && (kc0 + 1) * BK <= p.K);
-    gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, kc0 * BK, p.N, p.K, tid, b_in && (kc0 + 1) * BK <= p.K);
     sstore<T, TS, A_KMAJ>(smem, ra, tid);
-    sstore<T, TS, B_KMAJ>(smem + OPB, rb, tid);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        gload<T, TS, B_KMAJ, EDGE>(rb[c], B, p.ldb, n0 + c * TS, kc0 * BK, p.N, p.K, tid, b_in && (kc0 + 1) * BK <= p.K);
+        sstore<T, TS, B_KMAJ>(smem + (1 + c) * OPB, rb[c], tid);
+    }
     __syncthreads();
 
     for (int kc = kc0; kc < nk; ++kc) {
@@ -243,42 +255,52 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_kernel(GemmArgs
         if (more) {
             const bool k_in = (kc + 2) * BK <= p.K;
             gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid, a_in && k_in);
-            gload<T, TS, B_KMAJ, EDGE>(rb, B, p.ldb, n0, (kc + 1) * BK, p.N, p.K, tid, b_in && k_in);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+                gload<T, TS, B_KMAJ, EDGE>(rb[c], B, p.ldb, n0 + c * TS, (kc + 1) * BK, p.N, p.K, tid, b_in && k_in);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            T a[FR], bb[FR];
+            T a[FR], bb[NCT][FR];
             const int k = kk * 4 + kq;
 #pragma unroll
             for (int f = 0; f < FR; ++f) {
                 a[f] = fragread<T, TS, A_KMAJ>(sA, wm * WT + f * 16, lr, k, swz);
-                bb[f] = fragread<T, TS, B_KMAJ>(sB, wn * WT + f * 16, lr, k, swz);
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    bb[c][f] = fragread<T, TS, B_KMAJ>(sB + c * OPB, wn * WT + f * 16, lr, k, swz);
             }
 #pragma unroll
-            for (int fi = 0; fi < FR; ++fi)
+            for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                for (int fj = 0; fj < FR; ++fj)
-                    acc[fi][fj] = Traits<T>::mfma(a[fi], bb[fj], acc[fi][fj]);
+                for (int fi = 0; fi < FR; ++fi)
+#pragma unroll
+                    for (int fj = 0; fj < FR; ++fj)
+                        acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
         }
         if (more) {
             char* dA = smem + ((kc + 1 - kc0) & 1) * STAGE;
             sstore<T, TS, A_KMAJ>(dA, ra, tid);
-            sstore<T, TS, B_KMAJ>(dA + OPB, rb, tid);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ>(dA + (1 + c) * OPB, rb[c], tid);
         }
         __syncthreads();
     }
 
+    // (in-place use: every global read of this workgroup's rows of A happened above)
 #pragma unroll
-    for (int fi = 0; fi < FR; ++fi)
+    for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int fj = 0; fj < FR; ++fj)
+        for (int fi = 0; fi < FR; ++fi)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
-                const int col = n0 + wn * WT + fj * 16 + lr;
-                if (!EDGE || (row < p.M && col < p.N))
-                    C[(int64_t)row * p.ldc + col] = p.alpha * acc[fi][fj][i];
-            }
+            for (int fj = 0; fj < FR; ++fj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
+                    const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
+                    if (!EDGE || (row < p.M && col < p.N))
+                        C[(int64_t)row * p.ldc + col] = p.alpha * acc[c][fi][fj][i];
+                }
 }
 
 template <typename T, int TS, bool EDGE>
@@ -384,16 +406,28 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.beta_over_alpha = g.has_beta ? beta / alpha : T(0);
     // Tile choice: 128x128 unless that grid cannot even give every CU one workgroup; then
     // 64x64 tiles (4x the workgroups) -- the narrow panel/merge/solve GEMMs of the path.
-    int ts = 128;
+    int ts = 128, nct = 1;
     {
         const int64_t tm = gpk_cdiv(M, 128), tn = gpk_cdiv(N, 128);
         const int64_t t128 = (lower_only && tm == tn ? tm * (tm + 1) / 2 : tm * tn) * batch * batch2;
         if (t128 < g_small_tile_below) ts = 64;
+        // In-place use (C aliases the A operand: the panel TRSM  P <- P inv(L_cc)^T  of the Cholesky):
+        // every workgroup reads the full K range of its rows of A and then overwrites a column slice
+        // of them, so ONE workgroup must own all N columns of a row tile -- with two column tiles a
+        // late workgroup would read what its neighbour already overwrote.
+        if ((const void*)A == (const void*)C || (const void*)B == (const void*)C) {
+            if (N > 128 || ((const void*)B == (const void*)C)) return GPK_ERR_ARG(16);   // cannot be made race-free
+            if (ts == 64 && a_kmaj && b_kmaj)
+                nct = 2;          // 64 x 128 per workgroup: keeps the 2x finer row split of the small-tile path
+            else
+                ts = 128;
+        }
     }
     g.tiles_m = (int)gpk_cdiv(M, ts);
-    g.tiles_n = (int)gpk_cdiv(N, ts);
+    g.tiles_n = (int)gpk_cdiv(N, ts * nct);
     g.lower_only = lower_only ? 1 : 0;
     g.tri_k = (flags & 2) ? 1 : 0;
+    g.tri_k_lo = (flags & 4) ? 1 : 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
@@ -414,7 +448,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&
                          (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
                          (sA2 % VEC == 0) && (sB2 % VEC == 0);
-    const bool edge = !aligned || (M % ts) || (N % ts) || (K % BK);
+    const bool edge = !aligned || (M % ts) || (N % (ts * nct)) || (K % BK);
     g.vec_ok = aligned ? 1 : 0;
 
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
@@ -424,7 +458,12 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         const double fl = (lower_only ? 1.0 : 2.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
         slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), fl, stream);
     }
-    if (ts == 128) {
+    if (nct == 2) {
+        if (edge)
+            hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, true, 2>), grid, dim3(256), 0, stream, g);
+        else
+            hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, false, 2>), grid, dim3(256), 0, stream, g);
+    } else if (ts == 128) {
         if (edge)
             launch_layout<T, 128, true>(a_kmaj, b_kmaj, grid, stream, g);
         else

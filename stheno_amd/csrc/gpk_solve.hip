@@ -222,7 +222,7 @@ template <typename T>
 int gpk_trtri_merge_launch(const T* L, int64_t n, int64_t ld, int64_t batch, int64_t bstride,
                            const T* dinv128, int sb, T* dinv_sb, T* tmp, hipStream_t stream) {
     if (n <= 0 || batch <= 0) return GPK_OK;
-    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(9);
+    if (!gpk_valid_sb(sb)) return GPK_ERR_ARG(9);
     const int nblk128 = (int)gpk_cdiv(n, GPK_DB);
     const int64_t s128 = (int64_t)nblk128 * GPK_DB * GPK_DB;
     const int nsb = (int)gpk_cdiv(n, sb);
@@ -288,7 +288,7 @@ template <typename T>
 int gpk_trsm_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
                     int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream) {
     if (n <= 0 || nrhs <= 0 || batch <= 0) return GPK_OK;
-    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(6);
+    if (!gpk_valid_sb(sb)) return GPK_ERR_ARG(6);
     const int nsb = (int)gpk_cdiv(n, sb);
     const int64_t per = (int64_t)sb * sb, ssb = (int64_t)nsb * per;
     const int64_t st_tmp = (int64_t)sb * nrhs;
@@ -296,7 +296,7 @@ int gpk_trsm_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv
         const int64_t r0 = (int64_t)q * sb;
         const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
         int st = gpk_gemm_launch<T>(true, false, rq, nrhs, rq, T(1), dinv_sb + q * per, sb, ssb,
-                                    B + r0 * ldb, ldb, sB, T(0), tmp, nrhs, st_tmp, batch, false, stream);
+                                    B + r0 * ldb, ldb, sB, T(0), tmp, nrhs, st_tmp, batch, 4, stream);   // inv(L_qq) is lower triangular
         if (st) return st;
         st = gpk_copy2d_launch<T>(tmp, nrhs, st_tmp, B + r0 * ldb, ldb, sB, rq, nrhs, batch, stream);
         if (st) return st;
@@ -318,7 +318,7 @@ template <typename T>
 int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
                     int nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream) {
     if (n <= 0 || nrhs <= 0 || batch <= 0) return GPK_OK;
-    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(6);
+    if (!gpk_valid_sb(sb)) return GPK_ERR_ARG(6);
     if (nrhs > 8) return GPK_ERR_ARG(8);
     if (batch > 65535) return GPK_ERR_ARG(12);
     const int nsb = (int)gpk_cdiv(n, sb);
@@ -349,7 +349,7 @@ template <typename T>
 int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb, T* W, int64_t ldw, T* tmp,
                      hipStream_t stream) {
     if (n <= 0) return GPK_OK;
-    if (sb != 128 && sb != 256 && sb != 512) return GPK_ERR_ARG(6);
+    if (!gpk_valid_sb(sb)) return GPK_ERR_ARG(6);
     int st = gpk_set_identity_launch<T>(W, n, ldw, 0, 1, stream);
     if (st) return st;
     const int nsb = (int)gpk_cdiv(n, sb);

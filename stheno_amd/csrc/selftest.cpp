@@ -134,8 +134,58 @@ static void test_gemm_case(bool ak, bool bk, int M, int N, int K, double alpha, 
     snprintf(nm, sizeof nm, "gemm_%s %c%c M%d N%d K%d a%.0f b%.0f batch%d low%d pad%d st%d", DT<T>::name(), ak ? 'k' : 'r', bk ? 'k' : 'r', M, N, K, alpha, beta, batch, (int)lower, pad, st);
     report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * std::sqrt((double)K + 1));
 }
+// GPK_GEMM_TRI_K_LOWER: A (M x K, k-major) lower triangular -> same result as the full product
+template <typename T>
+static void test_gemm_trilow_case(bool bk, int M, int N) {
+    const int K = M;
+    auto A = randv<T>((size_t)M * K), B = randv<T>((size_t)(bk ? N : K) * (bk ? K : N));
+    for (int m = 0; m < M; ++m) for (int k = m + 1; k < K; ++k) A[(size_t)m * K + k] = T(0);
+    Dev<T> dA(A.size()), dB(B.size()), dC((size_t)M * N);
+    dA.up(A); dB.up(B);
+    int st = gpk_gemm(DT<T>::v, 1, bk, M, N, K, 1.0, dA.p, K, 0, dB.p, bk ? K : N, 0, 0.0, dC.p, N, 0, 1, GPK_GEMM_TRI_K_LOWER, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<double> ref((size_t)M * N, 0.0);
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+        double s = 0;
+        for (int k = 0; k <= m; ++k) s += (double)A[(size_t)m * K + k] * (double)(bk ? B[(size_t)n * K + k] : B[(size_t)k * N + n]);
+        ref[(size_t)m * N + n] = s;
+    }
+    char nm[160];
+    snprintf(nm, sizeof nm, "gemm_trilow_%s k%c M%d N%d st%d", DT<T>::name(), bk ? 'k' : 'r', M, N, st);
+    report(nm, st ? INFINITY : relerr(dC.down(), ref), DT<T>::eps * std::sqrt((double)K + 1));
+}
+// in-place use (C aliases A): P <- P W^T, the panel TRSM of the Cholesky; one workgroup per row tile
+template <typename T>
+static void test_gemm_inplace_case(int M, int64_t lda, int batch) {
+    const int N = 128, K = 128;
+    const int64_t sA = (int64_t)M * lda;
+    auto A = randv<T>((size_t)sA * batch), W = randv<T>((size_t)N * K);
+    Dev<T> dA(A.size()), dW(W.size());
+    dA.up(A); dW.up(W);
+    int st = gpk_gemm(DT<T>::v, 1, 1, M, N, K, 1.0, dA.p, lda, sA, dW.p, K, 0, 0.0, dA.p, lda, sA, batch, 0, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto got = dA.down();
+    std::vector<double> ref(A.begin(), A.end());
+    for (int b = 0; b < batch; ++b)
+        for (int m = 0; m < M; ++m)
+            for (int n = 0; n < N; ++n) {
+                double s = 0;
+                for (int k = 0; k < K; ++k) s += (double)A[b * sA + m * lda + k] * (double)W[(size_t)n * K + k];
+                ref[b * sA + m * lda + n] = s;
+            }
+    char nm[160];
+    snprintf(nm, sizeof nm, "gemm_inplace_%s M%d lda%d batch%d st%d", DT<T>::name(), M, (int)lda, batch, st);
+    report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * 12);
+}
 template <typename T>
 static void test_gemm() {
+    test_gemm_inplace_case<T>(15360, 256, 1);       // 64 x 128 per workgroup (two column tiles)
+    test_gemm_inplace_case<T>(3001, 131, 1);        // ragged, unaligned
+    test_gemm_inplace_case<T>(1920, 130, 80);       // 128-tile path (>= 1024 tiles)
+    test_gemm_trilow_case<T>(false, 512, 2048);     // 64x64 tiles
+    test_gemm_trilow_case<T>(false, 300, 70);       // ragged
+    test_gemm_trilow_case<T>(true, 1024, 256);
+    test_gemm_trilow_case<T>(false, 1024, 8192 + 64);   // 128x128 tiles (>= 1024 of them), ragged edge
     for (int ak = 0; ak < 2; ++ak)
         for (int bk = 0; bk < 2; ++bk) {
             test_gemm_case<T>(ak, bk, 128, 128, 128, 1, 0, 1, false, 0);

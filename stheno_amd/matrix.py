@@ -29,8 +29,23 @@ class _Config:
 config = _Config()
 
 
-def _solve_block(n):
-    """Diagonal-block size used by the many-right-hand-side triangular solve."""
+def _solve_block(n, nrhs, fp64=True):
+    """Size of the merged (explicitly inverted) diagonal blocks used by the triangular solves --
+    measured on MI355X (profiles/r01_experiments.md): the few-right-hand-side GEMV sweep is
+    launch-latency-bound (512-blocks); the many-right-hand-side sweep runs on the MFMA GEMM, where
+    bigger blocks mean fewer, better-filled launches (fp64: 1024 from n = 8192, 2048 from n = 32768;
+    in fp32 the posterior mean loses accuracy with the block size -- 3e-4 / 6e-4 / 1.1e-3 / 2.4e-3 relative
+    at 128 / 512 / 1024 / 2048 for cfg3's kernel at N = 8192 -- so fp32 stays at 512); with far more
+    right-hand sides than unknowns (pseudo-point path: M x N with N >> M; accuracy measured insensitive
+    to the block size there) the whole factor is inverted once (M^3/3 flops) and the solve is ONE
+    triangular GEMM."""
+    if nrhs > 8:
+        if nrhs >= 4 * n and n >= 1024:
+            return min(4096, 1 << (n - 1).bit_length())
+        if fp64 and n >= 32768:
+            return 2048
+        if fp64 and n >= 8192:
+            return 1024
     if n >= 2048:
         return 512
     if n >= 512:
@@ -84,7 +99,7 @@ class Chol:
         # Batched factors keep the 128-blocks (the merge loops over the batch on the host and the
         # batch already fills the GPU); a single large factor always uses the merged blocks, also
         # for the few-rhs GEMV sweep: 4x fewer (launch-latency-bound) steps for a 0.2 ms merge.
-        sb = 128 if self.l.dim() > 2 else _solve_block(n)
+        sb = 128 if self.l.dim() > 2 else _solve_block(n, nrhs, self.l.dtype == torch.float64)
         if sb not in self._dinv_sb:
             self._dinv_sb[sb] = ops.get_backend().trtri_merge(self.l, self.dinv, sb)
         return sb, self._dinv_sb[sb]

@@ -231,7 +231,7 @@ class HipBackend:
         return w
 
     def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False,
-             tri_k=False):
+             tri_k=False, tri_k_lower=False):
         """``out[m, n] = alpha * sum_k a(m, k) b(n, k) + beta * out``.
 
         ``a_kmajor``: ``a`` is stored (M, K); otherwise (K, M).  ``b_kmajor``: ``b`` is stored
@@ -251,7 +251,8 @@ class HipBackend:
         o3, _ = _as3(out)
         code = self.lib.gpk_gemm(_dtype_id(a3), int(a_kmajor), int(b_kmajor), M, N, K, float(alpha), self._ptr(a3),
                                  _ld(a3), _bs(a3), self._ptr(b3), _ld(b3), _bs(b3), float(beta), self._ptr(o3),
-                                 _ld(o3), _bs(o3), B, int(lower_only) | (2 if tri_k else 0), self._stream())
+                                 _ld(o3), _bs(o3), B, int(lower_only) | (2 if tri_k else 0) | (4 if tri_k_lower else 0),
+                                 self._stream())
         self._st(code, "gpk_gemm")
         return out
 

@@ -97,7 +97,7 @@ class OracleBackend:
         return self._t(np.linalg.inv(np.tril(_np(l))), l)
 
     def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False,
-             tri_k=False):
+             tri_k=False, tri_k_lower=False):
         A = a if a_kmajor else a.transpose(-1, -2)
         Bt = b.transpose(-1, -2) if b_kmajor else b
         res = alpha * (A @ Bt)
