@@ -359,7 +359,7 @@ int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb
         const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
         const int64_t nc = r0 + rq;          // columns that can be non-zero in block row q
         st = gpk_gemm_launch<T>(true, false, rq, nc, rq, T(1), dinv_sb + q * per, sb, 0, W + r0 * ldw, ldw, 0, T(0),
-                                tmp, nc, 0, 1, 0, stream);
+                                tmp, nc, 0, 1, 4, stream);   // inv(L_qq) is lower triangular
         if (st) return st;
         st = gpk_copy2d_launch<T>(tmp, nc, 0, W + r0 * ldw, ldw, 0, rq, nc, 1, stream);
         if (st) return st;

@@ -96,6 +96,34 @@ def test_cholesky_solve_logdet(dtype, n):
     assert rel(c.iqf_diag(dev(b, dtype)), O.iqf_diag(l_ref, b)) < tol * 10
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n", [129, 1000, 2500])
+def test_strict_upper_triangle_is_never_read(dtype, n):
+    """The path builds K lower-triangle-only into uninitialised memory and factorises in place:
+    nothing may depend on what the strict upper triangle holds.  Poison it with NaN."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 3))
+    k = O.kernel_matrix([("eq", 1.0, 1.0)], x) + 0.5 * np.eye(n)
+    a = dev(k, dtype).clone()
+    a[torch.triu(torch.ones(n, n, dtype=torch.bool, device=a.device), diagonal=1)] = float("nan")
+    c = Chol.factor_(a).check()
+    l_ref = np.linalg.cholesky(k)
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    assert rel(torch.tril(c.l), l_ref) < tol
+    assert abs(float(c.logdet()) - O.logdet_chol(l_ref)) < tol * max(1.0, abs(O.logdet_chol(l_ref)))
+    for nrhs in (1, 40):
+        b = rng.standard_normal((n, nrhs))
+        got = c.solve(dev(b, dtype))
+        assert torch.isfinite(got).all() and rel(got, O.solve_lower(l_ref, b)) < tol * 10
+    w = c.inverse_lower()
+    assert torch.isfinite(torch.tril(w)).all() and rel(torch.tril(w), np.linalg.inv(l_ref)) < tol * 100
+    # the fused kernel-matrix build in `lower` mode into a poisoned buffer, then the whole logpdf
+    out = torch.full((n, n), float("nan"), dtype=dtype, device=a.device)
+    ops.get_backend().kmat(ops.KTerms([("eq", 1.0, 1.0)]), dev(x, dtype), None, lower=True, diag_add=0.5, out=out)
+    c2 = Chol.factor_(out).check()
+    assert rel(torch.tril(c2.l), l_ref) < tol
+
+
 def test_not_positive_definite_raises():
     a = dev(np.array([[1.0, 2.0], [2.0, 1.0]]))
     with pytest.raises(torch.linalg.LinAlgError):
