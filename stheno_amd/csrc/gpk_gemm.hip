@@ -24,9 +24,12 @@
 //    8-lane ds_write_b128 groups are conflict-free.  An operand stored with the
 //    row index contiguous is staged as [BK][128 + 16] (pad keeps the two
 //    k-rows of a 32-lane group on different bank halves).
-//  * blockIdx -> tile mapping is XCD-aware for big grids: workgroup b runs on
-//    XCD b % 8, and each XCD walks 8x8 super-tiles so that the 64 tiles in
-//    flight on one XCD share 16 operand panels in that XCD's 4 MiB L2.
+//  * blockIdx -> tile mapping: plain row-major (triangular for the lower-only mode);
+//    workgroup b runs on XCD b % 8, so consecutive tiles of a tile row spread over the 8
+//    L2s.  An 8x8-super-tile-per-XCD order (each XCD's 64 tiles in flight share 16 operand
+//    panels of its 4 MiB L2) is implemented behind g_swizzle_from but OFF by default: on
+//    MI355X it measured 4 % SLOWER on the Cholesky trailing update (ragged diagonal
+//    super-tiles unbalance the XCDs; the 256 MB MALL already serves the panel re-reads).
 //  * accumulators are initialised with C * (beta / alpha) so the epilogue is a
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
