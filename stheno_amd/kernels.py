@@ -308,6 +308,21 @@ class Stretched(Kernel):
         return f"({self.k!r} > {self.scale})"
 
 
+def _merge_terms(terms):
+    """Add up the variances of terms with the same primitive and the same length scale (``p + p``
+    has the kernel ``4 k``, not four terms; the fused kernels take at most 8 distinct terms)."""
+    out = []
+    for kind, var, scale in terms:
+        for i, (k2, v2, s2) in enumerate(out):
+            same = (scale is s2) if (torch.is_tensor(scale) or torch.is_tensor(s2)) else (scale == s2)
+            if k2 == kind and same:
+                out[i] = (k2, v2 + var, s2)
+                break
+        else:
+            out.append((kind, var, scale))
+    return out
+
+
 class Sum(Kernel):
     def __init__(self, a, b):
         self.a, self.b = a, b
@@ -317,13 +332,13 @@ class Sum(Kernel):
         ta, tb = self.a.terms(), self.b.terms()
         if ta is None or tb is None:
             return None
-        return ta + tb
+        return _merge_terms(ta + tb)
 
     def tensor_terms(self):
         ta, tb = self.a.tensor_terms(), self.b.tensor_terms()
         if ta is None or tb is None:
             return None
-        return ta + tb
+        return _merge_terms(ta + tb)
 
     def pairwise(self, x, y=None, **kw):
         if self.terms() is not None:

@@ -178,3 +178,86 @@ def test_additive_decomposition_gpu():
 @pytest.mark.usefixtures("hip_backend")
 def test_joint_sampling_and_errors_gpu():
     _sampling_and_errors()
+
+
+# ---------------------------------------------------------------------------------------------
+# Mirrors of the reference's own multi-process tests (cited per function).
+# ---------------------------------------------------------------------------------------------
+def _reference_mirrors(tol):
+    lin = lambda a, b, k: t(np.linspace(a, b, k))
+
+    # tests/model/test_observations.py:8-44 (test_combine)
+    x1, x2 = lin(0, 2, 10), lin(2, 4, 10)
+    m = st.Measure()
+    p1 = st.GP(1, st.EQ(), measure=m)
+    p2 = st.GP(2, st.Matern12(), measure=m)
+    g = torch.Generator(device=_dev()).manual_seed(0)
+    y1, y2 = p1(x1).sample(generator=g), p2(x2).sample(generator=g)
+    assert st.combine(p1(x1, 1)).x is x1
+    fdd_c, y_c = st.combine((p1(x1, 1), y1[:, 0]))
+    np.testing.assert_allclose(n(y_c).reshape(-1), n(y1)[:, 0])
+    for fdd_c in (st.combine(p1(x1, 1), p2(x2, 2)), st.combine((p1(x1, 1), y1[:, 0]), (p2(x2, 2), y2))[0]):
+        np.testing.assert_allclose(n(fdd_c.mean), np.concatenate([n(p1(x1, 1).mean), n(p2(x2, 2).mean)]), atol=tol)
+        want = np.zeros((20, 20))
+        want[:10, :10], want[10:, 10:] = n(B.dense(p1(x1, 1).var)), n(B.dense(p2(x2, 2).var))
+        np.testing.assert_allclose(n(B.dense(fdd_c.var)), want, atol=tol)
+    _, y_c = st.combine((p1(x1, 1), y1[:, 0]), (p2(x2, 2), y2))
+    np.testing.assert_allclose(n(y_c), np.concatenate([n(y1), n(y2)]))
+
+    # tests/model/test_model.py:533-560 (test_multi_sample): constant processes
+    m = st.Measure()
+    q1, q2, q3 = st.GP(1, 0, measure=m), st.GP(2, 0, measure=m), st.GP(3, 0, measure=m)
+    s1, s2, s3 = m.sample(q1(lin(0, 1, 5)), q2(lin(0, 1, 10)), q3(lin(0, 1, 15)), generator=g)
+    assert s1.shape == (5, 1) and s2.shape == (10, 1) and s3.shape == (15, 1)
+    for s, v in ((s1, 1), (s2, 2), (s3, 3)):
+        np.testing.assert_allclose(n(s), v, atol=1e-4)       # sqrt(B.epsilon) of jitter noise
+
+    # tests/model/test_model.py:563-570 (test_sample_correct_measure)
+    m = st.Measure()
+    p = st.GP(1, st.EQ(), measure=m)
+    post = m | (p(t(0.0)), t([1.0]))
+    np.testing.assert_allclose(n(post.sample(10, p(t(0.0)), generator=g)), np.ones((1, 10)), atol=1e-4)
+
+    # tests/model/test_cases.py:9-19 (test_summation_with_itself)
+    p = st.GP(1, st.EQ())
+    p_many = p + p + p + p + p
+    x = lin(0, 10, 5)
+    np.testing.assert_allclose(n(B.dense(p_many(x).var)), 25 * n(B.dense(p(x).var)), atol=tol)
+    np.testing.assert_allclose(n(p_many(x).mean), 5 * np.ones((5, 1)), atol=tol)
+    y = t(np.random.default_rng(0).standard_normal((5, 1)))
+    post = p.measure | (p(x), y)
+    np.testing.assert_allclose(n(post(p_many)(x).mean), 5 * n(y), atol=1e-4)
+
+    # tests/model/test_cases.py:22-53 (test_additive_model)
+    m = st.Measure()
+    p1, p2 = st.GP(1, st.EQ(), measure=m), st.GP(2, st.EQ(), measure=m)
+    p_sum = p1 + p2
+    x = lin(0, 5, 10)
+    y1, y2 = p1(x).sample(generator=g), p2(x).sample(generator=g)
+    assert m.kernels[p2, p1] == st.ZeroKernel() and m.kernels[p1, p2] == st.ZeroKernel()
+    for first, second, target, want in (
+        ((p1, y1), (p2, y2), p_sum, y1 + y2), ((p2, y2), (p1, y1), p_sum, y1 + y2),
+        ((p1, y1), (p_sum, y1 + y2), p2, y2), ((p_sum, y1 + y2), (p1, y1), p2, y2),
+        ((p2, y2), (p_sum, y1 + y2), p1, y1), ((p_sum, y1 + y2), (p2, y2), p1, y1),
+    ):
+        post = (m | (first[0](x), first[1])) | (second[0](x), second[1])
+        np.testing.assert_allclose(n(post(target)(x).mean), n(want), atol=2e-3)   # two interpolations at eps = 1e-12
+
+    # tests/model/test_cases.py:81-92 (test_negation)
+    p = st.GP(1, st.EQ())
+    pn = -p
+    x = lin(0, 5, 10)
+    y = p(x).sample(generator=g)
+    np.testing.assert_allclose(n((p.measure | (p(x), y))(pn)(x).mean), -n(y), atol=1e-4)
+    np.testing.assert_allclose(n((p.measure | (pn(x), -y))(p)(x).mean), n(y), atol=1e-4)
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_reference_multi_process_cases_cpu():
+    _reference_mirrors(1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_reference_multi_process_cases_gpu():
+    _reference_mirrors(1e-9)
