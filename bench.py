@@ -127,7 +127,7 @@ def pmc_traffic(name, w):
         return None
     with open(path) as f:
         d = json.load(f)
-    k = d["kernels"].get("gemm_kernel<%s, 128, true, true, false>" % ("double" if w["dtype"] == "f64" else "float"))
+    k = d["kernels"].get("gemm_kernel<%s, 128, true, true, false, 1>" % ("double" if w["dtype"] == "f64" else "float"))
     return None if k is None else k["hbm_bytes_per_launch"]
 
 
@@ -237,7 +237,7 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         peak = PEAK_TFLOPS[w["dtype"]]
         roofline = {
-            "kernel": f"gemm_kernel<{'double' if w['dtype'] == 'f64' else 'float'}, 128, true, true, false>",
+            "kernel": f"gemm_kernel<{'double' if w['dtype'] == 'f64' else 'float'}, 128, true, true, false, 1>",
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": pmc_traffic(name, w),
             "launches_per_step": nl.value // prof_steps,

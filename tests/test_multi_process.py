@@ -252,6 +252,46 @@ def _reference_mirrors(tol):
     np.testing.assert_allclose(n((p.measure | (pn(x), -y))(p)(x).mean), n(y), atol=1e-4)
 
 
+def _reference_logpdf(cls, tol):
+    """tests/model/test_model.py:376-404 (test_logpdf)."""
+    lin = lambda a, b, k: t(np.linspace(a, b, k))
+    m = st.Measure()
+    p1 = st.GP(1, st.EQ(), measure=m)
+    p2 = st.GP(2, st.Exp(), measure=m)
+    p3 = p1 + p2
+    x1, x2, x3 = lin(0, 2, 5), lin(1, 3, 6), lin(2, 4, 7)
+    g = torch.Generator(device=_dev()).manual_seed(5)
+    y1, y2, y3 = m.sample(p1(x1), p2(x2), p3(x3), generator=g)
+    np.testing.assert_allclose(float(p1(x1).logpdf(y1)), float(m.logpdf(p1(x1), y1)), rtol=tol)
+    np.testing.assert_allclose(float(p1(x1).logpdf(y1)), float(m.logpdf((p1(x1), y1))), rtol=tol)
+    d1 = m
+    d2 = d1 | (p1(x1), y1)
+    d3 = d2 | (p2(x2), y2)
+    # The joint sample lies (to sqrt(B.epsilon)) in a 11-dimensional subspace of the 18 observations
+    # (p3 = p1 + p2 is observed without noise), so the two sides agree only as far as the jitter
+    # allows; with observation noise the identity holds to rounding.
+    d3n = (d1 | (p1(x1, 0.1), y1)) | (p2(x2, 0.2), y2)
+    lhs = d1(p1)(x1, 0.1).logpdf(y1) + (d1 | (p1(x1, 0.1), y1))(p2)(x2, 0.2).logpdf(y2) + d3n(p3)(x3, 0.3).logpdf(y3)
+    rhs = m.logpdf((p1(x1, 0.1), y1), (p2(x2, 0.2), y2), (p3(x3, 0.3), y3))
+    np.testing.assert_allclose(float(lhs), float(rhs), rtol=tol)
+    assert d3 is not None
+    obs = st.Obs(p3(x3), y3)
+    np.testing.assert_allclose(float(m.logpdf(obs)), float(p3(x3).logpdf(y3)), rtol=tol)
+    obs = cls(p3(x3), p3(x3, 1), y3)
+    np.testing.assert_allclose(float(m.logpdf(obs)), float(p3(x3, 1).logpdf(y3)), rtol=1e-6)
+
+
+@pytest.mark.parametrize("cls", [st.PseudoObs, st.PseudoObsFITC, st.PseudoObsDTC])
+def test_reference_logpdf_cpu(oracle_backend, cls):
+    _reference_logpdf(cls, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", [st.PseudoObs, st.PseudoObsFITC, st.PseudoObsDTC])
+def test_reference_logpdf_gpu(hip_backend, cls):
+    _reference_logpdf(cls, 1e-7)
+
+
 @pytest.mark.usefixtures("oracle_backend")
 def test_reference_multi_process_cases_cpu():
     _reference_mirrors(1e-9)
