@@ -58,6 +58,7 @@ struct GemmArgs {
     int tri_k_lo;     // A (M x K) is lower triangular (zero for k > row): stop at k = m0 + TS; tile rows run
                       // longest-first (bottom rows first)
     int swizzle;
+    int tri_pairs;    // triangular enumeration by row pairs / 8-column chunks (see decode_tile)
     int n_super;
     int SN;
 };
@@ -74,6 +75,28 @@ template <typename T>
 __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& ti, int& tj) {
     const bool tri = p.lower_only && p.tiles_m == p.tiles_n;   // square: triangular enumeration
     if (!p.swizzle) {
+        if (tri && p.tri_pairs) {
+            // rows in pairs, columns in chunks of 8: [row 2q, cols c..c+7][row 2q+1, cols c..c+7] ...
+            // the two tiles of a column sit 8 workgroups apart = on the same XCD, back to back:
+            // each B panel is fetched once per row PAIR into that XCD's L2.  Pair q spans 2q+2 columns.
+            int q = (int)((sqrtf(1.f + 2.f * (float)bid) - 1.f) * 0.5f);
+            while (2 * (q + 1) * (q + 2) <= bid) ++q;
+            while (2 * q * (q + 1) > bid) --q;
+            const int w = bid - 2 * q * (q + 1), width = 2 * q + 2;
+            const int c = w >> 4, i = w & 15;
+            int r, col;
+            if (8 * c + 8 <= width) {
+                r = i >> 3;
+                col = 8 * c + (i & 7);
+            } else {
+                const int rem = width - 8 * c;
+                r = i / rem;
+                col = 8 * c + i % rem;
+            }
+            ti = 2 * q + r;
+            tj = col;
+            return ti < p.tiles_m && tj <= ti && r < 2;
+        }
         if (tri) {
             tri_decode(bid, ti, tj);
             return ti < p.tiles_m;
@@ -346,6 +369,7 @@ struct Prof {
 Prof g_prof;
 
 int64_t g_small_tile_below = 1024;  // tuning knob (gpk_debug_set(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
+int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_debug_set(4, v)): row-pair order from this many tiles
 int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_debug_set(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
                                     // unbalance the XCDs), so it is off unless asked for
@@ -356,6 +380,7 @@ int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_debug_set(2, v)); r01 sw
 extern "C" void gpk_debug_set(int key, int64_t value) {
     if (key == 1) g_small_tile_below = value;
     if (key == 2) g_swizzle_from = (int)value;
+    if (key == 4) g_tri_pairs_from = (int)value;
 }
 
 extern "C" int gpk_prof_start(void) {
@@ -438,6 +463,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     int64_t gridx;
     g.swizzle = (total >= g_swizzle_from) ? 1 : 0;
     g.n_super = 0;
+    g.tri_pairs = 0;
     g.SN = 1;
     if (g.swizzle) {
         const int SM = (g.tiles_m + 7) / 8;
@@ -446,6 +472,11 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         gridx = gpk_cdiv(g.n_super, 8) * 8 * 64;
     } else {
         gridx = total;
+        g.tri_pairs = (tri && total >= g_tri_pairs_from) ? 1 : 0;
+        if (g.tri_pairs) {
+            const int64_t P = (g.tiles_m + 1) / 2;
+            gridx = 2 * P * (P + 1);
+        }
     }
 
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&

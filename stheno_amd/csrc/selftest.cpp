@@ -958,6 +958,12 @@ int main(int argc, char** argv) {
         gpk_debug_set(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
         test_gemm<double>(); test_gemm<float>();
         gpk_debug_set(1, 1024);              // library default
+        gpk_debug_set(2, 64);                // the (default-off) XCD super-tile order
+        test_gemm<double>(); test_gemm<float>();
+        gpk_debug_set(2, (int64_t)1 << 30);
+        gpk_debug_set(4, 1);                 // the (default-off) row-pair triangular order
+        test_gemm<double>(); test_gemm<float>();
+        gpk_debug_set(4, (int64_t)1 << 30);
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_misc<double>(); test_misc<float>();
