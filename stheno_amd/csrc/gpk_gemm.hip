@@ -33,6 +33,7 @@
 //  * accumulators are initialised with C * (beta / alpha) so the epilogue is a
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -262,29 +263,31 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
     if (p.tri_k_lo) nk = min(nk, (m0 + TS + BK - 1) / BK);   // A vanishes right of its diagonal
     int kc0 = p.tri_k ? m0 / BK : 0;            // all-zero k-chunks of triangular operands are skipped
     if (kc0 > nk - 1) kc0 = nk > 0 ? nk - 1 : 0;
-    vec_t ra[FR], rb[NCT][FR];
+    // Register staging.  Small tiles (TS = 64) serve the narrow, latency-bound GEMMs of the path
+    // (panel / merge / solve), where a workgroup is often alone on its CU: they keep TWO k-chunks of
+    // global loads in flight (PF2); the 128-tile kernel hides the latency with its second workgroup.
+    constexpr bool PF2 = (TS == 64);
+    vec_t ra[PF2 ? 2 : 1][FR], rb[PF2 ? 2 : 1][NCT][FR];
 
     const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS * NCT <= p.N);
-    gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, kc0 * BK, p.M, p.K, tid, a_in && (kc0 + 1) * BK <= p.K);
-    sstore<T, TS, A_KMAJ>(smem, ra, tid);
+    auto issue = [&](auto set_c, int kc) {           // global -> register set `set`
+        constexpr int set = decltype(set_c)::value;
+        const bool k_in = (kc + 1) * BK <= p.K;
+        gload<T, TS, A_KMAJ, EDGE>(ra[set], A, p.lda, m0, kc * BK, p.M, p.K, tid, a_in && k_in);
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        gload<T, TS, B_KMAJ, EDGE>(rb[c], B, p.ldb, n0 + c * TS, kc0 * BK, p.N, p.K, tid, b_in && (kc0 + 1) * BK <= p.K);
-        sstore<T, TS, B_KMAJ>(smem + (1 + c) * OPB, rb[c], tid);
-    }
-    __syncthreads();
-
-    for (int kc = kc0; kc < nk; ++kc) {
-        const char* sA = smem + ((kc - kc0) & 1) * STAGE;
+        for (int c = 0; c < NCT; ++c)
+            gload<T, TS, B_KMAJ, EDGE>(rb[set][c], B, p.ldb, n0 + c * TS, kc * BK, p.N, p.K, tid, b_in && k_in);
+    };
+    auto commit = [&](auto set_c, int stage) {       // register set -> LDS stage
+        constexpr int set = decltype(set_c)::value;
+        char* dA = smem + stage * STAGE;
+        sstore<T, TS, A_KMAJ>(dA, ra[set], tid);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ>(dA + (1 + c) * OPB, rb[set][c], tid);
+    };
+    auto mma = [&](int stage) {
+        const char* sA = smem + stage * STAGE;
         const char* sB = sA + OPB;
-        const bool more = (kc + 1 < nk);
-        if (more) {
-            const bool k_in = (kc + 2) * BK <= p.K;
-            gload<T, TS, A_KMAJ, EDGE>(ra, A, p.lda, m0, (kc + 1) * BK, p.M, p.K, tid, a_in && k_in);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c)
-                gload<T, TS, B_KMAJ, EDGE>(rb[c], B, p.ldb, n0 + c * TS, (kc + 1) * BK, p.N, p.K, tid, b_in && k_in);
-        }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             T a[FR], bb[NCT][FR];
@@ -304,13 +307,39 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
                     for (int fj = 0; fj < FR; ++fj)
                         acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
         }
-        if (more) {
-            char* dA = smem + ((kc + 1 - kc0) & 1) * STAGE;
-            sstore<T, TS, A_KMAJ>(dA, ra, tid);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ>(dA + (1 + c) * OPB, rb[c], tid);
-        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, PF2 ? 1 : 0> S1;
+
+    if (PF2) {
+        issue(S0{}, kc0);
+        if (kc0 + 1 < nk) issue(S1{}, kc0 + 1);
+        commit(S0{}, 0);
         __syncthreads();
+        for (int kc = kc0; kc < nk; kc += 2) {
+            // LDS stage 0 holds chunk kc, register set 1 holds chunk kc + 1
+            if (kc + 2 < nk) issue(S0{}, kc + 2);
+            mma(0);
+            if (kc + 1 >= nk) break;
+            commit(S1{}, 1);
+            __syncthreads();
+            // LDS stage 1 holds chunk kc + 1, register set 0 holds chunk kc + 2
+            if (kc + 3 < nk) issue(S1{}, kc + 3);
+            mma(1);
+            if (kc + 2 < nk) commit(S0{}, 0);
+            __syncthreads();
+        }
+    } else {
+        issue(S0{}, kc0);
+        commit(S0{}, 0);
+        __syncthreads();
+        for (int kc = kc0; kc < nk; ++kc) {
+            const bool more = (kc + 1 < nk);
+            if (more) issue(S0{}, kc + 1);
+            mma((kc - kc0) & 1);
+            if (more) commit(S0{}, (kc + 1 - kc0) & 1);
+            __syncthreads();
+        }
     }
 
     // (in-place use: every global read of this workgroup's rows of A happened above)
