@@ -675,6 +675,21 @@ static void profile_one(int n, int nbo, int reps) {
     }
 }
 
+// one GEMM shape, timed alone:  --gemm f64|f32 M N K [lower]   (k-major operands, C = C - A B^T)
+template <typename T>
+static void gemm_one(int M, int N, int K, int flags, int reps) {
+    Dev<T> A((size_t)M * K), B((size_t)N * K), C((size_t)M * N);
+    A.up(randv<T>((size_t)M * K, 0.01)); B.up(randv<T>((size_t)N * K, 0.01)); C.zero();
+    Timer tm;
+    for (int rep = 0; rep < reps; ++rep) {
+        tm.start();
+        gpk_gemm(DT<T>::v, 1, 1, M, N, K, -1.0, A.p, K, 0, B.p, K, 0, 1.0, C.p, N, 0, 1, flags, nullptr);
+        const float ms = tm.stop();
+        const double fl = ((flags & 1) ? 1.0 : 2.0) * M * (double)N * K;
+        printf("GEMM %s M=%d N=%d K=%d flags=%d  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), M, N, K, flags, ms, fl / ms * 1e-9);
+    }
+}
+
 __global__ void rsq_probe(const double* x, double* y, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = __builtin_amdgcn_rsq(x[i]);
@@ -943,6 +958,12 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--profile") && i + 3 < argc) {   // --profile f64|f32 N NBO
             const int n = atoi(argv[i + 2]), nbo = atoi(argv[i + 3]);
             if (!strcmp(argv[i + 1], "f64")) profile_one<double>(n, nbo, 2); else profile_one<float>(n, nbo, 2);
+            return 0;
+        }
+        if (!strcmp(argv[i], "--gemm") && i + 4 < argc) {      // --gemm f64|f32 M N K [flags]
+            const int M = atoi(argv[i + 2]), N = atoi(argv[i + 3]), K = atoi(argv[i + 4]);
+            const int flags = (i + 5 < argc) ? atoi(argv[i + 5]) : 0;
+            if (!strcmp(argv[i + 1], "f64")) gemm_one<double>(M, N, K, flags, 4); else gemm_one<float>(M, N, K, flags, 4);
             return 0;
         }
         if (!strcmp(argv[i], "--perf")) do_perf = true;
