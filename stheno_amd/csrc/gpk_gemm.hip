@@ -288,6 +288,38 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
     auto mma = [&](int stage) {
         const char* sA = smem + stage * STAGE;
         const char* sB = sA + OPB;
+        if constexpr (sizeof(T) == 4 && A_KMAJ && B_KMAJ) {
+            // fp32, both operands k-contiguous: a lane fetches TWO consecutive k values with one
+            // ds_read_b64 and feeds them to two successive MFMAs.  The contraction order inside the
+            // chunk is permuted identically for A and B (step 2p+e, lane group kq <-> k = 8p + 2kq + e),
+            // which is harmless for a sum.  Halves the LDS read instructions and removes the 2-way
+            // bank conflict of ds_read_b32 on a 128-byte row pitch (bank = dword mod 32: the two
+            // rows 2a, 2a+1 of a 32-lane group alias); the b64 pattern equals the fp64 one.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pp = 0; pp < BK / 8; ++pp) {
+                f2 a2[FR], b2[NCT][FR];
+                const int u = pp * 4 + kq;           // 8-byte unit of the 128-byte row
+                const int uo = (((u >> 1) ^ swz) << 4) + (u & 1) * 8;
+#pragma unroll
+                for (int f = 0; f < FR; ++f) {
+                    a2[f] = *reinterpret_cast<const f2*>(sA + (wm * WT + f * 16 + lr) * 128 + uo);
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+                        b2[c][f] = *reinterpret_cast<const f2*>(sB + c * OPB + (wn * WT + f * 16 + lr) * 128 + uo);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int fi = 0; fi < FR; ++fi)
+#pragma unroll
+                            for (int fj = 0; fj < FR; ++fj)
+                                acc[c][fi][fj] = Traits<T>::mfma((T)a2[fi][e], (T)b2[c][fj][e], acc[c][fi][fj]);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             T a[FR], bb[NCT][FR];
