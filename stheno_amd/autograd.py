@@ -114,7 +114,7 @@ class _SparseELBO(torch.autograd.Function):
         d = noise_vec.detach()
         v = be.kmat(terms, z, x)                                               # K_zx
         chol_z = Chol.factor_(be.kmat(terms, z, None, lower=True, diag_add=config.epsilon))
-        chol_z.solve_(v)                                                       # V
+        v = chol_z.solve_(v)                                                   # V
         _, q = be.colreduce(v, want_ss=True)
         corr = be.kdiag(terms, x) - q
         s = torch.rsqrt(d)

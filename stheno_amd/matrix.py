@@ -104,8 +104,22 @@ class Chol:
             self._dinv_sb[sb] = ops.get_backend().trtri_merge(self.l, self.dinv, sb)
         return sb, self._dinv_sb[sb]
 
+    def _apply_full_inverse(self, b):
+        """``L^{-1} b`` as ONE triangular GEMM into a fresh buffer when the whole factor has been inverted
+        (far more right-hand sides than unknowns, see ``_solve_block``); ``None`` if that does not apply."""
+        if self.l.dim() != 2 or b.dim() != 2 or b.shape[-1] <= 8:
+            return None
+        sb, dsb = self._blocks(b.shape[-1])
+        if dsb is None or sb < self.n:
+            return None
+        return ops.get_backend().gemm(dsb[0, 0][: self.n, : self.n], b, a_kmajor=True, b_kmajor=False, tri_k_lower=True)
+
     def solve_(self, b):
-        """``b <- L^{-1} b`` in place (``b``: (..., n, nrhs), unit inner stride)."""
+        """``L^{-1} b``, overwriting ``b`` where possible (``b``: (..., n, nrhs), unit inner stride).
+        Use the RETURN value: the single-GEMM case writes a fresh buffer and leaves ``b`` as it was."""
+        out = self._apply_full_inverse(b)
+        if out is not None:
+            return out
         sb, dsb = self._blocks(b.shape[-1])
         return ops.get_backend().tri_solve_(self.l, dsb, sb, b)
 
@@ -116,6 +130,9 @@ class Chol:
         lb, bb = tuple(self.l.shape[:-2]), tuple(b.shape[:-2])
         if lb and bb and lb != bb:
             raise ValueError(f"batch shapes {lb} and {bb} do not match")
+        out = self._apply_full_inverse(b)
+        if out is not None:
+            return out
         out = b.expand((lb or bb) + tuple(b.shape[-2:])).clone(memory_format=torch.contiguous_format)
         return self.solve_(out)
 
