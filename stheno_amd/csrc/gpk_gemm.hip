@@ -286,6 +286,9 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
         for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ>(dA + (1 + c) * OPB, rb[set][c], tid);
     };
     auto mma = [&](int stage) {
+        // scheduler hint: interleave the LDS reads with the MFMAs of this k-chunk (measured +2 % for fp64,
+        // -7 % for fp32, whose paired-k reads already leave fewer LDS instructions)
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_iglp_opt(0);
         const char* sA = smem + stage * STAGE;
         const char* sB = sA + OPB;
         if constexpr (sizeof(T) == 4 && A_KMAJ && B_KMAJ) {
