@@ -418,6 +418,8 @@ static void test_potrf() {
     test_potrf_case<T>(1024, 1, 256, 1, 256, 512);
     test_potrf_case<T>(1200, 1, 512, 4, 100, 512);
     test_potrf_case<T>(1664, 1, 256, 1, 300, 256);
+    test_potrf_case<T>(700, 70, 256, 1, 0, 128);     // larger batch, ragged
+    test_potrf_case<T>(512, 64, 128, 2, 0, 128);
 }
 
 // ----------------------------------------------------------------------------
