@@ -5,7 +5,7 @@
 // LAPACK dpotrf/spotrf under `B.logdet` / `B.iqf_diag` (stheno/random.py:274-276)
 // and under `B.cholesky(K_z)` (stheno/model/observations.py:300).
 //
-// Structure per outer block of `nbo` columns (nbo = 256 by default):
+// Structure per outer block of `nbo` columns (nbo = 1024 from n = 8192, 512 from 2048, else 256):
 //   for each 128-column inner block c:
 //     1. potrf_diag_kernel: ONE workgroup factorises the 128x128 diagonal block
 //        entirely in LDS (16-wide micro-panels: shuffle-based 16x16 Cholesky on
@@ -14,7 +14,7 @@
 //        doubling with MFMA) and writes inv(L_cc) to the `dinv` workspace.
 //     2. panel TRSM as an MFMA GEMM:  A[c+128:, c:c+128] <- A[...] * inv(L_cc)^T
 //     3. strip update (rank 128) of the remaining columns of the outer block.
-//   4. trailing SYRK update (rank nbo, lower tiles only, XCD-aware tile order):
+//   4. trailing SYRK update (rank nbo, lower tiles only):
 //        A[k1:, k1:] -= A[k1:, k0:k1] A[k1:, k0:k1]^T        <- the MFMA-bound part
 //
 // inv(L_cc) blocks are kept: gpk_solve.hip turns every triangular solve of the
