@@ -87,7 +87,7 @@ def gp_logpdf(kernel, x, noise_vec, r):
 
 
 # ---------------------------------------------------------------------------------------------
-# Pseudo-point ELBO (VFE / DTC), stheno/model/observations.py:279-336, differentiable w.r.t. the
+# Pseudo-point ELBO (VFE / FITC / DTC), stheno/model/observations.py:279-336, differentiable w.r.t. the
 # kernel variances / length scales, the (diagonal) observation noise, the inducing inputs z and
 # the residual r = y - m(x).
 #
@@ -100,6 +100,8 @@ def gp_logpdf(kernel, x, noise_vec, r):
 # The M x N cotangent costs ONE extra MFMA GEMM (2 M^2 N flops) on the stored, whitened and scaled
 # V; gpk_kmat_vjp_dense then reads it once and returns the per-term sums, the column sums that
 # give (V^T A^{-1} V)_jj without another TRSM, and d/dz.  Everything else is M x M.
+# FITC = the DTC bound at the noise d + (k_jj - q_jj); its dependence on V through q_jj adds one M x N GEMM,
+# one weighted M x M SYRK and a second pass of gpk_kmat_vjp_dense.
 # ---------------------------------------------------------------------------------------------
 class _SparseELBO(torch.autograd.Function):
     @staticmethod
@@ -117,6 +119,9 @@ class _SparseELBO(torch.autograd.Function):
         v = chol_z.solve_(v)                                                   # V
         _, q = be.colreduce(v, want_ss=True)
         corr = be.kdiag(terms, x) - q
+        fitc = tau < 0
+        if fitc:                     # FITC: the DTC bound with the noise d + (k_jj - q_jj)   (observations.py:312)
+            d, tau = d + corr, 0.0
         s = torch.rsqrt(d)
         be.scale_cols_(v, s)                                                   # V D^{-1/2}
         a = torch.zeros((m, m), dtype=x.dtype, device=x.device)
@@ -132,7 +137,7 @@ class _SparseELBO(torch.autograd.Function):
         elbo = -0.5 * (torch.log(2 * math.pi * d).sum() + chol_a.logdet() + (r[:, 0] ** 2 / d).sum() - uu[0]
                        + tau * (corr / d).sum())
         ctx.saved = dict(x=x, z=z, r=r, d=d, s=s, v=v, q=q, corr=corr, a=a, u=u, chol_z=chol_z, chol_a=chol_a,
-                         terms=terms, tau=tau, nt=nt)
+                         terms=terms, tau=tau, nt=nt, fitc=fitc)
         ctx.param_meta = [(p_.device, p_.dtype) for p_ in params]
         ctx.values = ([float(v_) for v_ in variances], [float(s_) for s_ in scales])
         ctx.kinds = kinds
@@ -157,25 +162,37 @@ class _SparseELBO(torch.autograd.Function):
         w = be.colreduce(w_z, c, want_dot=True, want_ss=False)[0]              # L^{-T} c
         g_k = be.gemm(h, v, a_kmajor=True, b_kmajor=False)                     # M x N, the one big GEMM
         need_z = ctx.needs_input_grad[1]
+        fitc = sv["fitc"]
         s_k, colsum, gz_k = be.kmat_vjp_dense(terms, z, x, g_k, colscale=s, w=w, b=b, want_colsum=True,
-                                              want_gradx=need_z)
-        del g_k
+                                              want_gradx=need_z and not fitc)
         vav = tau * q - d * colsum + vtc * beta                                # (V^T A^{-1} V)_jj
         g_d = -0.5 * (1.0 / d - (vav + beta * beta + tau * corr) / (d * d))
         a_full = be.symmetrize_(be.copy(sv["a"]))
         mid = tau * a_full - (tau + 1.0) * eye + a_inv + c[:, None] * c[None, :]
+        if fitc:
+            # the effective noise depends on V through q_jj = |V_j|^2:  dELBO/dV -= 2 V diag(g_d), i.e. the
+            # cotangent of K_zx gets  -2 (L^{-T} V) diag(g_d)  and the K_z part  -2 V diag(g_d) V^T
+            rr = be.gemm(w_z, v, a_kmajor=False, b_kmajor=False)               # L^{-T} V D^{-1/2}   (M x N)
+            g_k.addcmul_(rr, (-2.0 * g_d / (s * s))[None, :])
+            s_k, _, gz_k = be.kmat_vjp_dense(terms, z, x, g_k, colscale=s, w=w, b=b, want_gradx=need_z)
+            rr.copy_(v)
+            be.scale_cols_(rr, g_d * d)
+            vgv = be.symmetrize_(be.gemm(rr, v, a_kmajor=True, b_kmajor=True, lower_only=True))
+            mid = mid - 2.0 * vgv
+            del rr
+        del g_k
         t1 = be.gemm(mid, w_z, a_kmajor=True, b_kmajor=False)
         g_kz = be.gemm(w_z, t1, a_kmajor=False, b_kmajor=False, alpha=-0.5)
         s_kz, _, gz_kz = be.kmat_vjp_dense(terms, z, z, g_kz, want_gradx=need_z)
         S = s_k + s_kz
-        # through k(x_j, x_j) (VFE only): stationary terms are constant on the diagonal
-        g_kd = -0.5 * tau / d
+        # through k(x_j, x_j) (VFE: trace term; FITC: the effective noise): stationary terms are constant there
+        g_kd = g_d if fitc else -0.5 * tau / d
         variances, scales = ctx.values
         go = grad_out.to(x.dtype)
         grads_v, grads_s = [], []
         for t in range(nt):
             gv, gs = S[t, 0], -2.0 * variances[t] / scales[t] * S[t, 1]
-            if tau:
+            if tau or fitc:
                 if ctx.kinds[t] == "linear":
                     xx = ((x * x).sum(-1) * g_kd).sum() / scales[t] ** 2
                     gv, gs = gv + xx, gs - 2.0 * variances[t] / scales[t] * xx
@@ -200,11 +217,11 @@ def elbo_needs_grad(tensor_terms, noise_vec, z, r):
 
 
 def sparse_elbo(kernel, x, z, noise_vec, r, method):
-    """Differentiable VFE / DTC bound for ``r = y - m(x)`` with inducing inputs ``z``."""
-    if method not in ("vfe", "dtc"):
-        raise NotImplementedError(f'gradients of the "{method}" bound are not implemented (use VFE or DTC)')
+    """Differentiable VFE / FITC / DTC bound for ``r = y - m(x)`` with inducing inputs ``z``."""
+    if method not in ("vfe", "fitc", "dtc"):
+        raise ValueError(f'Invalid approximation method "{method}".')
     tt = kernel.tensor_terms()
     kinds = tuple(k for k, _, _ in tt)
     as_t = lambda v: v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64)  # noqa: E731
     params = [as_t(v) for _, v, _ in tt] + [as_t(s) for _, _, s in tt]
-    return _SparseELBO.apply(x, z, r, noise_vec, 1.0 if method == "vfe" else 0.0, kinds, *params)
+    return _SparseELBO.apply(x, z, r, noise_vec, {"vfe": 1.0, "dtc": 0.0, "fitc": -1.0}[method], kinds, *params)
