@@ -77,6 +77,27 @@ def needs_grad(tensor_terms, noise_vec, r):
     return (noise_vec is not None and noise_vec.requires_grad) or r.requires_grad
 
 
+def kernel_requires_grad(kernel, _depth=0):
+    """Does any hyper-parameter reachable from ``kernel`` carry a gradient?  (Used to refuse -- loudly --
+    the cases the differentiable paths do not cover, instead of returning a value cut off from the graph.)"""
+    from . import kernels as _k
+
+    if _depth > 16:
+        return False
+    tt = kernel.tensor_terms() if isinstance(kernel, _k.Kernel) else None
+    if tt is not None:
+        return any((torch.is_tensor(v) and v.requires_grad) or (torch.is_tensor(s) and s.requires_grad) for _, v, s in tt)
+    if isinstance(kernel, _k.MultiOutputKernel):
+        ks = kernel.kernels
+        return any(kernel_requires_grad(ks[p], _depth + 1) for p in kernel.pids)
+    for val in vars(kernel).values():
+        if torch.is_tensor(val) and val.requires_grad:
+            return True
+        if isinstance(val, _k.Kernel) and kernel_requires_grad(val, _depth + 1):
+            return True
+    return False
+
+
 def gp_logpdf(kernel, x, noise_vec, r):
     """Differentiable log-density of ``r = y - m(x)`` under ``N(0, k(x) + diag(noise_vec) + eps I)``."""
     tt = kernel.tensor_terms()

@@ -231,6 +231,19 @@ class Normal(RandomVector):
             if noise_vec is not NotImplemented and tt is not None and _ag.needs_grad(tt, noise_vec, r):
                 lp = _ag.gp_logpdf(var.kernel, var.x, noise_vec, r)
                 return lp[0] if lp.shape[0] == 1 else lp
+        if torch.is_grad_enabled() and isinstance(var, KernelDense):
+            from . import autograd as _ag
+
+            nz = var.noise
+            noisy = (isinstance(nz, Diagonal) and nz.diag().requires_grad) or (isinstance(nz, Dense) and nz.mat is not None
+                                                                               and nz.mat.requires_grad)
+            if noisy or r.requires_grad or _ag.kernel_requires_grad(var.kernel):
+                raise NotImplementedError(
+                    "gradients of logpdf are implemented for one unbatched process whose kernel is a sum of "
+                    "primitives with scalar or per-point noise; this call (batched, multi-process, posterior or "
+                    "dense-noise) would return a value cut off from the autograd graph -- wrap it in torch.no_grad() "
+                    "if that is intended"
+                )
         if isinstance(var, Zero):
             raise torch.linalg.LinAlgError("the variance is identically zero")
         logdet = var.logdet()

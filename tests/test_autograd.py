@@ -239,6 +239,14 @@ def test_elbo_gradients_unsupported_cases_are_loud(oracle_backend):
     y = torch.randn(30, 1, dtype=torch.float64)
     v = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
     f = st.GP(v * st.EQ())
+    # logpdf cases outside the differentiable path refuse instead of returning a detached value
+    with pytest.raises(NotImplementedError):        # batched
+        f(torch.randn(3, 20, 2, dtype=torch.float64), 0.1).logpdf(torch.randn(3, 20, 1, dtype=torch.float64))
+    g = st.GP(st.Matern32(), measure=f.measure)
+    with pytest.raises(NotImplementedError):        # several processes observed jointly
+        f.measure.logpdf((f(x[:7], 0.1), y[:7]), (g(x[7:12], 0.1), y[7:12]))
+    with torch.no_grad():                           # ... unless gradients are off
+        assert torch.isfinite(f.measure.logpdf((f(x[:7], 0.1), y[:7]), (g(x[7:12], 0.1), y[7:12])))
     with pytest.raises(NotImplementedError):        # noisy inducing points
         st.PseudoObs(f(x[:5], 0.01), f(x, 0.1), y).elbo(f.measure)
 
