@@ -136,14 +136,25 @@ template <typename T>
 __device__ __forceinline__ void micro_trsm(T* S, const T* rdiag, int c0, int tid) {
     const int row = c0 + 16 + tid;
     if (row < GPK_DB) {
-        T x[16];
+        // All 120 multipliers of the 16x16 factor, its 16 reciprocal pivots and this thread's row are
+        // fetched from LDS up front (the workgroup owns the CU: 512 VGPRs per lane are there to be used).
+        // Left to itself the compiler interleaves one ds_read with one or two FMAs and pays an LDS latency
+        // ~60 times per micro-step (measured 4k cycles per step, a quarter of the kernel).
+        T l[16][16], rd[16], x[16];
+#pragma unroll
+        for (int c = 1; c < 16; ++c)
+#pragma unroll
+            for (int j = 0; j < c; ++j) l[c][j] = S[(c0 + c) * LDP + c0 + j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rd[j] = rdiag[c0 + j];
 #pragma unroll
         for (int c = 0; c < 16; ++c) x[c] = S[row * LDP + c0 + c];
+        __builtin_amdgcn_sched_barrier(0);     // keep the loads above, the dependent chain below
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            x[j] *= rdiag[c0 + j];
+            x[j] *= rd[j];
 #pragma unroll
-            for (int c = j + 1; c < 16; ++c) x[c] -= x[j] * S[(c0 + c) * LDP + c0 + j];
+            for (int c = j + 1; c < 16; ++c) x[c] -= x[j] * l[c][j];
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) S[row * LDP + c0 + c] = x[c];
@@ -389,13 +400,20 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
     //    micro-block 4*wave + g; lane lr solves for column lr of the inverse.
     if (wave < 2) {
         const int c0 = 16 * (4 * wave + kq);
-        T x[16];
+        T x[16], l[16][16], rd[16];
+#pragma unroll
+        for (int i = 1; i < 16; ++i)
+#pragma unroll
+            for (int k = 0; k < i; ++k) l[i][k] = S[(c0 + i) * LDP + c0 + k];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rd[i] = rdiag[c0 + i];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             T v = (i == lr) ? T(1) : T(0);
 #pragma unroll
-            for (int k = 0; k < i; ++k) v -= S[(c0 + i) * LDP + c0 + k] * x[k];
-            x[i] = v * rdiag[c0 + i];
+            for (int k = 0; k < i; ++k) v -= l[i][k] * x[k];
+            x[i] = v * rd[i];
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) S[(c0 + i) * LDP + c0 + lr] = x[i];   // zeros above the diagonal
