@@ -107,17 +107,19 @@ __device__ __forceinline__ void micro_chol(T* S, T* rdiag, int c0, int lane, int
     T a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = S[(c0 + lr) * LDP + c0 + c];
+    // The 16 columns are one dependent chain: nothing but the chain goes inside the loop.  The
+    // non-positive-pivot report and the reciprocal pivots are collected in registers and leave once,
+    // after the loop (16 exec-masked atomics / LDS stores inside it cost ~10 % of the micro-step).
+    int bad = 0;
+    T myr = T(0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const T d = lane_bcast(a[j], j);
-        if (!(d > T(0)) && lane == 0) atomicCAS(info, 0, off + c0 + j + 1);
+        bad = (!(d > T(0)) && bad == 0) ? j + 1 : bad;
         T ljj, rinv;
         sqrt_rsqrt(d, ljj, rinv);
-        if (lr == j)
-            a[j] = ljj;
-        else
-            a[j] *= rinv;
-        if (lane == j) rdiag[c0 + j] = rinv;
+        a[j] = (lr == j) ? ljj : a[j] * rinv;
+        myr = (lr == j) ? rinv : myr;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
             const T lcj = lane_bcast(a[j], c);
@@ -125,9 +127,11 @@ __device__ __forceinline__ void micro_chol(T* S, T* rdiag, int c0, int lane, int
         }
     }
     if (lane < 16) {
+        rdiag[c0 + lr] = myr;
 #pragma unroll
         for (int c = 0; c < 16; ++c) S[(c0 + lr) * LDP + c0 + c] = a[c];
     }
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, off + c0 + bad);
 }
 
 // micro-panel TRSM: one thread per row below the micro-block at (c0, c0); right-looking, so
