@@ -98,14 +98,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs<T> p) {
         }
         __syncthreads();
 
-        // prefix copy (rows of x written back to ycopy; x must fit one chunk)
-        if (p.ycopy != nullptr && kc == 0) {
+        // prefix copy (the rows of x in this chunk written back to ycopy)
+        if (p.ycopy != nullptr && kc < p.ncopy) {
             T* __restrict__ yc = p.ycopy + b * p.sy;
-            for (int64_t idx = (int64_t)blockIdx.x * 256 + tid; idx < p.ncopy * p.nrhs;
+            const int64_t nc = (p.ncopy - kc < kb) ? p.ncopy - kc : kb;
+            for (int64_t idx = (int64_t)blockIdx.x * 256 + tid; idx < nc * p.nrhs;
                  idx += (int64_t)gridDim.x * 256) {
                 const int64_t i = idx / p.nrhs;
                 const int c = (int)(idx % p.nrhs);
-                yc[i * p.ldy + c] = xs[i * NR + c];
+                yc[(kc + i) * p.ldy + c] = xs[i * NR + c];
             }
         }
 
@@ -174,7 +175,6 @@ int gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda
                 const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy, T* ycopy,
                 int64_t ncopy, int64_t batch, hipStream_t stream) {
     if (nrhs > 8 || nrhs < 1) return GPK_ERR_ARG(3);
-    if (ycopy != nullptr && K > GEMV_MAXK) return GPK_ERR_ARG(2);
     if (M <= 0 && ncopy <= 0) return GPK_OK;
     if (batch > 65535) return GPK_ERR_ARG(17);
     constexpr int VEC = Traits<T>::VEC;

@@ -39,13 +39,12 @@ def _solve_block(n, nrhs, fp64=True):
     right-hand sides than unknowns (pseudo-point path: M x N with N >> M; accuracy measured insensitive
     to the block size there) the whole factor is inverted once (M^3/3 flops) and the solve is ONE
     triangular GEMM."""
-    if nrhs > 8:
-        if nrhs >= 4 * n and n >= 1024:
-            return min(4096, 1 << (n - 1).bit_length())
-        if fp64 and n >= 32768:
-            return 2048
-        if fp64 and n >= 8192:
-            return 1024
+    if nrhs > 8 and nrhs >= 4 * n and n >= 1024:
+        return min(4096, 1 << (n - 1).bit_length())
+    if fp64 and n >= 32768:          # the GEMV sweep takes the same blocks: one merge serves logpdf and posterior
+        return 2048
+    if fp64 and n >= 8192:
+        return 1024
     if n >= 2048:
         return 512
     if n >= 512:
