@@ -177,7 +177,7 @@ class Kernel:
         if isinstance(other, Kernel):
             raise NotImplementedError("products of kernels are outside the accelerated path")
         v = _as_param(other)
-        if not torch.is_tensor(v) and v == 0:
+        if isinstance(self, ZeroKernel) or (not torch.is_tensor(v) and v == 0):
             return ZeroKernel()
         return Scaled(self, v)
 
@@ -187,7 +187,8 @@ class Kernel:
         return Stretched(self, _as_param(scale))
 
     def __reversed__(self):
-        return Reversed(self)
+        # sums of (stretched / scaled) primitives are symmetric, the zero kernel included
+        return self if self.terms() is not None else Reversed(self)
 
     def __eq__(self, other):
         if isinstance(self, ZeroKernel) and isinstance(other, ZeroKernel):
@@ -362,6 +363,7 @@ class Reversed(Kernel):
 
     def __init__(self, k):
         self.k = k
+        self.stationary = k.stationary
 
     def terms(self):
         return self.k.terms()   # sums of primitives are symmetric
@@ -536,6 +538,9 @@ class FunctionMean(Mean):
     def __call__(self, x, cache=None):
         return uprank(self.f(uprank(x)))
 
+    def __repr__(self):
+        return getattr(self.f, "__name__", "f")
+
 
 class ScaledMean(Mean):
     def __init__(self, m, v):
@@ -544,6 +549,9 @@ class ScaledMean(Mean):
     def __call__(self, x, cache=None):
         return self.v * self.m(x, cache)
 
+    def __repr__(self):
+        return f"{self.v} * {self.m!r}"
+
 
 class SumMean(Mean):
     def __init__(self, a, b):
@@ -551,6 +559,9 @@ class SumMean(Mean):
 
     def __call__(self, x, cache=None):
         return self.a(x, cache) + self.b(x, cache)
+
+    def __repr__(self):
+        return f"{self.a!r} + {self.b!r}"
 
 
 def _wrap_mean(m):

@@ -384,3 +384,59 @@ def test_big_buffers_are_released_without_the_cyclic_gc():
     approx(p_sum(t([0.0, 1.0])).var, 3 * O.kernel_matrix([("eq", 1, 1)], np.array([0.0, 1.0])))
     q = (m | (p_sum(x, 0.1), y))(p_sum)                                   # prior handle dropped, posterior used
     assert torch.isfinite(q(xs).mean).all()
+
+
+# ---------------------------------------------------------------- GP bookkeeping (tests/model/test_gp.py)
+def test_gp_construction_and_resolution():    # test_gp.py:55-92
+    from stheno_amd import kernels as K
+
+    x = t(np.random.default_rng(0).standard_normal((10, 1)))
+    k = st.EQ()
+    m = lambda u: u ** 2
+    assert isinstance(st.GP(k).mean, K.ZeroMean)
+    assert isinstance(st.GP(5, k).mean, K.ScaledMean)
+    assert isinstance(st.GP(0, k).mean, K.ZeroMean)
+    assert isinstance(st.GP(m, k).mean, K.FunctionMean)
+    assert isinstance(st.GP(k).kernel, st.EQ)
+    assert isinstance(st.GP(5).kernel, K.Scaled)
+    assert isinstance(st.GP(0).kernel, st.ZeroKernel)
+    p = st.GP(m, k)
+    approx(p.kernel(x, x), O.kernel_matrix([("eq", 1.0, 1.0)], B.to_numpy(x)))
+    approx(p.kernel.elwise(x), np.ones((10, 1)))
+    d = p(x)                                   # without noise
+    approx(B.dense(d.var), O.kernel_matrix([("eq", 1.0, 1.0)], B.to_numpy(x)))
+    approx(d.mean, B.to_numpy(x) ** 2)
+    d = p(x, 1)                                # with noise
+    approx(B.dense(d.var), O.kernel_matrix([("eq", 1.0, 1.0)], B.to_numpy(x)) + np.eye(10))
+    approx(d.mean, B.to_numpy(x) ** 2)
+
+
+def test_gp_sum_and_mul_with_other_things():  # test_gp.py:95-152
+    x = t(np.random.default_rng(1).standard_normal((5, 1)))
+    p = st.GP(lambda u: u ** 2, st.EQ())
+    five = lambda u: 5 * torch.ones(u.shape[0], 1, dtype=u.dtype)
+    kx = B.to_numpy(B.dense(p.kernel(x)))
+    for p_sum in (p + 5.0, 5.0 + p, p + five, five + p):
+        approx(p_sum.mean(x), B.to_numpy(p.mean(x)) + 5.0)
+        approx(B.dense(p_sum.kernel(x)), kx)
+    for p_mul in (p * 5.0, 5.0 * p):
+        approx(p_mul.mean(x), 5.0 * B.to_numpy(p.mean(x)))
+        approx(B.dense(p_mul.kernel(x)), 25.0 * kx)
+    with pytest.raises(NotImplementedError):   # products with functions / processes: outside the path
+        p * five
+    with pytest.raises(NotImplementedError):
+        p * p
+    with pytest.raises(AssertionError):        # different measures (test_gp.py:24-33)
+        p + st.GP(st.EQ())
+    with pytest.raises(RuntimeError):          # test_gp.py:41-43
+        st.GP().measure
+
+
+def test_gp_stationarity_and_display():       # test_gp.py:46-50,155-172
+    m = st.Measure()
+    p1, p2 = st.GP(st.EQ(), measure=m), st.GP(st.EQ().stretch(2), measure=m)
+    p = p1 + 2 * p2
+    assert p.stationary
+    assert not (p + st.GP(st.Linear(), measure=m)).stationary
+    assert str(st.GP()) == "GP()"
+    assert str(st.GP(st.EQ())) == "GP(0, EQ())"
