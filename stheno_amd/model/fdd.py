@@ -25,6 +25,19 @@ def _noise_as_matrix(noise, x, n):
     return Dense(noise)
 
 
+def _multi_parts(p, x):
+    """Flatten a (nested) tuple of FDDs and plain inputs into ``(process, input)`` parts; a plain input
+    stands for every component process of the product process ``p`` at that input
+    (``stheno/mo/kernel.py:58-76``; ``tests/model/test_fdd.py:85-95`` builds such specifications)."""
+    if isinstance(x, FDD):
+        xr = _k.uprank(x.x)
+        return list(xr.parts) if isinstance(xr, _k.MultiInput) else [(x.p, x.x)]
+    if isinstance(x, (tuple, list)):
+        return [part for e in x for part in _multi_parts(p, e)]
+    comps = p._parents if isinstance(p.kernel, _k.MultiOutputKernel) and p._parents else (p,)
+    return [(q, x) for q in comps]
+
+
 class FDD(Normal):
     """Finite-dimensional distribution of process ``p`` at inputs ``x`` with additive
     ``noise``.  Nothing is computed at construction (``fdd.py:59-83``)."""
@@ -35,8 +48,8 @@ class FDD(Normal):
             self.x = x
             self.noise = None
             return
-        if isinstance(x, (tuple, list)) and len(x) and all(isinstance(e, FDD) for e in x):
-            x = _k.MultiInput([(e.p, e.x) for e in x])     # inputs of a product process
+        if isinstance(x, (tuple, list)):
+            x = _k.MultiInput(_multi_parts(p, x))          # inputs of a product process
         xr = _k.uprank(x)
         self.x = x
         self._xr = xr

@@ -292,6 +292,43 @@ def test_reference_logpdf_gpu(hip_backend, cls):
     _reference_logpdf(cls, 1e-7)
 
 
+def _reference_fdd_take():
+    """tests/model/test_fdd.py:85-108 (test_fdd_take): a nested input specification, a coin flip per element."""
+    from stheno_amd.model.fdd import take
+
+    with st.Measure():
+        f1 = st.GP(1, st.EQ())
+        f2 = st.GP(2, st.Exp())
+        f = st.cross(f1, f2)
+    x = t(np.linspace(0, 3, 5))
+    fdd = f((x, (f2(x), x), f1(x), (f2(x), (f1(x), x))))
+    nel = st.kernels.num_elements(fdd.x)
+    assert nel == 5 * (2 + 1 + 2 + 1 + 1 + 1 + 2)
+    rng = np.random.default_rng(4)
+    noise = st.Diagonal(t(rng.random(nel)))
+    fdd = f(fdd.x, noise)
+    mask = torch.as_tensor(rng.standard_normal(nel) > 0, device=_dev())
+    taken = take(fdd, mask)
+    m = n(mask)
+    np.testing.assert_allclose(n(taken.mean), n(fdd.mean)[m], atol=1e-12)
+    np.testing.assert_allclose(n(B.dense(taken.var)), n(B.dense(fdd.var))[m][:, m], atol=1e-10)
+    np.testing.assert_allclose(n(taken.noise.diag()), n(noise.diag())[m])
+    assert isinstance(taken.noise, st.Diagonal)
+    with pytest.raises(AssertionError):
+        take(fdd, torch.tensor([1, 2]))
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_reference_fdd_take_cpu():
+    _reference_fdd_take()
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_reference_fdd_take_gpu():
+    _reference_fdd_take()
+
+
 @pytest.mark.usefixtures("oracle_backend")
 def test_reference_multi_process_cases_cpu():
     _reference_mirrors(1e-9)
