@@ -43,7 +43,8 @@ class MultiInput:
 
     dtype = property(lambda self: self.parts[0][1].dtype)
     device = property(lambda self: self.parts[0][1].device)
-    sizes = property(lambda self: [x.shape[0] for _, x in self.parts])
+    # rows each part contributes: a plain input under a product process stands for ALL its components
+    sizes = property(lambda self: [p.kernel.num_outputs(x) for p, x in self.parts])
     shape = property(lambda self: (sum(self.sizes), 1))
 
     def dim(self):
@@ -424,21 +425,26 @@ class MultiOutputKernel(Kernel):
         return [(pid, x) for pid in self.pids]
 
     def num_outputs(self, x):
-        return sum(xi.shape[0] for _, xi in self._split(x))
+        kernels = self.kernels
+        return sum(kernels[pi].num_outputs(xi) for pi, xi in self._split(x))
 
     def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None, out=None):
         kernels = self.kernels
         sym = y is None
         X = self._split(x)
         Y = X if sym else self._split(y)
-        nx, ny = sum(xi.shape[0] for _, xi in X), sum(yj.shape[0] for _, yj in Y)
+        # a part's process may itself be a product process (then its plain input expands): sizes come
+        # from the processes' own kernels (the reference marks such kernels "ADK": stheno/mo/adk.py)
+        sx = [kernels[pi].num_outputs(xi) for pi, xi in X]
+        sy = sx if sym else [kernels[pj].num_outputs(yj) for pj, yj in Y]
+        nx, ny = sum(sx), sum(sy)
         if out is None:
             out = ops._alloc((), nx, ny, X[0][1].dtype, X[0][1].device)
         r0 = 0
         for i, (pi, xi) in enumerate(X):
-            r1, c0 = r0 + xi.shape[0], 0
+            r1, c0 = r0 + sx[i], 0
             for j, (pj, yj) in enumerate(Y):
-                c1 = c0 + yj.shape[0]
+                c1 = c0 + sy[j]
                 if not (sym and lower and j > i) and r1 > r0 and c1 > c0:
                     if sym and i == j:
                         _eval_into(kernels[pi], xi, None, out[r0:r1, c0:c1], lower=lower)
@@ -471,11 +477,12 @@ class _CrossKernel(Kernel):
         kernels = self.mok.kernels
         X = self.mok._split(x)
         y = uprank(y)
-        nx, ny = sum(xi.shape[0] for _, xi in X), y.shape[-2]
+        sx = [kernels[pi].num_outputs(xi) for pi, xi in X]
+        nx, ny = sum(sx), kernels[self.j].num_outputs(y)
         out = ops._alloc((), nx, ny, X[0][1].dtype, X[0][1].device)
         r0 = 0
-        for pi, xi in X:
-            r1 = r0 + xi.shape[0]
+        for (pi, xi), n_i in zip(X, sx):
+            r1 = r0 + n_i
             if r1 > r0 and ny > 0:
                 _eval_into(kernels[pi, self.j], xi, y, out[r0:r1])
             r0 = r1

@@ -318,6 +318,95 @@ def _reference_fdd_take():
         take(fdd, torch.tensor([1, 2]))
 
 
+def _noise_forms():
+    rng = np.random.default_rng(8)
+    return {
+        "none": lambda x: (),
+        "scalar": lambda x: (float(rng.random()) + 0.05,),
+        "vector": lambda x: (t(rng.random(len(x)) + 0.05),),
+        "matrix": lambda x: (t(np.diag(rng.random(len(x)) + 0.05)),),
+        "Diagonal": lambda x: (st.Diagonal(t(rng.random(len(x)) + 0.05)),),
+    }
+
+
+def _assert_equal_measures(fdds, *posts, tol):
+    ref = posts[0]
+    for post in posts[1:]:
+        for fdd in fdds:
+            a, b = ref(fdd), post(fdd)
+            np.testing.assert_allclose(n(b.mean), n(a.mean), atol=tol, rtol=tol)
+            np.testing.assert_allclose(n(B.dense(b.var)), n(B.dense(a.var)), atol=tol, rtol=tol)
+
+
+def _reference_conditioning(form, tol):
+    """tests/model/test_model.py:123-195 (test_conditioning): every spelling, every noise form, one and two data sets."""
+    gen = _noise_forms()[form]
+    m = st.Measure()
+    p1 = st.GP(1, st.EQ(), measure=m)
+    p2 = st.GP(2, st.Exp(), measure=m)
+    p_sum = p1 + p2
+    g = torch.Generator(device=_dev()).manual_seed(1)
+    x1 = t(np.linspace(0, 2, 3)); n1 = gen(x1)
+    y1 = p1(x1, *n1).sample(generator=g); tup1 = (p1(x1, *n1), y1)
+    x_sum = t(np.linspace(3, 5, 3)); n_sum = gen(x_sum)
+    y_sum = p_sum(x_sum, *n_sum).sample(generator=g); tup_sum = (p_sum(x_sum, *n_sum), y_sum)
+    x_check = t(np.linspace(0, 5, 5))
+    fdds = [st.cross(p1, p2, p_sum)(x_check), p1(x_check), p2(x_check), p_sum(x_check)]
+    _assert_equal_measures(fdds, m.condition(*tup_sum), m.condition(tup_sum), m | tup_sum, m | (tup_sum,),
+                           m | st.Obs(*tup_sum), m | st.Obs(tup_sum), tol=tol)
+    _assert_equal_measures(fdds, m.condition(tup_sum, tup1), m | (tup_sum, tup1), m | st.Obs(tup_sum, tup1),
+                           (m | tup_sum) | tup1, (m | tup1) | tup_sum, tol=max(tol, 2e-6))
+
+
+def _reference_pseudoobs(cls, form, tol):
+    """tests/model/test_model.py:249-330 (test_pseudoobs_and_elbo): inducing points at the observations
+    (also of several processes at once) reproduce exact conditioning and the exact log-density."""
+    gen = _noise_forms()[form]
+    m = st.Measure()
+    p1 = st.GP(1, st.EQ(), measure=m)
+    p2 = st.GP(2, st.Exp(), measure=m)
+    p_sum = p1 + p2
+    g = torch.Generator(device=_dev()).manual_seed(2)
+    x1 = t(np.linspace(0, 2, 3)); n1 = gen(x1)
+    y1 = p1(x1, *n1).sample(generator=g); tup1 = (p1(x1, *n1), y1)
+    x_sum = t(np.linspace(3, 5, 3)); n_sum = gen(x_sum)
+    y_sum = p_sum(x_sum, *n_sum).sample(generator=g); tup_sum = (p_sum(x_sum, *n_sum), y_sum)
+    x_check = t(np.linspace(0, 5, 5))
+    fdds = [st.cross(p1, p2, p_sum)(x_check), p1(x_check), p2(x_check), p_sum(x_check)]
+    _assert_equal_measures(
+        fdds, m | tup_sum, m | cls(p_sum(x_sum), *tup_sum), m | cls((p_sum(x_sum),), *tup_sum),
+        m | cls((p_sum(x_sum), p1(x1)), *tup_sum), m | cls(p_sum(x_sum), tup_sum),
+        m.condition(cls((p_sum(x_sum), p1(x1)), tup_sum)), tol=tol)
+    np.testing.assert_allclose(float(m.logpdf(st.Obs(*tup_sum))), float(cls(p_sum(x_sum), tup_sum).elbo(m)), rtol=tol)
+    _assert_equal_measures(fdds, m | (tup_sum, tup1), m.condition(cls((p_sum(x_sum), p1(x1)), tup_sum, tup1)), tol=tol)
+    np.testing.assert_allclose(float(m.logpdf(st.Obs(tup_sum, tup1))),
+                               float(cls((p_sum(x_sum), p1(x1)), tup_sum, tup1).elbo(m)), rtol=tol)
+
+
+@pytest.mark.parametrize("form", ["none", "scalar", "vector", "matrix", "Diagonal"])
+def test_reference_conditioning_cpu(oracle_backend, form):
+    _reference_conditioning(form, 1e-6)
+
+
+@pytest.mark.parametrize("form", ["scalar", "vector", "Diagonal"])
+@pytest.mark.parametrize("cls", [st.PseudoObs, st.PseudoObsFITC, st.PseudoObsDTC])
+def test_reference_pseudoobs_cpu(oracle_backend, cls, form):
+    _reference_pseudoobs(cls, form, 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["none", "scalar", "vector", "matrix", "Diagonal"])
+def test_reference_conditioning_gpu(hip_backend, form):
+    _reference_conditioning(form, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["scalar", "vector", "Diagonal"])
+@pytest.mark.parametrize("cls", [st.PseudoObs, st.PseudoObsFITC, st.PseudoObsDTC])
+def test_reference_pseudoobs_gpu(hip_backend, cls, form):
+    _reference_pseudoobs(cls, form, 2e-6)
+
+
 @pytest.mark.usefixtures("oracle_backend")
 def test_reference_fdd_take_cpu():
     _reference_fdd_take()
