@@ -16,9 +16,15 @@ class _LazyStore:
         self._store = {}
 
     def purge(self, index):
-        """Drop every cached entry that involves ``index`` (the id of a process that died)."""
+        """Forget ``index`` (the id of a process that died) entirely: cached entries, the rules it owns and
+        its membership in other rules' index sets.  CPython recycles ids, so a later process may get the
+        same one -- it must not inherit the dead process's rules, nor be taken for "known" by older rules."""
         for k in [k for k in self._store if index in k]:
             del self._store[k]
+        self._purge_rules(index)
+
+    def _purge_rules(self, index):  # pragma: no cover
+        pass
 
     def _key(self, key):
         if isinstance(key, tuple):
@@ -51,7 +57,11 @@ class LazyVector(_LazyStore):
         self._rules = []
 
     def add_rule(self, indices, builder):
-        self._rules.append((frozenset(indices), builder))
+        self._rules.append((set(indices), builder))
+
+    def _purge_rules(self, index):
+        for indices, _ in self._rules:
+            indices.discard(index)
 
     def _build(self, k):
         (i,) = k
@@ -72,13 +82,21 @@ class LazyMatrix(_LazyStore):
         self._rules, self._left, self._right = [], [], []
 
     def add_rule(self, indices, builder):
-        self._rules.append((frozenset(indices), builder))
+        self._rules.append((set(indices), builder))
 
     def add_left_rule(self, i_left, indices, builder):
-        self._left.append((i_left, frozenset(indices), builder))
+        self._left.append((i_left, set(indices), builder))
 
     def add_right_rule(self, i_right, indices, builder):
-        self._right.append((i_right, frozenset(indices), builder))
+        self._right.append((i_right, set(indices), builder))
+
+    def _purge_rules(self, index):
+        self._left = [r for r in self._left if r[0] != index]
+        self._right = [r for r in self._right if r[0] != index]
+        for indices, _ in self._rules:
+            indices.discard(index)
+        for _, indices, _ in self._left + self._right:
+            indices.discard(index)
 
     def _build(self, k):
         i, j = k

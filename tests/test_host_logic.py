@@ -440,3 +440,44 @@ def test_gp_stationarity_and_display():       # test_gp.py:46-50,155-172
     assert not (p + st.GP(st.Linear(), measure=m)).stationary
     assert str(st.GP()) == "GP()"
     assert str(st.GP(st.EQ())) == "GP(0, EQ())"
+
+
+def test_recycled_process_ids_do_not_inherit_rules():
+    """CPython recycles object ids: a process handle created after another one died may get its id; it
+    must not pick up the dead handle's cross-kernel rules (found by the multi-process mirrors on the GPU box)."""
+    rng = np.random.default_rng(3)
+    x = t(rng.standard_normal((6, 1)))
+    y = t(rng.standard_normal((6, 1)))
+    m = st.Measure()
+    p1 = st.GP(st.EQ(), measure=m)
+    p2 = st.GP(st.Matern32(), measure=m)
+    q = p1 + p2
+    post = m | (q(x, 0.1), y)
+    want = B.to_numpy(post.kernels[p2, p1].pairwise(x, x))
+    for _ in range(50):
+        a = post(p1)
+        del a
+        b = post(p2)                     # frequently lands on the address `a` just vacated
+        approx(post.kernels[b, p1].pairwise(x, x), want, atol=1e-12)
+        approx(post.kernels[p1, b].pairwise(x, x), want.T, atol=1e-12)
+        del b
+
+    # the mechanism, deterministically: index 7 dies and is re-used by a process with other rules
+    from stheno_amd.lazy import LazyMatrix
+    lm = LazyMatrix()
+    lm[1] = "k11"
+    lm[7] = "old77"
+    lm.add_left_rule(7, {1}, lambda j: "old rule (7, %d)" % j)
+    lm.add_right_rule(7, {1}, lambda i: "old rule (%d, 7)" % i)
+    assert lm[7, 1] == "old rule (7, 1)" and lm[1, 7] == "old rule (1, 7)"
+    lm.purge(7)
+    lm[7] = "new77"
+    lm.add_left_rule(7, {1}, lambda j: "new rule (7, %d)" % j)
+    lm.add_right_rule(7, {1}, lambda i: "new rule (%d, 7)" % i)
+    assert lm[7, 1] == "new rule (7, 1)" and lm[1, 7] == "new rule (1, 7)" and lm[7] == "new77"
+    # ... and an older rule must not claim to know a newcomer that recycled a dead index
+    lm.add_left_rule(1, {7}, lambda j: "rule of 1 about the OLD 7")
+    lm.purge(7)
+    lm[7] = "newest"
+    lm.add_right_rule(7, {1}, lambda i: "newest rule (%d, 7)" % i)
+    assert lm[1, 7] == "newest rule (1, 7)"
