@@ -639,6 +639,8 @@ class PosteriorKernel(Kernel):
         vx = _whiten(cache, self.K_z, self.k_zi, self.z, x)
         vy = vx if (sym and self.k_zi is self.k_zj) else _whiten(cache, self.K_z, self.k_zj, self.z, y)
         # out -= vx^T vy   (operands stored (K, M) / (K, N): row index contiguous)
+        if out.stride(-1) != 1 and out.shape[-1] > 1:
+            out = out.contiguous()          # e.g. the transposed view a reversed cross-kernel hands back
         ops.get_backend().gemm(vx, vy, a_kmajor=False, b_kmajor=False, alpha=-1.0, beta=1.0, out=out)
         return _add_diag(out, diag_add, diag_vec) if sym else out
 

@@ -76,6 +76,15 @@ def _as3(t):
     return t, bshape
 
 
+def _as3_out(t):
+    """``_as3`` for an OUTPUT: a tensor that would have to be copied to get a unit inner stride cannot
+    receive results in place -- refuse it (a transposed view once swallowed a GEMM update silently)."""
+    t3, bshape = _as3(t)
+    if t3.data_ptr() != t.data_ptr() or (t.dim() >= 2 and t.shape[-1] > 1 and t.stride(-1) != 1):
+        raise ValueError("output tensors need a unit inner stride (and a regular batch stride); pass a contiguous buffer")
+    return t3, bshape
+
+
 def _alloc(bshape, rows, cols, dtype, device):
     """An uninitialised (..., rows, cols) matrix whose leading dimension is padded to a multiple
     of 16 elements when ``cols`` is not one: rows stay 16-byte aligned, so the kernels keep their
@@ -142,7 +151,7 @@ class HipBackend:
             raise ValueError("x and y must agree in batch size and input dimension")
         if out is None:
             out = _alloc(bshape, n, m, x.dtype, x.device)
-        o3, _ = _as3(out)
+        o3, _ = _as3_out(out)
         dv = None
         if diag_vec is not None:
             dv = diag_vec.reshape(B, n).contiguous()
@@ -248,7 +257,7 @@ class HipBackend:
             if beta != 0.0:
                 raise ValueError("beta != 0 requires `out`")
             out = _alloc(bshape if a3.shape[0] >= b3.shape[0] else tuple(b.shape[:-2]), M, N, a.dtype, a.device)
-        o3, _ = _as3(out)
+        o3, _ = _as3_out(out)
         code = self.lib.gpk_gemm(_dtype_id(a3), int(a_kmajor), int(b_kmajor), M, N, K, float(alpha), self._ptr(a3),
                                  _ld(a3), _bs(a3), self._ptr(b3), _ld(b3), _bs(b3), float(beta), self._ptr(o3),
                                  _ld(o3), _bs(o3), B, int(lower_only) | (2 if tri_k else 0) | (4 if tri_k_lower else 0),
@@ -265,7 +274,7 @@ class HipBackend:
         nrhs = x3.shape[2]
         if out is None:
             out = torch.empty(bshape + (M, nrhs), dtype=a.dtype, device=a.device)
-        o3, _ = _as3(out)
+        o3, _ = _as3_out(out)
         code = self.lib.gpk_gemv(_dtype_id(a3), 0, M, K, nrhs, float(alpha), self._ptr(a3), _ld(a3), _bs(a3),
                                  self._ptr(x3), _ld(x3), _bs(x3), float(beta), self._ptr(o3), _ld(o3), _bs(o3), B,
                                  self._stream())
@@ -363,14 +372,14 @@ class HipBackend:
 
     # -- in-place odds and ends ------------------------------------------------
     def tril_(self, a):
-        a3, _ = _as3(a)
+        a3, _ = _as3_out(a)
         self._check(a3)
         B, n, _ = a3.shape
         self._st(self.lib.gpk_tril(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._stream()), "gpk_tril")
         return a
 
     def symmetrize_(self, a):
-        a3, _ = _as3(a)
+        a3, _ = _as3_out(a)
         self._check(a3)
         B, n, _ = a3.shape
         self._st(self.lib.gpk_symmetrize(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._stream()),
@@ -378,7 +387,7 @@ class HipBackend:
         return a
 
     def add_diag_(self, a, s=0.0, v=None):
-        a3, _ = _as3(a)
+        a3, _ = _as3_out(a)
         self._check(a3, v)
         B, n, _ = a3.shape
         v2 = v.reshape(B, n).contiguous() if v is not None else None
@@ -387,7 +396,7 @@ class HipBackend:
         return a
 
     def scale_cols_(self, v, s):
-        v3, _ = _as3(v)
+        v3, _ = _as3_out(v)
         self._check(v3, s)
         B, R, C = v3.shape
         s2 = s.reshape(B, C).contiguous()
@@ -401,7 +410,7 @@ class HipBackend:
         self._check(s3)
         B, R, C = s3.shape
         out = _alloc(bshape, R, C, src.dtype, src.device)
-        o3, _ = _as3(out)
+        o3, _ = _as3_out(out)
         self._st(self.lib.gpk_copy2d(_dtype_id(s3), self._ptr(s3), _ld(s3), _bs(s3), self._ptr(o3), _ld(o3), _bs(o3),
                                      R, C, B, self._stream()), "gpk_copy2d")
         return out

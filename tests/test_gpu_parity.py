@@ -289,3 +289,16 @@ def test_triangular_inverse_and_k_inverse(n):
     kinv = be.gemm(W, W, a_kmajor=False, b_kmajor=False, lower_only=True, tri_k=True)
     ksym = torch.tril(kinv) + torch.tril(kinv, -1).T
     assert float((ksym @ k_full - eye).abs().max()) < 1e-8
+
+
+def test_outputs_must_not_need_a_copy():
+    """A transposed view as ``out=`` once made the GEMM write into a temporary copy and return the
+    un-updated tensor (posterior of a product process under chained conditioning): now refused."""
+    be = ops.get_backend()
+    a = dev(np.random.default_rng(0).standard_normal((8, 5)))
+    good = be.gemm(a, a, out=dev(np.zeros((8, 8))))
+    assert rel(good, (a @ a.T).cpu().numpy()) < 1e-12
+    with pytest.raises(ValueError):
+        be.gemm(a, a, out=dev(np.zeros((8, 8))).t())
+    with pytest.raises(ValueError):
+        be.add_diag_(dev(np.zeros((8, 8))).t(), 1.0)
