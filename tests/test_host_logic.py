@@ -481,3 +481,33 @@ def test_recycled_process_ids_do_not_inherit_rules():
     lm[7] = "newest"
     lm.add_right_rule(7, {1}, lambda i: "newest rule (%d, 7)" % i)
     assert lm[1, 7] == "newest rule (1, 7)"
+
+
+def test_measure_groups():                    # tests/model/test_model.py:23-59
+    prior = st.Measure()
+    f1 = st.GP(st.EQ(), measure=prior)
+    f2 = st.GP(st.EQ(), measure=prior)
+    assert f1._measures == f2._measures == [prior]
+    x = t(np.linspace(0, 5, 10))
+    y = f1(x).sample()
+    post = prior | (f1(x), y)
+    assert f1._measures == f2._measures == [prior, post]
+    f_sum = f1 + f2                            # known to both measures
+    assert f_sum._measures == [prior, post]
+    f3 = st.GP(st.EQ(), measure=prior)         # created after the conditioning: the posterior does not know it
+    f_sum = f1 + f3
+    assert f3._measures == f_sum._measures == [prior]
+    with pytest.raises(AssertionError):
+        post(f1) + f3
+    f_sum = post(f1) + post(f2)                # extend the posterior
+    assert f_sum._measures == [post]
+    f3 = st.GP(st.EQ(), measure=post)
+    f_sum = post(f1) + f3
+    assert f3._measures == f_sum._measures == [post]
+    with pytest.raises(AssertionError):
+        f1 + f3
+    del post                                   # (this package: a posterior dies with its last handle)
+    import gc
+    del f_sum, f3
+    gc.collect()
+    assert f1._measures == [prior]
