@@ -511,3 +511,24 @@ def test_measure_groups():                    # tests/model/test_model.py:23-59
     del f_sum, f3
     gc.collect()
     assert f1._measures == [prior]
+
+
+def test_normal_mean_is_zero_entropy_and_sampling(normal1):   # test_random.py:53-65,207-209,228-245
+    d = st.Normal(torch.eye(3, dtype=f64))
+    assert d.mean_is_zero
+    approx(d.mean, np.zeros((3, 1)))
+    assert st.Normal(Zero(f64, 3, 1), torch.eye(3, dtype=f64)).mean_is_zero
+    assert not st.Normal(torch.randn(3, 1, dtype=f64), torch.eye(3, dtype=f64)).mean_is_zero
+    sp = multivariate_normal(B.to_numpy(normal1.mean)[:, 0], B.to_numpy(B.dense(normal1.var)))
+    approx(normal1.entropy(), sp.entropy(), rtol=1e-10)
+    g = torch.Generator().manual_seed(0)
+    for mean in (0.0, 1.0):
+        dist = st.Normal(mean * torch.ones(200, 1, dtype=f64), 3 * torch.eye(200, dtype=f64))
+        s = dist.sample(2000, generator=g)
+        assert s.shape == (200, 2000)
+        assert abs(float(s.mean()) - mean) < 5e-2 and abs(float(s.std()) ** 2 - 3) < 5e-2
+        s = dist.sample(2000, noise=2, generator=g)
+        assert abs(float(s.mean()) - mean) < 5e-2 and abs(float(s.std()) ** 2 - 5) < 5e-2
+    a = dist.sample(generator=torch.Generator().manual_seed(7))
+    b = dist.sample(generator=torch.Generator().manual_seed(7))
+    approx(a, b)
