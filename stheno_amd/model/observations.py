@@ -138,7 +138,7 @@ class Observations(AbstractObservations):
                 # one kernel matrix and one Cholesky factor.
                 K_x = self.fdd.var
             else:
-                K_x = _kernel_matrix(measure.kernels[p], _k.uprank(self.fdd.x), self.fdd.noise)
+                K_x = _kernel_matrix(measure.kernels[p], self.fdd._xr, self.fdd.noise)
             self._K_x[id(measure)] = K_x
             return K_x
 
@@ -147,14 +147,14 @@ class Observations(AbstractObservations):
             return measure.kernels[p_i, p_j]
         return _k.PosteriorKernel(
             measure.kernels[p_i, p_j], measure.kernels[self.fdd.p, p_i], measure.kernels[self.fdd.p, p_j],
-            _k.uprank(self.fdd.x), self.K_x(measure),
+            self.fdd._xr, self.K_x(measure),
         )
 
     def posterior_mean(self, measure, p):
         if _k.num_elements(self.fdd.x) == 0:
             return measure.means[p]
         return _k.PosteriorMean(
-            measure.means[p], measure.means[self.fdd.p], measure.kernels[self.fdd.p, p], _k.uprank(self.fdd.x),
+            measure.means[p], measure.means[self.fdd.p], measure.kernels[self.fdd.p, p], self.fdd._xr,
             self.K_x(measure), self.y,
         )
 
@@ -192,8 +192,8 @@ class AbstractPseudoObservations(AbstractObservations):
 
         if not torch.is_grad_enabled():
             return None
-        p_x, x, noise_x = self.fdd.p, _k.uprank(self.fdd.x), self.fdd.noise
-        p_z, z, noise_z = self.u.p, _k.uprank(self.u.x), self.u.noise
+        p_x, x, noise_x = self.fdd.p, self.fdd._xr, self.fdd.noise
+        p_z, z, noise_z = self.u.p, self.u._xr, self.u.noise
         if isinstance(x, _k.MultiInput) or isinstance(z, _k.MultiInput) or not isinstance(noise_x, Diagonal):
             return None
         k = measure.kernels[p_z]
@@ -220,7 +220,7 @@ class AbstractPseudoObservations(AbstractObservations):
             l_z = p["K_z"].chol().lower()
             t = p["chol_A"].solve(l_z.transpose(-1, -2).contiguous())      # L_A^{-1} L_z^T
             dot, _ = be.colreduce(t, p["u"], want_dot=True, want_ss=False)  # (L_A^{-1} L_z^T)^T L_A^{-1} p
-            z = _k.uprank(self.u.x)
+            z = self.u._xr
             self._mu[id(measure)] = measure.means[self.u.p](z) + dot[..., None]
         return self._mu[id(measure)]
 
@@ -245,7 +245,7 @@ class AbstractPseudoObservations(AbstractObservations):
         return self._A[id(measure)]
 
     def posterior_kernel(self, measure, p_i, p_j):
-        z = _k.uprank(self.u.x)
+        z = self.u._xr
         return _k.PosteriorKernel(
             measure.kernels[p_i, p_j], measure.kernels[self.u.p, p_i], measure.kernels[self.u.p, p_j], z,
             self.K_z(measure),
@@ -253,7 +253,7 @@ class AbstractPseudoObservations(AbstractObservations):
 
     def posterior_mean(self, measure, p):
         return _k.PosteriorMean(
-            measure.means[p], measure.means[self.u.p], measure.kernels[self.u.p, p], _k.uprank(self.u.x),
+            measure.means[p], measure.means[self.u.p], measure.kernels[self.u.p, p], self.u._xr,
             self.K_z(measure), self.mu(measure),
         )
 
@@ -267,8 +267,8 @@ class AbstractPseudoObservations(AbstractObservations):
         given -- is called on the tensor holding those sums; ``stheno_amd.dist.sharded_elbo``
         passes an all-reduce there to shard the observations over ranks."""
         be = ops.get_backend()
-        p_x, x, noise_x = self.fdd.p, _k.uprank(self.fdd.x), self.fdd.noise
-        p_z, z, noise_z = self.u.p, _k.uprank(self.u.x), self.u.noise
+        p_x, x, noise_x = self.fdd.p, self.fdd._xr, self.fdd.noise
+        p_z, z, noise_z = self.u.p, self.u._xr, self.u.noise
 
         K_zx = measure.kernels[p_z, p_x].pairwise(z, x)                       # :285
         K_z = _kernel_matrix(measure.kernels[p_z], z, noise_z)                # :286

@@ -532,3 +532,35 @@ def test_normal_mean_is_zero_entropy_and_sampling(normal1):   # test_random.py:5
     a = dist.sample(generator=torch.Generator().manual_seed(7))
     b = dist.sample(generator=torch.Generator().manual_seed(7))
     approx(a, b)
+
+
+def test_pseudoobs_kernel_call_count():       # tests/model/test_model.py:335-365
+    """A pseudo-point posterior prediction evaluates the kernel exactly as often as the reference does:
+    pairwise (x_ind, x_obs), (x_ind, x_ind), (x_ind, x_new); elwise at x_obs and at x_new."""
+    from stheno_amd import ops
+
+    be = ops.get_backend()
+    calls = {"kmat": [], "kdiag": []}
+    kmat0, kdiag0 = be.kmat, be.kdiag
+
+    def kmat(terms, x, y=None, **kw):
+        calls["kmat"].append((x.shape[-2], None if y is None else y.shape[-2]))
+        return kmat0(terms, x, y, **kw)
+
+    def kdiag(terms, x):
+        calls["kdiag"].append(x.shape[-2])
+        return kdiag0(terms, x)
+
+    be.kmat, be.kdiag = kmat, kdiag
+    try:
+        rng = np.random.default_rng(0)
+        x_obs, y_obs = t(np.linspace(0, 5, 10)), t(rng.standard_normal(10))
+        x_ind, x_new = t(np.linspace(0, 5, 5)), t(rng.standard_normal(1))
+        p = st.GP(1, st.EQ())
+        p_post = p | st.PseudoObs(p(x_ind), (p(x_obs, 0.1), y_obs))
+        mean, var = p_post(x_new).marginals()
+        assert mean.shape == var.shape == (1,)
+    finally:
+        be.kmat, be.kdiag = kmat0, kdiag0
+    assert sorted(calls["kmat"], key=str) == sorted([(5, 10), (5, None), (5, 1)], key=str), calls
+    assert sorted(calls["kdiag"]) == [1, 10], calls
