@@ -602,24 +602,25 @@ class MultiOutputMean(Mean):
 def _cross(cache, k, z, x):
     """Memoised ``k(z, x)`` tensor within one ``mean_var(_diag)`` evaluation: the
     reference evaluates the data/inducing cross-kernel once per prediction
-    (pinned by ``tests/model/test_model.py:335-365``)."""
+    (pinned by ``tests/model/test_model.py:335-365``).  Entries are keyed by object identity and
+    keep their key objects alive, so an id cannot be recycled while the cache lives."""
     if cache is None:
         return k.pairwise(z, x)
     key = ("kzx", id(k), id(z), id(x))
     if key not in cache:
-        cache[key] = k.pairwise(z, x)
-    return cache[key]
+        cache[key] = (k.pairwise(z, x), k, z, x)
+    return cache[key][0]
 
 
 def _whiten(cache, K_z, k, z, x):
     """``L^{-1} k(z, x)`` (memoised), ``L = chol(K_z)``."""
     key = ("v", id(K_z), id(k), id(z), id(x))
     if cache is not None and key in cache:
-        return cache[key]
+        return cache[key][0]
     kzx = _cross(cache, k, z, x)
     v = K_z.chol().solve(kzx)
     if cache is not None:
-        cache[key] = v
+        cache[key] = (v, K_z, k, z, x)
     return v
 
 
