@@ -1,6 +1,7 @@
 """Observations: exact conditioning and the pseudo-point (VFE / FITC / DTC)
 approximations (``stheno/model/observations.py``)."""
 import math
+import weakref
 
 import torch
 
@@ -123,13 +124,15 @@ class Observations(AbstractObservations):
 
     def __init__(self, *args):
         AbstractObservations.__init__(self, *args)
-        self._K_x = {}
+        # per-measure caches hold their measures weakly: an entry dies with its measure, so a later
+        # measure that happens to get the same id() can never see it
+        self._K_x = weakref.WeakKeyDictionary()
 
     def K_x(self, measure):
         """``k(x) + noise`` of the data under ``measure``; built once per measure, its
         Cholesky factor is shared by every later prediction (``observations.py:127-141``)."""
         try:
-            return self._K_x[id(measure)]
+            return self._K_x[measure]
         except KeyError:
             p = self.fdd.p
             if p._measures and p._measures[0] is measure and self.fdd.noise is not None:
@@ -139,7 +142,7 @@ class Observations(AbstractObservations):
                 K_x = self.fdd.var
             else:
                 K_x = _kernel_matrix(measure.kernels[p], self.fdd._xr, self.fdd.noise)
-            self._K_x[id(measure)] = K_x
+            self._K_x[measure] = K_x
             return K_x
 
     def posterior_kernel(self, measure, p_i, p_j):
@@ -169,12 +172,12 @@ class AbstractPseudoObservations(AbstractObservations):
         if isinstance(u, tuple):
             u = combine(*u)
         self.u = u
-        self._K_z, self._elbo, self._mu, self._A, self._parts = {}, {}, {}, {}, {}
+        self._K_z, self._elbo, self._mu, self._A, self._parts = (weakref.WeakKeyDictionary() for _ in range(5))
 
     def K_z(self, measure):
-        if id(measure) not in self._K_z:
+        if measure not in self._K_z:
             self._compute(measure)
-        return self._K_z[id(measure)]
+        return self._K_z[measure]
 
     def elbo(self, measure):
         """The evidence lower bound (``observations.py:213-222``).  If a kernel hyper-parameter, the
@@ -183,9 +186,9 @@ class AbstractPseudoObservations(AbstractObservations):
         diff = self._differentiable(measure)
         if diff is not None:
             return diff
-        if id(measure) not in self._elbo:
+        if measure not in self._elbo:
             self._compute(measure)
-        return self._elbo[id(measure)]
+        return self._elbo[measure]
 
     def _differentiable(self, measure):
         from .. import autograd
@@ -213,25 +216,25 @@ class AbstractPseudoObservations(AbstractObservations):
 
     def mu(self, measure):
         """Mean of the optimal approximating distribution (``observations.py:224-237``)."""
-        if id(measure) not in self._mu:
+        if measure not in self._mu:
             self.elbo(measure)
             be = ops.get_backend()
-            p = self._parts[id(measure)]
+            p = self._parts[measure]
             l_z = p["K_z"].chol().lower()
             t = p["chol_A"].solve(l_z.transpose(-1, -2).contiguous())      # L_A^{-1} L_z^T
             dot, _ = be.colreduce(t, p["u"], want_dot=True, want_ss=False)  # (L_A^{-1} L_z^T)^T L_A^{-1} p
             z = self.u._xr
-            self._mu[id(measure)] = measure.means[self.u.p](z) + dot[..., None]
-        return self._mu[id(measure)]
+            self._mu[measure] = measure.means[self.u.p](z) + dot[..., None]
+        return self._mu[measure]
 
     def A(self, measure):
         """``L_z A L_z^T`` (``observations.py:239-253,323``).  Its Cholesky factor is
         ``L_z L_A`` -- already known -- so the returned ``Dense`` carries that factor in
         product form and only forms the M x M product if its entries are asked for."""
-        if id(measure) not in self._A:
+        if measure not in self._A:
             self.elbo(measure)
             be = ops.get_backend()
-            p = self._parts[id(measure)]
+            p = self._parts[measure]
             chol_z = p["K_z"].chol()
 
             def build():
@@ -241,8 +244,8 @@ class AbstractPseudoObservations(AbstractObservations):
                 return be.gemm(l_z, w, a_kmajor=True, b_kmajor=False)           # L_z (A L_z^T)
 
             a = p["A"]
-            self._A[id(measure)] = FactoredDense(build, ChainChol(chol_z, p["chol_A"]), a.shape, a.dtype, a.device)
-        return self._A[id(measure)]
+            self._A[measure] = FactoredDense(build, ChainChol(chol_z, p["chol_A"]), a.shape, a.dtype, a.device)
+        return self._A[measure]
 
     def posterior_kernel(self, measure, p_i, p_j):
         z = self.u._xr
@@ -272,7 +275,7 @@ class AbstractPseudoObservations(AbstractObservations):
 
         K_zx = measure.kernels[p_z, p_x].pairwise(z, x)                       # :285
         K_z = _kernel_matrix(measure.kernels[p_z], z, noise_z)                # :286
-        self._K_z[id(measure)] = K_z
+        self._K_z[measure] = K_z
 
         if not isinstance(noise_x, Diagonal):                                 # :293-297
             raise RuntimeError(
@@ -319,8 +322,8 @@ class AbstractPseudoObservations(AbstractObservations):
         _, uu = be.colreduce(u, want_ss=True)
         det_part = logdet_noise + chol_A.logdet()                             # :334
         iqf_part = yky - uu[..., 0]                                           # :335
-        self._parts[id(measure)] = dict(K_z=K_z, A=A, chol_A=chol_A, u=u)
-        self._elbo[id(measure)] = -0.5 * (det_part + iqf_part + trace_part)   # :336
+        self._parts[measure] = dict(K_z=K_z, A=A, chol_A=chol_A, u=u)
+        self._elbo[measure] = -0.5 * (det_part + iqf_part + trace_part)   # :336
 
 
 class PseudoObservations(AbstractPseudoObservations):
