@@ -417,6 +417,11 @@ class MultiOutputKernel(Kernel):
         return self._measure().kernels
 
     def _split(self, x):
+        if hasattr(x, "p") and hasattr(x, "_xr"):          # an FDD: that process at those inputs
+            xr = x._xr
+            return [(id(q), xi) for q, xi in xr.parts] if isinstance(xr, MultiInput) else [(id(x.p), xr)]
+        if isinstance(x, (tuple, list)):                   # several FDDs (mo/input.py:7-9)
+            return [part for e in x for part in self._split(e)]
         x = uprank(x)
         if isinstance(x, MultiInput):
             return [(id(p), xi) for p, xi in x.parts]

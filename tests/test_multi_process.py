@@ -318,6 +318,50 @@ def _reference_fdd_take():
         take(fdd, torch.tensor([1, 2]))
 
 
+def _reference_mok():
+    """tests/mo/test_kernel.py:11-104 (test_mok), pairwise part: plain inputs, FDDs and tuples of FDDs."""
+    lin = lambda a, b, k: t(np.linspace(a, b, k))
+    x1, x2 = lin(0, 1, 10), lin(1, 2, 5)
+    m = st.Measure()
+    p1 = st.GP(st.EQ(), measure=m)
+    p2 = st.GP(2 * st.EQ().stretch(2), measure=m)
+    k = st.kernels.MultiOutputKernel(m, [p1, p2])
+    ks = m.kernels
+    kk = lambda a, b, u, v: n(ks[a, b].pairwise(u, v))
+    assert str(k) == "MultiOutputKernel(EQ(), 2.0 * (EQ() > 2.0))"
+    # input versus input
+    np.testing.assert_allclose(n(k.pairwise(x1, x2)), np.block([[kk(p1, p1, x1, x2), kk(p1, p2, x1, x2)],
+                                                                  [kk(p2, p1, x1, x2), kk(p2, p2, x1, x2)]]), atol=1e-14)
+    np.testing.assert_allclose(n(k.elwise(x1)), np.concatenate([n(ks[p1].elwise(x1)), n(ks[p2].elwise(x1))]), atol=1e-14)
+    # input versus FDD
+    np.testing.assert_allclose(n(k.pairwise(p1(x1), x2)), np.hstack([kk(p1, p1, x1, x2), kk(p1, p2, x1, x2)]), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise(p2(x1), x2)), np.hstack([kk(p2, p1, x1, x2), kk(p2, p2, x1, x2)]), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise(x1, p1(x2))), np.vstack([kk(p1, p1, x1, x2), kk(p2, p1, x1, x2)]), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise(x1, p2(x2))), np.vstack([kk(p1, p2, x1, x2), kk(p2, p2, x1, x2)]), atol=1e-14)
+    # FDD versus FDD
+    np.testing.assert_allclose(n(k.pairwise(p1(x1), p1(x2))), kk(p1, p1, x1, x2), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise(p1(x1), p2(x2))), kk(p1, p2, x1, x2), atol=1e-14)
+    # several FDDs versus input, FDD, several FDDs
+    np.testing.assert_allclose(n(k.pairwise((p2(x1), p1(x2)), x1)), np.block([[kk(p2, p1, x1, x1), kk(p2, p2, x1, x1)],
+                                                                                [kk(p1, p1, x2, x1), kk(p1, p2, x2, x1)]]), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise(x1, (p2(x1), p1(x2)))), np.block([[kk(p1, p2, x1, x1), kk(p1, p1, x1, x2)],
+                                                                                [kk(p2, p2, x1, x1), kk(p2, p1, x1, x2)]]), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise((p2(x1), p1(x2)), p2(x1))), np.vstack([kk(p2, p2, x1, x1), kk(p1, p2, x2, x1)]), atol=1e-14)
+    np.testing.assert_allclose(n(k.pairwise(p2(x1), (p2(x1), p1(x2)))), np.hstack([kk(p2, p2, x1, x1), kk(p2, p1, x1, x2)]), atol=1e-14)
+    np.testing.assert_allclose(n(k.elwise((p2(x1), p1(x2)))), np.concatenate([n(ks[p2].elwise(x1)), n(ks[p1].elwise(x2))]), atol=1e-14)
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_reference_mok_cpu():
+    _reference_mok()
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_reference_mok_gpu():
+    _reference_mok()
+
+
 def _noise_forms():
     rng = np.random.default_rng(8)
     return {
