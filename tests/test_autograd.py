@@ -255,3 +255,53 @@ def test_elbo_gradients_unsupported_cases_are_loud(oracle_backend):
 @pytest.mark.parametrize("kinds,n,m,d,method", ELBO_CASES + [(("eq",), 1500, 200, 8, "vfe"), (("eq", "linear"), 900, 130, 4, "dtc")])
 def test_elbo_gradients_gpu(hip_backend, kinds, n, m, d, method):
     run_elbo_case("cuda", torch.float64, kinds, n, m, d, method, seed=n + m, tol=2e-5)
+
+
+def test_readme_example13_flow_host_logic(oracle_backend):
+    """The reference's torch learning example, line for line on the API level
+    (``readme_example13_optimisation_torch.py:9-60``): nn.Parameters, predictions before and after,
+    ``logpdf`` in an Adam loop."""
+    from stheno_amd.torch import EQ, GP, B as B_
+
+    old = B_.epsilon
+    B_.epsilon = 1e-6
+    try:
+        torch.manual_seed(0)
+        x = torch.linspace(0, 2, 40, dtype=torch.float64)
+        x_obs = torch.linspace(0, 2, 25, dtype=torch.float64)
+        y_obs = torch.sin(5 * x_obs) + 0.05 ** 0.5 * torch.randn(25, dtype=torch.float64)
+
+        class Model(torch.nn.Module):
+            def __init__(self, init_var=0.3, init_scale=1.0, init_noise=0.2):
+                super().__init__()
+                self.log_var = torch.nn.Parameter(torch.log(torch.tensor(init_var, dtype=torch.float64)))
+                self.log_scale = torch.nn.Parameter(torch.log(torch.tensor(init_scale, dtype=torch.float64)))
+                self.log_noise = torch.nn.Parameter(torch.log(torch.tensor(init_noise, dtype=torch.float64)))
+
+            def construct(self):
+                kernel = torch.exp(self.log_var) * EQ().stretch(torch.exp(self.log_scale))
+                return GP(kernel), torch.exp(self.log_noise)
+
+        model = Model()
+        f, noise = model.construct()
+        f_post = f | (f(x_obs, noise), y_obs)
+        mean0, lo0, hi0 = f_post(x, noise).marginal_credible_bounds()
+        assert mean0.shape == lo0.shape == hi0.shape == (40,)
+        opt = torch.optim.Adam(model.parameters(), lr=5e-2)
+        losses = []
+        for _ in range(60):
+            opt.zero_grad()
+            f, noise = model.construct()
+            loss = -f(x_obs, noise).logpdf(y_obs)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        assert losses[-1] < losses[0] - 1.0
+        f, noise = model.construct()
+        f_post = f | (f(x_obs, noise), y_obs)
+        mean1, lo1, hi1 = f_post(x, noise).marginal_credible_bounds()
+        err0 = float((mean0.detach() - torch.sin(5 * x)).abs().mean())
+        err1 = float((mean1.detach() - torch.sin(5 * x)).abs().mean())
+        assert err1 < err0
+    finally:
+        B_.epsilon = old
