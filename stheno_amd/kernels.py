@@ -582,7 +582,9 @@ def _wrap_mean(m):
     if callable(m):
         return FunctionMean(m)
     v = _as_float(m)
-    return ZeroMean() if v == 0 else ScaledMean(OneMean(), v)
+    if v == 0:
+        return ZeroMean()
+    return OneMean() if v == 1 else ScaledMean(OneMean(), v)
 
 
 class MultiOutputMean(Mean):

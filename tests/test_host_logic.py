@@ -396,6 +396,7 @@ def test_gp_construction_and_resolution():    # test_gp.py:55-92
     assert isinstance(st.GP(k).mean, K.ZeroMean)
     assert isinstance(st.GP(5, k).mean, K.ScaledMean)
     assert isinstance(st.GP(0, k).mean, K.ZeroMean)
+    assert isinstance(st.GP(1, k).mean, K.OneMean) and str(st.GP(1, k)) == "GP(1, EQ())"
     assert isinstance(st.GP(m, k).mean, K.FunctionMean)
     assert isinstance(st.GP(k).kernel, st.EQ)
     assert isinstance(st.GP(5).kernel, K.Scaled)
