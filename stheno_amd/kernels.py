@@ -38,17 +38,17 @@ class MultiInput:
         self.parts = [(p, uprank(x)) for p, x in parts]
         if not self.parts:
             raise ValueError("a multi-input needs at least one part")
-        if any(x.dim() != 2 for _, x in self.parts):
-            raise NotImplementedError("multi-process inputs with batch dimensions are outside the accelerated path")
+        if len({tuple(x.shape[:-2]) for _, x in self.parts}) != 1:
+            raise ValueError("the parts of a multi-process input must share their batch dimensions")
 
     dtype = property(lambda self: self.parts[0][1].dtype)
     device = property(lambda self: self.parts[0][1].device)
     # rows each part contributes: a plain input under a product process stands for ALL its components
     sizes = property(lambda self: [p.kernel.num_outputs(x) for p, x in self.parts])
-    shape = property(lambda self: (sum(self.sizes), 1))
+    shape = property(lambda self: tuple(self.parts[0][1].shape[:-2]) + (sum(self.sizes), 1))
 
     def dim(self):
-        return 2
+        return self.parts[0][1].dim()
 
     def offsets(self):
         out, o = [], 0
@@ -269,6 +269,9 @@ class Scaled(Kernel):
         self.k, self.v = k, v
         self.stationary = k.stationary
 
+    def num_outputs(self, x):
+        return self.k.num_outputs(x)
+
     def terms(self):
         t = self.k.terms()
         return None if t is None else [(kind, var * _as_float(self.v), s) for kind, var, s in t]
@@ -330,6 +333,9 @@ class Sum(Kernel):
         self.a, self.b = a, b
         self.stationary = a.stationary and b.stationary
 
+    def num_outputs(self, x):
+        return self.a.num_outputs(x)
+
     def terms(self):
         ta, tb = self.a.terms(), self.b.terms()
         if ta is None or tb is None:
@@ -365,6 +371,9 @@ class Reversed(Kernel):
     def __init__(self, k):
         self.k = k
         self.stationary = k.stationary
+
+    def num_outputs(self, x):
+        return self.k.num_outputs(x)
 
     def terms(self):
         return self.k.terms()   # sums of primitives are symmetric
@@ -425,8 +434,6 @@ class MultiOutputKernel(Kernel):
         x = uprank(x)
         if isinstance(x, MultiInput):
             return [(id(p), xi) for p, xi in x.parts]
-        if x.dim() != 2:
-            raise NotImplementedError("multi-process inputs with batch dimensions are outside the accelerated path")
         return [(pid, x) for pid in self.pids]
 
     def num_outputs(self, x):
@@ -444,7 +451,7 @@ class MultiOutputKernel(Kernel):
         sy = sx if sym else [kernels[pj].num_outputs(yj) for pj, yj in Y]
         nx, ny = sum(sx), sum(sy)
         if out is None:
-            out = ops._alloc((), nx, ny, X[0][1].dtype, X[0][1].device)
+            out = ops._alloc(tuple(X[0][1].shape[:-2]), nx, ny, X[0][1].dtype, X[0][1].device)
         r0 = 0
         for i, (pi, xi) in enumerate(X):
             r1, c0 = r0 + sx[i], 0
@@ -452,9 +459,9 @@ class MultiOutputKernel(Kernel):
                 c1 = c0 + sy[j]
                 if not (sym and lower and j > i) and r1 > r0 and c1 > c0:
                     if sym and i == j:
-                        _eval_into(kernels[pi], xi, None, out[r0:r1, c0:c1], lower=lower)
+                        _eval_into(kernels[pi], xi, None, out[..., r0:r1, c0:c1], lower=lower)
                     else:
-                        _eval_into(kernels[pi, pj], xi, yj, out[r0:r1, c0:c1])
+                        _eval_into(kernels[pi, pj], xi, yj, out[..., r0:r1, c0:c1])
                 c0 = c1
             r0 = r1
         return _add_diag(out, diag_add, diag_vec) if sym else out
@@ -476,6 +483,9 @@ class _CrossKernel(Kernel):
     def __init__(self, mok, j):
         self.mok, self.j = mok, j
 
+    def num_outputs(self, x):
+        return self.mok.num_outputs(x)
+
     def pairwise(self, x, y=None, *, cache=None, **kw):
         if y is None:
             raise ValueError("a cross-kernel between a product process and another process needs both inputs")
@@ -484,12 +494,12 @@ class _CrossKernel(Kernel):
         y = uprank(y)
         sx = [kernels[pi].num_outputs(xi) for pi, xi in X]
         nx, ny = sum(sx), kernels[self.j].num_outputs(y)
-        out = ops._alloc((), nx, ny, X[0][1].dtype, X[0][1].device)
+        out = ops._alloc(tuple(X[0][1].shape[:-2]), nx, ny, X[0][1].dtype, X[0][1].device)
         r0 = 0
         for (pi, xi), n_i in zip(X, sx):
             r1 = r0 + n_i
             if r1 > r0 and ny > 0:
-                _eval_into(kernels[pi, self.j], xi, y, out[r0:r1])
+                _eval_into(kernels[pi, self.j], xi, y, out[..., r0:r1, :])
             r0 = r1
         return out
 
@@ -637,6 +647,9 @@ class PosteriorKernel(Kernel):
 
     def __init__(self, k_ij, k_zi, k_zj, z, K_z):
         self.k_ij, self.k_zi, self.k_zj, self.z, self.K_z = k_ij, k_zi, k_zj, z, K_z
+
+    def num_outputs(self, x):
+        return self.k_ij.num_outputs(x)
 
     def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None):
         x = uprank(x)

@@ -471,3 +471,46 @@ def test_reference_multi_process_cases_cpu():
 @pytest.mark.usefixtures("hip_backend")
 def test_reference_multi_process_cases_gpu():
     _reference_mirrors(1e-9)
+
+
+def _reference_batched():
+    """tests/model/test_cases.py:134-176 (test_batched, test_mo_batched): leading batch dimensions through
+    joint sampling, joint log-densities and conditioning of several FDDs / of a product process."""
+    g = torch.Generator(device=_dev()).manual_seed(6)
+    rng = np.random.default_rng(6)
+    x1, x2 = t(rng.standard_normal((16, 10, 1))), t(rng.standard_normal((16, 5, 1)))
+    p = st.GP(1, 2 * st.EQ().stretch(0.5))
+    y1, y2 = p.measure.sample(p(x1), p(x2), generator=g)
+    logpdf = p.measure.logpdf((p(x1, 0.1), y1), (p(x2, 0.1), y2))
+    assert y1.shape == (16, 10, 1) and y2.shape == (16, 5, 1) and logpdf.shape == (16,)
+    pp = p | ((p(x1), y1), (p(x2), y2))
+    y1_2, y2_2 = pp.measure.sample(pp(x1), pp(x2), generator=g)
+    logpdf2 = pp.measure.logpdf((pp(x1, 0.1), y1), (pp(x2, 0.1), y2))
+    assert y1_2.shape == (16, 10, 1) and y2_2.shape == (16, 5, 1) and logpdf2.shape == (16,)
+    np.testing.assert_allclose(n(y1_2), n(y1), atol=1e-4)
+    np.testing.assert_allclose(n(y2_2), n(y2), atol=1e-4)
+    assert bool((logpdf2 > logpdf).all())
+    # a product process at batched inputs
+    x = t(rng.standard_normal((16, 10, 1)))
+    with st.Measure():
+        q = st.cross(st.GP(1, 2 * st.EQ().stretch(0.5)), st.GP(2, 2 * st.EQ().stretch(0.5)))
+    y = q(x).sample(generator=g)
+    lp = q(x, 0.1).logpdf(y)
+    assert lp.shape == (16,) and y.shape == (16, 20, 1)
+    qq = q | (q(x), y)
+    y2 = qq(x).sample(generator=g)
+    lp2 = qq(x, 0.1).logpdf(y)
+    assert y2.shape == (16, 20, 1) and lp2.shape == (16,)
+    assert bool((lp2 > lp).all())
+    np.testing.assert_allclose(n(y2), n(y), atol=1e-4)
+
+
+@pytest.mark.usefixtures("oracle_backend")
+def test_reference_batched_cpu():
+    _reference_batched()
+
+
+@pytest.mark.gpu
+@pytest.mark.usefixtures("hip_backend")
+def test_reference_batched_gpu():
+    _reference_batched()
