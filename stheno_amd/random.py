@@ -277,7 +277,23 @@ class Normal(RandomVector):
     def __add__(self, other):
         if isinstance(other, Normal):
             return Normal(self.mean + other.mean, self.var + other.var)
+        if isinstance(other, Random):
+            raise TypeError(f"cannot add a {type(other).__name__} to a Normal")
         return Normal(self.mean + other, self.var)
 
     def __mul__(self, other):
+        if isinstance(other, Random):
+            raise TypeError(f"cannot multiply a Normal by a {type(other).__name__}")
         return Normal(self.mean * other, Dense(self.var.dense() * (other * other)))
+
+    def lmatmul(self, a):
+        """Distribution of ``a @ x`` (``random.py:365-371``): mean ``a m``, variance ``a V a^T`` (two GEMMs)."""
+        a = a.dense() if isinstance(a, AbstractMatrix) else a
+        be = ops.get_backend()
+        av = be.gemm(a, self.var.dense(), a_kmajor=True, b_kmajor=False)          # a V
+        return Normal(be.gemm(a, self.mean, a_kmajor=True, b_kmajor=False), Dense(be.gemm(av, a, a_kmajor=True, b_kmajor=True)))
+
+    def rmatmul(self, a):
+        """Distribution of ``a^T @ x`` (``random.py:373-379``)."""
+        a = a.dense() if isinstance(a, AbstractMatrix) else a
+        return self.lmatmul(a.transpose(-1, -2).contiguous())

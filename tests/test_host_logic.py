@@ -565,3 +565,26 @@ def test_pseudoobs_kernel_call_count():       # tests/model/test_model.py:335-36
         be.kmat, be.kdiag = kmat0, kdiag0
     assert sorted(calls["kmat"], key=str) == sorted([(5, 10), (5, None), (5, 1)], key=str), calls
     assert sorted(calls["kdiag"]) == [1, 10], calls
+
+
+def test_normal_arithmetic(normal1):           # test_random.py:248-293
+    rng = np.random.default_rng(5)
+    normal2 = st.Normal(t(rng.standard_normal((3, 1))), t(np.eye(3) * 0.7 + 0.1))
+    a = Dense(t(rng.standard_normal((3, 3))))
+    an, m1, v1 = B.to_numpy(a), B.to_numpy(normal1.mean), B.to_numpy(B.dense(normal1.var))
+    m2, v2 = B.to_numpy(normal2.mean), B.to_numpy(B.dense(normal2.var))
+    approx(normal1.lmatmul(a).mean, an @ m1); approx(B.dense(normal1.lmatmul(a).var), an @ v1 @ an.T)
+    approx(normal1.rmatmul(a).mean, an.T @ m1); approx(B.dense(normal1.rmatmul(a).var), an.T @ v1 @ an)
+    b = 5.0
+    for d in (normal1 * b, b * normal1):
+        approx(d.mean, m1 * b); approx(B.dense(d.var), v1 * b ** 2)
+    with pytest.raises(TypeError):
+        normal1 * normal1
+    approx((normal1 + normal2).mean, m1 + m2); approx(B.dense((normal1 + normal2).var), v1 + v2)
+    approx((b + normal1).mean, m1 + b)
+    with pytest.raises(TypeError):
+        normal1 + st.RandomVector()
+    approx((-normal1).mean, -m1); approx(B.dense((-normal1).var), v1)
+    approx((normal1 - normal2).mean, m1 - m2); approx(B.dense((normal1 - normal2).var), v1 + v2)
+    approx((normal2 - normal1).mean, m2 - m1)
+    approx((normal1 / b).mean, m1 / b); approx(B.dense((normal1 / b).var), v1 / b ** 2)
