@@ -254,6 +254,28 @@ class Normal(RandomVector):
     def entropy(self):
         return (self.var.logdet() + self.dim * (LOG_2_PI + 1)) / 2
 
+    @property
+    def m2(self):
+        """Second moment ``V + m m^T`` (``random.py:200-202``)."""
+        m = self.mean
+        return Dense(self.var.dense() + m @ m.transpose(-1, -2))
+
+    def diagonalise(self):
+        """The distribution with its correlations set to zero (``random.py:240-246``)."""
+        return Normal(self.mean, Diagonal(self.var_diag))
+
+    def kl(self, other):
+        """``KL(self || other)`` (``random.py:294-311``): ``tr(V_o^{-1} V_s) = |L_o^{-1} L_s|_F^2`` from the two
+        Cholesky factors (one TRSM), the quadratic term by a TRSV."""
+        vs, vo = to_matrix(self.var), to_matrix(other.var)
+        if isinstance(vs, Diagonal) or isinstance(vo, Diagonal):
+            vs, vo = Dense(vs.dense()), Dense(vo.dense())
+        w = vo.chol().solve(vs.chol().lower())
+        _, ss = ops.get_backend().colreduce(w, want_ss=True)
+        ratio = ss.sum(-1)
+        iqf = vo.iqf_diag(other.mean - self.mean)[..., 0]
+        return (iqf + ratio + vo.logdet() - vs.logdet() - self.dim) / 2
+
     # -- sampling (random.py:331-363; adjacent to the hot path) ----------------
     def sample(self, num=1, noise=None, generator=None):
         """Samples as column vectors (..., N, num): ``chol(var) @ xi`` on the MFMA GEMM."""

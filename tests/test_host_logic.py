@@ -588,3 +588,19 @@ def test_normal_arithmetic(normal1):           # test_random.py:248-293
     approx((normal1 - normal2).mean, m1 - m2); approx(B.dense((normal1 - normal2).var), v1 + v2)
     approx((normal2 - normal1).mean, m2 - m1)
     approx((normal1 / b).mean, m1 / b); approx(B.dense((normal1 / b).var), v1 / b ** 2)
+
+
+def test_normal_m2_diagonalise_kl(normal1):    # test_random.py:160-163,178-182,212-215
+    rng = np.random.default_rng(9)
+    c = rng.standard_normal((3, 3))
+    normal2 = st.Normal(t(rng.standard_normal((3, 1))), t(c @ c.T + 0.5 * np.eye(3)))
+    m1, v1 = B.to_numpy(normal1.mean), B.to_numpy(B.dense(normal1.var))
+    m2, v2 = B.to_numpy(normal2.mean), B.to_numpy(B.dense(normal2.var))
+    approx(B.dense(normal1.m2), v1 + m1 @ m1.T)
+    d = normal1.diagonalise()
+    assert isinstance(d.var, Diagonal)
+    approx(d.mean, m1); approx(B.dense(d.var), np.diag(np.diag(v1)))
+    assert float(normal1.kl(normal1)) < 1e-5 and float(normal1.kl(normal2)) > 0.1
+    want = 0.5 * (np.trace(np.linalg.solve(v2, v1)) + ((m2 - m1).T @ np.linalg.solve(v2, m2 - m1))[0, 0] - 3
+                  + np.linalg.slogdet(v2)[1] - np.linalg.slogdet(v1)[1])
+    approx(normal1.kl(normal2), want, rtol=1e-8)
