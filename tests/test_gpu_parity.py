@@ -302,3 +302,19 @@ def test_outputs_must_not_need_a_copy():
         be.gemm(a, a, out=dev(np.zeros((8, 8))).t())
     with pytest.raises(ValueError):
         be.add_diag_(dev(np.zeros((8, 8))).t(), 1.0)
+
+
+def test_normal_arithmetic_and_kl_on_device():
+    rng = np.random.default_rng(2)
+    c1, c2 = rng.standard_normal((40, 40)), rng.standard_normal((40, 40))
+    v1, v2 = c1 @ c1.T + np.eye(40), c2 @ c2.T + np.eye(40)
+    m1, m2, a = rng.standard_normal((40, 1)), rng.standard_normal((40, 1)), rng.standard_normal((40, 40))
+    n1, n2 = st.Normal(dev(m1), dev(v1)), st.Normal(dev(m2), dev(v2))
+    la = n1.lmatmul(dev(a))
+    assert rel(la.mean, a @ m1) < 1e-12 and rel(B.dense(la.var), a @ v1 @ a.T) < 1e-12
+    ra = n1.rmatmul(dev(a))
+    assert rel(ra.mean, a.T @ m1) < 1e-12 and rel(B.dense(ra.var), a.T @ v1 @ a) < 1e-12
+    want = 0.5 * (np.trace(np.linalg.solve(v2, v1)) + ((m2 - m1).T @ np.linalg.solve(v2, m2 - m1))[0, 0] - 40
+                  + np.linalg.slogdet(v2)[1] - np.linalg.slogdet(v1)[1])
+    assert abs(float(n1.kl(n2)) - want) < 1e-9 * abs(want) and float(n1.kl(n1)) < 1e-9
+    assert rel(B.dense(n1.m2), v1 + m1 @ m1.T) < 1e-13
