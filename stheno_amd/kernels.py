@@ -451,7 +451,7 @@ class MultiOutputKernel(Kernel):
         sy = sx if sym else [kernels[pj].num_outputs(yj) for pj, yj in Y]
         nx, ny = sum(sx), sum(sy)
         if out is None:
-            out = ops._alloc(tuple(X[0][1].shape[:-2]), nx, ny, X[0][1].dtype, X[0][1].device)
+            out = ops.alloc_matrix(tuple(X[0][1].shape[:-2]), nx, ny, X[0][1].dtype, X[0][1].device)
         r0 = 0
         for i, (pi, xi) in enumerate(X):
             r1, c0 = r0 + sx[i], 0
@@ -494,7 +494,7 @@ class _CrossKernel(Kernel):
         y = uprank(y)
         sx = [kernels[pi].num_outputs(xi) for pi, xi in X]
         nx, ny = sum(sx), kernels[self.j].num_outputs(y)
-        out = ops._alloc(tuple(X[0][1].shape[:-2]), nx, ny, X[0][1].dtype, X[0][1].device)
+        out = ops.alloc_matrix(tuple(X[0][1].shape[:-2]), nx, ny, X[0][1].dtype, X[0][1].device)
         r0 = 0
         for (pi, xi), n_i in zip(X, sx):
             r1 = r0 + n_i

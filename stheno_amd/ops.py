@@ -85,7 +85,7 @@ def _as3_out(t):
     return t3, bshape
 
 
-def _alloc(bshape, rows, cols, dtype, device):
+def alloc_matrix(bshape, rows, cols, dtype, device):
     """An uninitialised (..., rows, cols) matrix whose leading dimension is padded to a multiple
     of 16 elements when ``cols`` is not one: rows stay 16-byte aligned, so the kernels keep their
     vector loads for odd sizes.  Returned as a view (unit inner stride, stride(-2) = padded ld)."""
@@ -93,6 +93,9 @@ def _alloc(bshape, rows, cols, dtype, device):
         ldp = (cols + 15) // 16 * 16
         return torch.empty(tuple(bshape) + (rows, ldp), dtype=dtype, device=device)[..., :cols]
     return torch.empty(tuple(bshape) + (rows, cols), dtype=dtype, device=device)
+
+
+_alloc = alloc_matrix      # (module-internal spelling)
 
 
 def _ld(t3):
