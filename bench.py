@@ -188,7 +188,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path in stheno_amd)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    use_dist = world > 1
+    use_dist = world > 1 or os.environ.get("GPK_BENCH_FORCE_DIST") == "1"   # (the env switch exercises the RCCL path on one GPU)
     if use_dist:
         import torch.distributed as dist
 
@@ -266,10 +266,12 @@ def main():
             "roofline": roofline,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.n) else cpu_baseline(name),
         }
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(line, flush=True)          # the ONE JSON line, last thing on stdout (after RCCL's own init / teardown chatter)
 
 
 if __name__ == "__main__":
