@@ -22,7 +22,8 @@ namespace {
 
 constexpr int TM = 32;   // tile rows
 constexpr int RW = 8;    // rows per wave
-constexpr int DC = 8;    // input dimensions per staged chunk
+// input dimensions per staged chunk: template parameter DC in {1, 2, 4, 8} -- the smallest that holds d
+// (the distance loop runs over the whole chunk; with D = 1 or 3 a fixed chunk of 8 is mostly zero padding)
 
 template <typename T>
 struct KTermT {
@@ -85,7 +86,7 @@ __device__ __forceinline__ T eval_terms(const KmatArgs<T>& p, T r2, T dot) {
     return val;
 }
 
-template <typename T, bool DOT>
+template <typename T, bool DOT, int DC>
 __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> p) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> p) {
 
     for (int dc = 0; dc < p.d; dc += DC) {
         __syncthreads();
-        {   // stage X chunk: TM*DC = 256 elements, one per thread
+        if (tid < TM * DC) {   // stage X chunk: TM*DC <= 256 elements, one per thread
             const int r = tid / DC, j = tid % DC;
             const int row = row0 + r;
             xs[tid] = (row < p.n && dc + j < p.d) ? X[(int64_t)row * p.ldx + dc + j] : T(0);
@@ -238,10 +239,22 @@ int gpk_kmat_launch(const int* kinds, const double* variances, const double* inv
     const int64_t gy = gpk_cdiv(n, TM);
     if (gy > 65535) return GPK_ERR_ARG(6);
     dim3 grid((unsigned)gpk_cdiv(m, 64 * VEC), (unsigned)gy, (unsigned)batch);
-    if (a.need_dot)
-        hipLaunchKernelGGL((kmat_kernel<T, true>), grid, dim3(256), 0, stream, a);
+#define GPK_KMAT_LAUNCH(DCV)                                                                     \
+    do {                                                                                         \
+        if (a.need_dot)                                                                          \
+            hipLaunchKernelGGL((kmat_kernel<T, true, DCV>), grid, dim3(256), 0, stream, a);      \
+        else                                                                                     \
+            hipLaunchKernelGGL((kmat_kernel<T, false, DCV>), grid, dim3(256), 0, stream, a);     \
+    } while (0)
+    if (d <= 1)
+        GPK_KMAT_LAUNCH(1);
+    else if (d <= 2)
+        GPK_KMAT_LAUNCH(2);
+    else if (d <= 4)
+        GPK_KMAT_LAUNCH(4);
     else
-        hipLaunchKernelGGL((kmat_kernel<T, false>), grid, dim3(256), 0, stream, a);
+        GPK_KMAT_LAUNCH(8);
+#undef GPK_KMAT_LAUNCH
     GPK_CHECK_LAUNCH();
     return GPK_OK;
 }
