@@ -16,8 +16,13 @@
  *    caller; term descriptors (`kinds`, `variances`, `inv_ls`) are HOST arrays.
  *  - `dtype`: GPK_F32 or GPK_F64; all device buffers of a call share it.
  *  - `stream` is a hipStream_t passed as void*.  Calls only ENQUEUE work: no
- *    allocation, no free, no host synchronisation, no retained pointers, no
- *    global state.  Thread-safe for distinct streams/buffers.
+ *    device allocation, no free, no host synchronisation, no retained pointers.
+ *    Process-wide state is limited to: one helper stream (CU-masked to one CU per XCD) +
+ *    events per device that gpk_potrf_la / gpk_init create on first use (fork/join around
+ *    the caller's stream, serialised by a mutex; that first use allocates 36 bytes for a
+ *    moment and synchronises once), the cached CU count per device, the tuning knobs of gpk_tune and the
+ *    opt-in measurement hooks gpk_prof_*.  Everything else is thread-safe for distinct
+ *    streams/buffers.
  *  - Return value: 0 on success; -k if argument k (1-based) is invalid;
  *    GPK_ERR_LAUNCH if a kernel launch failed.  No C++ exception crosses the ABI.
  */
@@ -47,10 +52,16 @@ extern "C" {
 #define GPK_GEMM_LOWER 1
 #define GPK_GEMM_TRI_K 2
 #define GPK_GEMM_TRI_K_LOWER 4
+#define GPK_GEMM_TRI_K_LOWER_B 8
 
 #define GPK_DIAG_BLOCK 128 /* order of the diagonal blocks whose inverses gpk_potrf leaves in `dinv` */
 
 int gpk_version(void);
+
+/* Optional: create the per-device helper stream of gpk_potrf_la now (current device) instead of at its first
+ * call -- it costs one stream creation, a 64-workgroup census kernel and ONE host synchronisation, which must
+ * not happen inside a stream capture. */
+int gpk_init(void);
 
 /* Kernel matrix  out[i][j] (+)= sum_t variances[t] * kappa_kinds[t](x_i, y_j; inv_ls[t])
  * and, if `symmetric` (x and y are the same points), + diag_add + diag_vec[i] on i == j.
@@ -84,6 +95,18 @@ int64_t gpk_dinv_elems(int64_t n);
 int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,
               int* info, int nbo, void* stream);
 
+/* The same factorisation for ONE large matrix with LOOK-AHEAD: outer blocks of `nb` columns (256 ... 4096,
+ * a power of two); the serial panel chain of outer step j+1 (diagonal-block factorisations) runs on a helper
+ * stream, on CUs the persistent trailing-update kernel of step j leaves empty, and the rows below each diagonal
+ * block are solved by ONE GEMM with the explicit inverse of the nb x nb diagonal block.  Results as gpk_potrf, plus
+ * `dinv_nb` = [ceil(n/nb)][nb][nb], the inverses of the nb x nb diagonal blocks of L -- exactly what
+ * gpk_trtri_merge(sb = nb) would produce, so the solves below can take them as they are.
+ * `ws`: gpk_potrf_la_ws_elems(n, nb) elements of scratch.  `info` as for gpk_potrf (one int, zeroed by the caller).
+ * The helper stream is forked from / joined to `stream` with events; under stream capture it joins the capture. */
+int64_t gpk_potrf_la_ws_elems(int64_t n, int nb);
+int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_nb, int nb, void* ws, int* info,
+                 void* stream);
+
 /* Merge the 128-block inverses into inverses of sb x sb diagonal blocks
  * (sb = 128 * 2^k <= 4096); dinv_sb: [batch][ceil(n/sb)][sb][sb];
  * tmp: >= ceil(n/sb) * sb * sb / 4 elements.  Part of the blocked TRSM below. */
@@ -111,13 +134,32 @@ int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, 
  * flags: GPK_GEMM_LOWER = only tiles on/below the diagonal (SYRK); GPK_GEMM_TRI_K = both operands
  * vanish for k < their row index (lower-triangular factors stored K x M, e.g. W^T W with W = L^{-1}):
  * all-zero k-chunks are skipped; GPK_GEMM_TRI_K_LOWER = A (M x K) is lower triangular (a(m,k) = 0 for
- * k > m, e.g. an inverted diagonal block times right-hand sides): the k loop stops at the tile's last row.
+ * k > m, e.g. an inverted diagonal block times right-hand sides): the k loop stops at the tile's last row;
+ * GPK_GEMM_TRI_K_LOWER_B = the same for B (b(n,k) = 0 for k > n: right-hand sides times an inverted block, transposed).
  * Replaces the dense products
  * `B.mm` / `B.matmul` / `B.iqf` outer products: stheno/model/observations.py:322-323,
  * mlkernels.PosteriorKernel (full covariance), `B.sample` (L xi): stheno/random.py:351. */
 int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
              const void* a, int64_t lda, int64_t sa, const void* b, int64_t ldb, int64_t sb, double beta,
              void* c, int64_t ldc, int64_t sc, int64_t batch, int flags, void* stream);
+
+/* Up to two rank-k updates in ONE persistent launch (a resident set of workgroups pulls 128x128 tiles of
+ * both problems from a device-side counter: one ramp, one tail):
+ *   c[m][n] = cin[m][n] + alpha * sum_k a[m][k] b[n][k]        a: m x k, b: n x k, both row-major
+ * `cin` may differ from `c` (out-of-place update).  lower_only: tiles on/below the diagonal only.
+ * ctrl: 128 bytes of device scratch (zeroed by the call).  reserve_cus != 0: the kernel leaves one CU per XCD
+ * empty while it runs, for work enqueued on another stream (what gpk_potrf_la does for its panel chain).
+ * This is the trailing update of gpk_potrf_la, exposed for measurement and reuse. */
+typedef struct {
+    int64_t m, n, k;
+    const void* a; int64_t lda;
+    const void* b; int64_t ldb;
+    const void* cin; int64_t ldcin;
+    void* c; int64_t ldc;
+    int lower_only;
+} gpk_update_t;
+int gpk_gemm_update2(int dtype, const gpk_update_t* upd, int nupd, double alpha, void* ctrl, int reserve_cus,
+                     void* stream);
 
 /* out[b] = 2 * sum_i log L[i][i].  Replaces `B.logdet`: stheno/random.py:274,
  * stheno/model/observations.py:334. */
@@ -202,6 +244,15 @@ int gpk_kmat_vjp_dense(int dtype, const int* kinds, const double* variances, con
  * + 1*(bounds-checked kernel), or -1 for all.  Not thread-safe; off by default; not used by the product path. */
 int gpk_prof_start(void);
 int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops);
+
+/* Development aids: tuning knobs for A/B measurements (native self-test `--set KEY VALUE`); defaults are the
+ * measured optima, the product path never calls these.  key 1: use 64x64 GEMM tiles below this many 128-tiles;
+ * 2: XCD super-tile order from this many tiles; 4: row-pair tile order from this many tiles; 6: look-ahead overlaps while the trailing matrix has at least this many
+ * rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the persistent update takes 64x64 tiles
+ * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm.
+ * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
+void gpk_tune(int key, int64_t value);
+void gpk_tune_diag_prof(long long* dev_buf);
 
 /* Strided 2-D copy (rows x cols). */
 int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, int64_t ldd, int64_t sd,

@@ -17,6 +17,16 @@
 
 #define D1(dtype, EXPR) DISPATCH(dtype, EXPR, EXPR)
 
+template <typename T>
+static int update2(const gpk_update_t* upd, int nupd, double alpha, void* ctrl, int reserve, hipStream_t stream) {
+    if (upd == nullptr || nupd < 1 || nupd > 2) return GPK_ERR_ARG(3);
+    GpkSeg<T> seg[2];
+    for (int i = 0; i < nupd; ++i)
+        seg[i] = GpkSeg<T>{upd[i].m, upd[i].n, upd[i].k, (const T*)upd[i].a, upd[i].lda, (const T*)upd[i].b, upd[i].ldb,
+                           (const T*)upd[i].cin, upd[i].ldcin, (T*)upd[i].c, upd[i].ldc, upd[i].lower_only, 0};
+    return gpk_gemm_persist_launch<T>(seg, nupd, (T)alpha, (unsigned*)ctrl, reserve, stream);
+}
+
 extern "C" {
 
 int gpk_version(void) { return 100; }
@@ -46,6 +56,31 @@ int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t bat
               int* info, int nbo, void* stream) {
     D1(dtype, gpk_potrf_launch<T>((T*)a, n, ld, batch, sa, (T*)dinv, info, nbo, (hipStream_t)stream));
 }
+
+int64_t gpk_potrf_la_ws_elems(int64_t n, int nb) { return gpk_potrf_la_ws_elems_impl(n, nb); }
+
+int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_nb, int nb, void* ws, int* info,
+                 void* stream) {
+    D1(dtype, gpk_potrf_la_launch<T>((T*)a, n, ld, (T*)dinv, (T*)dinv_nb, nb, (T*)ws, info, (hipStream_t)stream));
+}
+
+int gpk_gemm_update2(int dtype, const gpk_update_t* upd, int nupd, double alpha, void* ctrl, int reserve_cus,
+                     void* stream) {
+    D1(dtype, update2<T>(upd, nupd, alpha, ctrl, reserve_cus, (hipStream_t)stream));
+}
+
+int gpk_init(void) {
+    hipStream_t aux;
+    unsigned keys[8];
+    return gpk_helper_stream(&aux, keys);
+}
+
+void gpk_tune(int key, int64_t value) {
+    gpk_tune_gemm(key, value);
+    gpk_tune_potrf(key, value);
+}
+
+void gpk_tune_diag_prof(long long* dev_buf) { gpk_set_diag_prof(dev_buf); }
 
 int gpk_trtri_merge(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
                     const void* dinv128, int sb, void* dinv_sb, void* tmp, void* stream) {

@@ -79,6 +79,7 @@ static inline int64_t gpk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // flags bit 1 (tri_k): both operands vanish for k < their row index (lower-triangular
 //   factors stored K x M): the k loop of tile row m0 starts at k = m0.
 // flags bit 2 (tri_k_lower): A (M x K) is lower triangular: the k loop of tile row m0 stops at m0 + tile.
+// flags bit 3 (tri_k_lower_b): B (N x K) is lower triangular: the k loop of tile column n0 stops at n0 + tile.
 // merged diagonal-block sizes of the solves: 128 * 2^k up to 4096
 static inline bool gpk_valid_sb(int sb) { return sb >= 128 && sb <= 4096 && (sb & (sb - 1)) == 0; }
 
@@ -96,9 +97,43 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
                      int64_t batch, int64_t batch2, int flags, hipStream_t stream);
 
+// Persistent two-problem update (see gemm_persist_kernel in gpk_gemm.hip): each segment is
+//   C[m][n] = Cin[m][n] + alpha * sum_k A[m][k] B[n][k]     (A: M x K, B: N x K, both k contiguous)
+// lower_only: tiles on/below the diagonal only.  ctrl: GPK_PERSIST_CTRL_WORDS unsigned words of device
+// scratch (zeroed by the launch).  reserve: keep one CU per XCD free of this kernel's workgroups.
+#define GPK_PERSIST_CTRL_WORDS 32
+// The library's helper stream (one per device, created on first use): masked to one CU per XCD; keys[x] = the
+// HW_ID key (+1) of that CU on XCD x, 0 if nothing is reserved.
+int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]);
+template <typename T>
+struct GpkSeg {
+    int64_t M, N, K;
+    const T* A; int64_t lda;
+    const T* B; int64_t ldb;
+    const T* Cin; int64_t ldcin;
+    T* C; int64_t ldc;
+    int lower_only;
+    int tri_b;      // B (N x K) is lower triangular: k stops at the column tile's last column (2: pair column tiles c, n-1-c)
+};
+// Cin == nullptr: C = alpha * A B^T (nothing is read from C)
+template <typename T>
+int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,
+                            hipStream_t stream);
+
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
                      int* info, int nbo, hipStream_t stream);
+
+// Look-ahead Cholesky of one large matrix (gpk_potrf.hip).  dinv_big: [ceil(n/nb)][nb][nb] (receives the
+// inverses of the nb x nb diagonal blocks of L); ws: gpk_potrf_la_ws_elems_impl(n, nb) elements.
+int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb);
+template <typename T>
+int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
+                        hipStream_t stream);
+
+void gpk_tune_gemm(int key, int64_t value);
+void gpk_tune_potrf(int key, int64_t value);
+void gpk_set_diag_prof(long long* dev_buf);
 
 template <typename T>
 int gpk_copy2d_launch(const T* src, int64_t lds, int64_t ss, T* dst, int64_t ldd, int64_t sd,

@@ -34,6 +34,7 @@
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -47,7 +48,8 @@ struct GemmArgs {
     const T* A;
     const T* B;
     T* C;
-    int64_t lda, ldb, ldc, sA, sB, sC;
+    const T* Cin;               // where beta * C is read from (== C unless the update goes out of place)
+    int64_t lda, ldb, ldc, ldcin, sA, sB, sC;
     int64_t sA2, sB2, sC2;      // second (blockIdx.z) batch level
     int M, N, K;
     T alpha, beta_over_alpha;
@@ -58,6 +60,8 @@ struct GemmArgs {
     int tri_k;        // operands are lower-triangular in k (zero for k < row index): start at k = m0
     int tri_k_lo;     // A (M x K) is lower triangular (zero for k > row): stop at k = m0 + TS; tile rows run
                       // longest-first (bottom rows first)
+    int tri_k_lo_b;   // B (N x K) is lower triangular (zero for k > column index n): stop at k = n0 + tile width
+    int pair_cols;    // persistent kernel, tri_k_lo_b: one task = column tiles c and tiles_n - 1 - c of a tile row
     int swizzle;
     int tri_pairs;    // triangular enumeration by row pairs / 8-column chunks (see decode_tile)
     int n_super;
@@ -101,6 +105,11 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
         if (tri) {
             tri_decode(bid, ti, tj);
             return ti < p.tiles_m;
+        }
+        if (p.tri_k_lo_b) {   // B lower triangular in k: column tile tj runs tj + 1 blocks of k -- longest columns first
+            tj = p.tiles_n - 1 - bid / p.tiles_m;
+            ti = bid - (bid / p.tiles_m) * p.tiles_m;
+            return tj >= 0;
         }
         ti = bid / p.tiles_n;
         tj = bid - ti * p.tiles_n;
@@ -205,19 +214,17 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 
 // NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
 // Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT = 1>
-__global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
+// One output tile (ti, tj) of one problem, computed by the calling workgroup (256 threads).  `smem`:
+// 2 * (1 + NCT) * op_bytes(TS) bytes of LDS, free on entry; every wave has passed a barrier after its
+// last LDS read when the function returns.
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT>
+__device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem) {
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
     constexpr int FR = TS / 32;          // 16x16 fragments per wave in each direction
     constexpr int WT = TS / 2;           // wave sub-tile edge
     constexpr int OPB = op_bytes(TS), STAGE = (1 + NCT) * OPB;
-
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-    int ti, tj;
-    if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,10 +233,10 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
     const int lr = lane & 15, kq = lane >> 4;
     const int swz = (lr >> 1) & 7;
 
-    const int64_t b = blockIdx.y, b2 = blockIdx.z;
     const T* __restrict__ A = p.A + b * p.sA + b2 * p.sA2;
     const T* __restrict__ B = p.B + b * p.sB + b2 * p.sB2;
     T* __restrict__ C = p.C + b * p.sC + b2 * p.sC2;
+    const T* __restrict__ Cin = p.Cin + b * p.sC + b2 * p.sC2;
 
     const int m0 = ti * TS, n0 = tj * TS * NCT;
 
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
                         const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
                         const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
                         T v = T(0);
-                        if (!EDGE || (row < p.M && col < p.N)) v = C[(int64_t)row * p.ldc + col];
+                        if (!EDGE || (row < p.M && col < p.N)) v = Cin[(int64_t)row * p.ldcin + col];
                         acc[c][fi][fj][i] = v * p.beta_over_alpha;
                     }
         } else {
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
 
     int nk = (p.K + BK - 1) / BK;
     if (p.tri_k_lo) nk = min(nk, (m0 + TS + BK - 1) / BK);   // A vanishes right of its diagonal
+    if (p.tri_k_lo_b) nk = min(nk, (n0 + TS * NCT + BK - 1) / BK);   // B vanishes right of its diagonal
     int kc0 = p.tri_k ? m0 / BK : 0;            // all-zero k-chunks of triangular operands are skipped
     if (kc0 > nk - 1) kc0 = nk > 0 ? nk - 1 : 0;
     // Register staging.  Small tiles (TS = 64) serve the narrow, latency-bound GEMMs of the path
@@ -393,6 +401,104 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
                 }
 }
 
+// NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
+// Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT = 1>
+__global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (1 + NCT) * op_bytes(TS)];
+    int ti, tj;
+    if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
+    gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
+}
+
+// ---- persistent variant: a resident set of workgroups pulls tiles of up to two problems ("segments")
+// from one device-side counter.  It exists for the look-ahead Cholesky (gpk_potrf.hip):
+//  * the trailing update of one outer step is two problems -- the next panel's strip (written OUT OF
+//    PLACE into the panel workspace) and the lower triangle behind it -- that should share one
+//    launch, one ramp and one tail;
+//  * `reserve`: the workgroups that find themselves on one of the CUs named by `rkeys` (one CU per XCD,
+//    identified by the CU / SH / SE fields of HW_REG_HW_ID) exit at once.  The grid has exactly one
+//    workgroup per residency slot and block b goes to XCD b % 8, so every XCD receives as many workgroups as
+//    it has slots, the pair on the reserved CU leaves, and that CU stays EMPTY for as long as the update
+//    runs.  The library's helper stream is created with a CU mask of exactly those CUs
+//    (gpk_helper_stream): the serial panel chain of the next outer step of the Cholesky runs there
+//    meanwhile.  Without this nothing co-resides with the update -- its two workgroups per CU hold 144 of
+//    160 KiB LDS and 444 of 512 VGPRs, and a second stream starves until the grid drains (measured,
+//    profiles/r01_experiments.md; an UNMASKED second stream starves even beside emptied CUs, r02 notes).
+//    Placement only: results do not depend on which workgroups leave.
+// ctrl[0] = tile counter, ctrl[1] = leavers; zeroed by the launcher (memset node) per launch.
+template <typename T>
+struct PersistArgs {
+    GemmArgs<T> seg[2];
+    int ntiles0, ntiles;      // tiles of segment 0, of both
+    unsigned* ctrl;
+    int reserve;
+    int max_leave;
+    unsigned rkeys[8];
+};
+
+template <typename T, int TS, bool EDGE>
+__global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_kernel(PersistArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * op_bytes(TS)];
+    // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast
+    // word lives in the unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel
+    // its fourth workgroup per CU)
+    volatile int& s_tile = *reinterpret_cast<volatile int*>(smem + TS * 128);
+    const int tid = threadIdx.x;
+    if (p.reserve) {
+        if (tid == 0) {
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            const unsigned key = ((hw >> 8) & 0xffu) + 1u;                 // CU_ID[11:8] SH_ID[12] SE_ID[15:13]
+            bool leave = (p.rkeys[xcc & 7u] == key);
+            // never more than `max_leave` leavers (the pair of workgroups of each reserved CU): were the rest of
+            // the chip blocked by somebody else's kernel, the whole grid could otherwise drain through the
+            // reserved CUs and leave the update undone
+            if (leave && atomicAdd(&p.ctrl[1], 1u) >= (unsigned)p.max_leave) leave = false;
+            s_tile = leave ? -1 : 0;
+        }
+        __syncthreads();
+        if (s_tile < 0) return;
+        __syncthreads();
+    }
+    int t = 0;
+    if (tid == 0) s_tile = (int)atomicAdd(&p.ctrl[0], 1u);
+    __syncthreads();
+    t = __builtin_amdgcn_readfirstlane(s_tile);     // uniform by construction; tell the compiler (scalar loads of the segment)
+    __syncthreads();
+    while (t < p.ntiles) {
+        // the next tile index is requested now and read after this tile: its latency hides under the k-loop
+        int nxt = 0;
+        if (tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);
+        const int sgi = (t >= p.ntiles0) ? 1 : 0;
+        const GemmArgs<T>& g = p.seg[sgi];
+        int ti, tj;
+        const int tl = t - (sgi ? p.ntiles0 : 0);
+        int reps = 1;
+        bool ok = true;
+        if (g.tri_k_lo_b && g.pair_cols) {
+            // B lower triangular in k: column tile c runs c + 1 blocks of k.  One task = the tiles c and
+            // tiles_n - 1 - c of one tile row, tiles_n + 1 blocks together whatever c is: equal tasks.
+            const int half = g.tiles_n >> 1;
+            ti = tl / half;
+            tj = tl - ti * half;
+            reps = 2;
+        } else {
+            ok = decode_tile(g, tl, ti, tj);
+        }
+        if (ok) {
+#pragma unroll 1
+            for (int r = 0; r < reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
+                gemm_tile<T, TS, true, true, EDGE, 1>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem);
+        }
+        if (tid == 0) s_tile = nxt;
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_tile);
+        __syncthreads();
+    }
+}
+
 template <typename T, int TS, bool EDGE>
 void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, const GemmArgs<T>& args) {
     if (a_kmaj && b_kmaj)
@@ -432,19 +538,35 @@ struct Prof {
 };
 Prof g_prof;
 
-int64_t g_small_tile_below = 1024;  // tuning knob (gpk_debug_set(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
-int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_debug_set(4, v)): row-pair order from this many tiles
-int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_debug_set(2, v)); r01 sweep: the 8x8 XCD supertile order
+int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
+int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
+int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
                                     // unbalance the XCDs), so it is off unless asked for
 
 }  // namespace
 
-// Development aid (not in include/gpk.h): runtime tuning knobs for A/B runs on the GPU box.
-extern "C" void gpk_debug_set(int key, int64_t value) {
+namespace {
+int64_t g_persist_small_below = 512;   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
+int g_cu_count[64] = {0};
+int device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (g_cu_count[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cu_count[dev] = n;
+    }
+    return g_cu_count[dev];
+}
+}  // namespace
+
+// Tuning knobs of this file (gpk_tune in include/gpk.h): A/B runs on the GPU box.
+void gpk_tune_gemm(int key, int64_t value) {
     if (key == 1) g_small_tile_below = value;
     if (key == 2) g_swizzle_from = (int)value;
     if (key == 4) g_tri_pairs_from = (int)value;
+    if (key == 8) g_persist_small_below = value;
 }
 
 extern "C" int gpk_prof_start(void) {
@@ -488,8 +610,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     constexpr int BK = Traits<T>::BK;
 
     GemmArgs<T> g;
-    g.A = A; g.B = B; g.C = C;
-    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.A = A; g.B = B; g.C = C; g.Cin = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldcin = ldc;
     g.sA = sA; g.sB = sB; g.sC = sC;
     g.sA2 = sA2; g.sB2 = sB2; g.sC2 = sC2;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -520,6 +642,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.lower_only = lower_only ? 1 : 0;
     g.tri_k = (flags & 2) ? 1 : 0;
     g.tri_k_lo = (flags & 4) ? 1 : 0;
+    g.tri_k_lo_b = (flags & 8) ? 1 : 0;
+    g.pair_cols = 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
@@ -586,12 +710,174 @@ int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T
                                ldc, sC, 0, batch, 1, flags, stream);
 }
 
+// ---- the library's helper stream: confined (CU mask) to one CU per XCD, whose identities the persistent
+// update is told to keep clear of ----
+namespace {
+struct HelperDev {
+    int state = 0;              // 0 = not tried, 1 = ready, -1 = unavailable
+    hipStream_t aux = nullptr;
+    unsigned keys[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+HelperDev g_helper[64];
+std::mutex g_helper_mutex;
+
+__global__ void helper_census_kernel(unsigned* out) {
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const unsigned key = ((hw >> 8) & 0xffu) + 1u;
+        const unsigned old = atomicCAS(&out[xcc & 7u], 0u, key);
+        if (old != 0u && old != key) atomicAdd(&out[8], 1u);     // a second CU on this XCD: the mask is not what we think
+    }
+}
+}  // namespace
+
+// One-time per device (first look-ahead factorisation, or gpk_init): creates the stream, runs a 64-workgroup
+// census on it and reads 36 bytes back -- the only host synchronisation and the only allocation of the library.
+int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GPK_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_helper_mutex);
+    HelperDev& h = g_helper[dev];
+    if (h.state == 0) {
+        h.state = -1;
+        // CU-mask bit b of this API: XCD b % 8, then SE (b / 8) % 4, then the (b / 32)-th ACTIVE CU of that SE
+        // (measured on MI355X, profiles/r02_experiments.md; an XCD with no bit set is left unrestricted, so every
+        // XCD gets its bit).  Bits 0..7 = the first active CU of SE 0 on each of the 8 XCDs.
+        uint32_t mask[8] = {0xffu, 0, 0, 0, 0, 0, 0, 0};
+        hipStream_t st = nullptr;
+        unsigned* d = nullptr;
+        if (hipExtStreamCreateWithCUMask(&st, 8, mask) == hipSuccess && hipMalloc(&d, 9 * sizeof(unsigned)) == hipSuccess) {
+            unsigned host[9] = {0};
+            bool ok = hipMemsetAsync(d, 0, sizeof(host), st) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(helper_census_kernel, dim3(64), dim3(64), 0, st, d);
+                ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+                     hipMemcpy(host, d, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+            }
+            int nk = 0;
+            for (int x = 0; x < 8; ++x) nk += host[x] != 0;
+            if (ok && host[8] == 0 && nk == 8) {
+                for (int x = 0; x < 8; ++x) h.keys[x] = host[x];
+                h.aux = st;
+                h.state = 1;
+            }
+        }
+        if (d) (void)hipFree(d);
+        if (h.state != 1) {
+            // no CU mask (or not the layout above): a plain helper stream, nothing reserved -- the look-ahead then
+            // does not overlap (results are the same)
+            if (st) (void)hipStreamDestroy(st);
+            if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) == hipSuccess) h.state = 2;
+        }
+    }
+    if (h.state <= 0) return GPK_ERR_LAUNCH;
+    *aux = h.aux;
+    for (int x = 0; x < 8; ++x) keys[x] = (h.state == 1) ? h.keys[x] : 0u;
+    return GPK_OK;
+}
+
+// ---- persistent launch: up to two k-major problems  C = Cin + alpha * A B^T  in one resident grid ----
+
+
+template <typename T>
+int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,
+                            hipStream_t stream) {
+    if (nseg < 1 || nseg > 2) return GPK_ERR_ARG(2);
+    if (ctrl == nullptr) return GPK_ERR_ARG(4);
+    if (alpha == T(0)) return GPK_ERR_ARG(3);
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int BK = Traits<T>::BK;
+    int64_t t128 = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const GpkSeg<T>& q = segs[i];
+        if (q.M > INT32_MAX || q.N > INT32_MAX || q.K > INT32_MAX || q.K <= 0) return GPK_ERR_ARG(1);
+        if (q.M <= 0 || q.N <= 0) continue;
+        const int64_t tm = gpk_cdiv(q.M, 128), tn = gpk_cdiv(q.N, 128);
+        t128 += (q.lower_only && tm == tn) ? tm * (tm + 1) / 2 : tm * tn;
+    }
+    if (t128 == 0) return GPK_OK;
+    const int ts = (t128 < g_persist_small_below) ? 64 : 128;
+
+    PersistArgs<T> pa;
+    bool edge = false;
+    int64_t total = 0;
+    double flops = 0;
+    int live = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const GpkSeg<T>& q = segs[i];
+        if (q.M <= 0 || q.N <= 0) continue;
+        GemmArgs<T>& g = pa.seg[live];
+        g.A = q.A; g.B = q.B; g.C = q.C; g.Cin = q.Cin;
+        g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldcin = q.ldcin;
+        g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
+        g.M = (int)q.M; g.N = (int)q.N; g.K = (int)q.K;
+        g.alpha = alpha; g.has_beta = q.Cin != nullptr ? 1 : 0; g.beta_over_alpha = g.has_beta ? T(1) / alpha : T(0);
+        if (!g.has_beta) g.Cin = q.C;
+        g.tiles_m = (int)gpk_cdiv(q.M, ts); g.tiles_n = (int)gpk_cdiv(q.N, ts);
+        g.lower_only = q.lower_only ? 1 : 0;
+        g.tri_k = g.tri_k_lo = 0;
+        g.tri_k_lo_b = q.tri_b ? 1 : 0;
+        g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1;
+        const bool aligned = ((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && (q.lda % VEC == 0) &&
+                             (q.ldb % VEC == 0);
+        g.vec_ok = aligned ? 1 : 0;
+        edge = edge || !aligned || (q.M % ts) || (q.N % ts) || (q.K % BK);
+        const bool tri = g.lower_only && g.tiles_m == g.tiles_n;
+        int64_t nt = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
+        g.pair_cols = (q.tri_b == 2 && !g.lower_only && g.tiles_n >= 2 && g.tiles_n % 2 == 0) ? 1 : 0;
+        if (g.pair_cols) nt = (int64_t)g.tiles_m * (g.tiles_n / 2);
+        if (live == 0) pa.ntiles0 = (int)nt;
+        total += nt;
+        flops += (q.lower_only || q.tri_b ? 1.0 : 2.0) * (double)q.M * (double)q.N * (double)q.K;
+        ++live;
+    }
+    if (live == 1) { pa.seg[1] = pa.seg[0]; }
+    if (total > INT32_MAX / 2) return GPK_ERR_ARG(1);
+    pa.ntiles = (int)total;
+    pa.ctrl = ctrl;
+    if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
+
+    const int per_cu = (ts == 128) ? 2 : 4;
+    int64_t slots = (int64_t)device_cus() * per_cu;
+    int64_t gridx = total < slots ? total : slots;
+    if (total < slots) reserve = 0;      // a grid that does not fill the chip leaves CUs free by itself
+    pa.reserve = 0;
+    pa.max_leave = 0;
+    for (int x = 0; x < 8; ++x) pa.rkeys[x] = 0;
+    if (reserve) {
+        hipStream_t aux;
+        unsigned keys[8];
+        if (gpk_helper_stream(&aux, keys) == GPK_OK) {
+            int nk = 0;
+            for (int x = 0; x < 8; ++x) { pa.rkeys[x] = keys[x]; nk += keys[x] != 0; }
+            pa.reserve = nk > 0 ? 1 : 0;
+            pa.max_leave = per_cu * nk;
+        }
+    }
+    ProfSlot* slot = nullptr;
+    if (g_prof.on) slot = g_prof.begin(32 + (sizeof(T) == 8 ? 8 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), flops, stream);
+    dim3 grid((unsigned)gridx);
+    if (ts == 128) {
+        if (edge) hipLaunchKernelGGL((gemm_persist_kernel<T, 128, true>), grid, dim3(256), 0, stream, pa);
+        else hipLaunchKernelGGL((gemm_persist_kernel<T, 128, false>), grid, dim3(256), 0, stream, pa);
+    } else {
+        if (edge) hipLaunchKernelGGL((gemm_persist_kernel<T, 64, true>), grid, dim3(256), 0, stream, pa);
+        else hipLaunchKernelGGL((gemm_persist_kernel<T, 64, false>), grid, dim3(256), 0, stream, pa);
+    }
+    if (slot) g_prof.end(slot, stream);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
 #define GPK_INST(T)                                                                                  \
     template int gpk_gemm_launch2<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,    \
                                      int64_t, int64_t, const T*, int64_t, int64_t, int64_t, T, T*,   \
                                      int64_t, int64_t, int64_t, int64_t, int64_t, int, hipStream_t); \
     template int gpk_gemm_launch<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,     \
                                     int64_t, const T*, int64_t, int64_t, T, T*, int64_t, int64_t,    \
-                                    int64_t, int, hipStream_t);
+                                    int64_t, int, hipStream_t);                                      \
+    template int gpk_gemm_persist_launch<T>(const GpkSeg<T>*, int, T, unsigned*, int, hipStream_t);
 GPK_INST(double)
 GPK_INST(float)

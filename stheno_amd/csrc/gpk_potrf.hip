@@ -20,6 +20,7 @@
 // inv(L_cc) blocks are kept: gpk_solve.hip turns every triangular solve of the
 // path into GEMM/GEMV work with them.
 #include "gpk_common.hpp"
+#include <vector>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct DiagArgs {
     T* dinv;
     int64_t dinv_bstride;
     int* info;
+    int info_base;     // added to the reported pivot order (the matrix may be a diagonal block of a larger one)
     long long* prof;   // debug: per-phase cycle stamps of workgroup 0 (nullable)
 };
 
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
     //   (c2)_s rank-16 update of the remaining tiles        waves 1-3}
     long long t_b = 0, t_c1 = 0, t_a = 0, t0 = 0;
     const bool prof = (p.prof != nullptr && blockIdx.x == 0);
-    if (wave == 0) micro_chol<T>(S, rdiag, 0, lane, lr, p.info + b, (int)p.off);
+    if (wave == 0) micro_chol<T>(S, rdiag, 0, lane, lr, p.info + b, (int)p.off + p.info_base);
     __syncthreads();
     for (int s = 0; s < 8; ++s) {
         const int c0 = 16 * s;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
         __syncthreads();
         if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); t_c1 += t1 - t0; t0 = t1; }
         if (wave == 0)
-            micro_chol<T>(S, rdiag, c0 + 16, lane, lr, p.info + b, (int)p.off);
+            micro_chol<T>(S, rdiag, c0 + 16, lane, lr, p.info + b, (int)p.off + p.info_base);
         else
             rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - 1, 3, lane, lr, kq);
         if (prof && tid == 0) t_a += (long long)__builtin_readcyclecounter() - t0;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
     PROF_MARK(5);
 }
 
-long long* g_diag_prof = nullptr;   // development aid, set through gpk_debug_diag_prof
+long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
 
 template <typename T>
 struct PanelCtx {
@@ -454,6 +456,7 @@ struct PanelCtx {
     int64_t dstride;
     int* info;
     hipStream_t stream;
+    int info_base;
 };
 
 // Factor the panel columns [c0, c0 + w) (rows c0..n), all updates from columns
@@ -466,7 +469,7 @@ int potrf_panel(const PanelCtx<T>& x, int64_t c0, int64_t w) {
     if (w <= GPK_DB) {
         DiagArgs<T> d;
         d.A = x.A; d.ld = x.ld; d.bstride = x.bstride; d.off = c0; d.n = (int)x.n;
-        d.dinv = x.dinv; d.dinv_bstride = x.dstride; d.info = x.info;
+        d.dinv = x.dinv; d.dinv_bstride = x.dstride; d.info = x.info; d.info_base = x.info_base;
         d.prof = g_diag_prof;
         hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3((unsigned)x.batch), dim3(256), 0, x.stream, d);
         GPK_CHECK_LAUNCH();
@@ -494,13 +497,13 @@ int potrf_panel(const PanelCtx<T>& x, int64_t c0, int64_t w) {
 
 }  // namespace
 
-// Development aid (not part of include/gpk.h): device buffer of 8 int64 per diagonal
+// Development aid (gpk_tune_diag_prof in include/gpk.h): device buffer of 16 int64 per diagonal
 // block that receives cycle-counter stamps of the diag kernel's phases.
-extern "C" void gpk_debug_diag_prof(long long* dev_buf) { g_diag_prof = dev_buf; }
+void gpk_set_diag_prof(long long* dev_buf) { g_diag_prof = dev_buf; }
 
 template <typename T>
-int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
-                     int* info, int nbo, hipStream_t stream) {
+static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
+                       int* info, int nbo, int info_base, hipStream_t stream) {
     if (n <= 0 || batch <= 0) return GPK_OK;
     if (n > INT32_MAX) return GPK_ERR_ARG(2);
     if (ld < n) return GPK_ERR_ARG(3);
@@ -511,7 +514,7 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
     const int64_t nblk = gpk_cdiv(n, GPK_DB);
     const int64_t dstride = nblk * GPK_DB * GPK_DB;
 
-    PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream};
+    PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream, info_base};
     for (int64_t k0 = 0; k0 < n; k0 += nbo) {
         const int64_t k1 = (k0 + nbo < n) ? k0 + nbo : n;
         int pst = potrf_panel<T>(ctx, k0, nbo);
@@ -524,6 +527,199 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
         }
     }
     return GPK_OK;
+}
+
+
+// ---------------------------------------------------------------------------
+// Look-ahead variant for ONE large matrix (n >= ~4096; the batched path above keeps every CU busy
+// without it).  Outer blocks of nb columns (nb = 1024: fp64, 512: fp32); per outer step j
+//
+//   chain(j)      factor the nb x nb DIAGONAL block only (the recursion above, restricted to nb rows)
+//                 and merge its 128-block inverses into W_j = inv(L_jj)  -- serial, latency-bound,
+//                 a few workgroups at a time;
+//   solve(j)      A[k1:, k0:k1] = T[k1:, :] W_j^T   ONE full-chip GEMM (k clipped to W's triangle) for all
+//                 rows below the diagonal block, instead of ~30 tall-skinny launches per panel; the
+//                 operand T is the panel as the previous trailing update left it, in a workspace, so
+//                 the GEMM runs out of place straight into A;
+//   diag(j+1)     A[k1:k2, k1:k2] -= P P^T  (small), then chain(j+1) is enqueued on a SECOND stream;
+//   trail(j)      the persistent two-segment update (gemm_persist_kernel): the next panel's strip
+//                 A[k2:, k1:k2] - P P^T  -> T, and the lower triangle A[k2:, k2:] -= P P^T in place,
+//                 with one CU per XCD kept empty for chain(j+1) to run on meanwhile.
+//
+// So the serial chain of step j+1 runs under the trailing update of step j (depth-1 look-ahead),
+// and what is left on the main stream is GEMM work at full-chip size.  W_j doubles as the merged
+// diagonal-block inverse that the triangular solves need afterwards (`dinv_big`).
+// ---------------------------------------------------------------------------
+#include <mutex>
+
+namespace {
+
+struct LaDevice {
+    hipStream_t aux = nullptr;
+    std::vector<hipEvent_t> events;
+};
+std::mutex g_la_mutex;
+LaDevice g_la_dev[64];
+int64_t g_la_min_rows = 2048;     // tuning knob (gpk_tune(6, v)): overlap while the trailing matrix has >= this many rows
+int64_t g_la_tail_rows = 5120;    // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path
+int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
+int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
+int g_la_mode = 1;                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
+
+LaDevice* la_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    LaDevice& d = g_la_dev[dev];
+    if (d.aux == nullptr) {
+        unsigned keys[8];
+        if (gpk_helper_stream(&d.aux, keys) != GPK_OK) {
+            d.aux = nullptr;
+            return nullptr;
+        }
+    }
+    return &d;
+}
+
+hipEvent_t la_event(LaDevice& d, size_t i) {
+    while (d.events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        d.events.push_back(e);
+    }
+    return d.events[i];
+}
+
+template <typename T>
+int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tmp, int* info, int64_t j,
+             hipStream_t s) {
+    const int64_t k0 = j * nb;
+    const int64_t w = (n - k0 < nb) ? n - k0 : nb;
+    T* Ab = A + k0 * ld + k0;
+    T* d128 = dinv128 + (k0 / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
+    PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0};
+    int st = potrf_panel<T>(sub, 0, nb);
+    if (st) return st;
+    return gpk_trtri_merge_launch<T>(Ab, w, ld, 1, 0, d128, nb, dinv_big + j * (int64_t)nb * nb, tmp, s);
+}
+
+}  // namespace
+
+void gpk_tune_potrf(int key, int64_t value) {
+    if (key == 6) g_la_min_rows = value;
+    if (key == 7) g_la_mode = (int)value;
+    if (key == 9) g_la_tail_rows = value;
+    if (key == 10) g_la_ps_mode = (int)value;
+    if (key == 11) g_la_strip_last = (int)value;
+}
+
+#define GPK_LA_PAD 16
+int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb) {
+    return (n > nb ? n : nb) * (int64_t)(nb + GPK_LA_PAD) + (int64_t)nb * nb / 4 + 16 + 64;   // panel, merge scratch, 64 elements >= the control words
+}
+
+template <typename T>
+int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
+                        hipStream_t stream) {
+    if (n <= 0) return GPK_OK;
+    if (n > INT32_MAX) return GPK_ERR_ARG(2);
+    if (ld < n) return GPK_ERR_ARG(3);
+    if (nb < 256 || nb > 4096 || (nb & (nb - 1))) return GPK_ERR_ARG(6);
+    if (dinv128 == nullptr || dinv_big == nullptr || ws == nullptr || info == nullptr) return GPK_ERR_ARG(4);
+
+    std::lock_guard<std::mutex> lock(g_la_mutex);
+    LaDevice* dev = la_device();
+    if (dev == nullptr) return GPK_ERR_LAUNCH;
+    unsigned* ctrl = reinterpret_cast<unsigned*>(ws);                   // 64 elements reserved
+    // n x nb, leading dimension nb + 16: with a power-of-two pitch the rows of a tile sit on a few memory channels and
+    // the panel GEMM, which streams this buffer once, crawls (measured 2x)
+    const int64_t ldt = nb + GPK_LA_PAD;
+    T* Tp = ws + 64;
+    T* tmp = Tp + (n > nb ? n : nb) * ldt;
+    const int64_t nblk = gpk_cdiv(n, nb);
+    const int64_t per = (int64_t)nb * nb;
+    size_t ev = 0;
+
+    // Small matrices, and the tail of big ones, are chain-bound: there the plain right-looking recursion
+    // (no explicit block inverse, no separate panel GEMM) is faster -- measured crossover ~5000 rows.
+    auto finish_plain = [&](int64_t k) -> int {       // factor A[k:, k:] (all earlier panels applied) the plain way
+        int s = potrf_plain<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB), info,
+                               0, (int)k, stream);
+        if (s) return s;
+        return gpk_trtri_merge_launch<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB),
+                                         nb, dinv_big + (k / nb) * per, Tp, stream);   // the panel workspace is free by now
+    };
+    if (n <= g_la_tail_rows) return finish_plain(0);
+
+    int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, 0, stream);
+    if (st) return st;
+    if (nblk > 1) {   // the first panel enters the workspace as it is
+        st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, n - nb, nb, 1, stream);
+        if (st) return st;
+    }
+    for (int64_t j = 0; j + 1 < nblk; ++j) {
+        const int64_t k0 = j * nb, k1 = k0 + nb;
+        const int64_t k2 = (k1 + nb < n) ? k1 + nb : n;
+        // solve(j): rows k1.. of panel j  (k clipped to W's triangle)
+        if (g_la_ps_mode == 0) {
+            st = gpk_gemm_launch<T>(true, true, n - k1, nb, nb, T(1), Tp + k1 * ldt, ldt, 0, dinv_big + j * per, nb, 0, T(0),
+                                    A + k1 * ld + k0, ld, 0, 1, 8, stream);
+        } else {
+            GpkSeg<T> ps{n - k1, nb, nb, Tp + k1 * ldt, ldt, dinv_big + j * per, nb, nullptr, 0, A + k1 * ld + k0, ld, 0, g_la_ps_mode};
+            st = gpk_gemm_persist_launch<T>(&ps, 1, T(1), ctrl, 0, stream);
+        }
+        if (st) return st;
+        const T* P1 = A + k1 * ld + k0;
+        if (n - k1 <= g_la_tail_rows) {
+            // last look-ahead step: the whole trailing matrix is updated in place, the rest is factorised the plain way
+            GpkSeg<T> sg{n - k1, n - k1, nb, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0};
+            st = gpk_gemm_persist_launch<T>(&sg, 1, T(-1), ctrl, 0, stream);
+            if (st) return st;
+            return finish_plain(k1);
+        }
+        // diag(j+1)
+        st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, nb, T(-1), P1, ld, 0, P1, ld, 0, T(1),
+                                A + k1 * ld + k1, ld, 0, 1, 1, stream);
+        if (st) return st;
+        const bool overlap = g_la_mode == 1 && (n - k2) >= g_la_min_rows;
+        hipEvent_t e_fork = nullptr, e_join = nullptr;
+        if (overlap) {
+            e_fork = la_event(*dev, ev++);
+            e_join = la_event(*dev, ev++);
+            if (e_fork == nullptr || e_join == nullptr) return GPK_ERR_LAUNCH;
+            if (hipEventRecord(e_fork, stream) != hipSuccess) return GPK_ERR_LAUNCH;
+        } else {
+            st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, stream);
+            if (st) return st;
+        }
+        // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
+        // ~0.3 ms for those, which the main stream would otherwise spend idle
+        if (k2 < n) {
+            const T* P2 = A + k2 * ld + k0;
+            GpkSeg<T> seg[2];
+            const int so = g_la_strip_last ? 1 : 0;   // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
+            seg[so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
+            seg[1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
+            st = gpk_gemm_persist_launch<T>(seg, 2, T(-1), ctrl, overlap ? 1 : 0, stream);
+            if (st) return st;
+        }
+        if (overlap) {
+            if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+            st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux);
+            if (st) return st;
+            if (hipEventRecord(e_join, dev->aux) != hipSuccess) return GPK_ERR_LAUNCH;
+            if (hipStreamWaitEvent(stream, e_join, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+        }
+    }
+    return GPK_OK;
+}
+
+template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t);
+template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t);
+
+template <typename T>
+int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
+                     int* info, int nbo, hipStream_t stream) {
+    return potrf_plain<T>(A, n, ld, batch, bstride, dinv, info, nbo, 0, stream);
 }
 
 template int gpk_potrf_launch<double>(double*, int64_t, int64_t, int64_t, int64_t, double*, int*,

@@ -422,6 +422,193 @@ static void test_potrf() {
     test_potrf_case<T>(512, 64, 128, 2, 0, 128);
 }
 
+
+// ----------------------------------------------------------------------------
+// persistent two-problem update + look-ahead Cholesky
+// ----------------------------------------------------------------------------
+template <typename T>
+static void test_update2_case(int M0, int N0, int M1, int K, int reserve, int pad) {
+    // segment 0: rectangular, OUT OF PLACE (cin != c); segment 1: square, lower tiles only, in place
+    const int64_t lda0 = K + pad, ldb0 = K + pad, ldcin = N0 + pad, ldc0 = N0 + 2 * pad, lda1 = K + pad, ldc1 = M1 + pad;
+    auto A0 = randv<T>((size_t)M0 * lda0), B0 = randv<T>((size_t)N0 * ldb0), Cin = randv<T>((size_t)M0 * ldcin);
+    auto A1 = randv<T>((size_t)M1 * lda1), C1 = randv<T>((size_t)M1 * ldc1);
+    std::vector<T> C0((size_t)M0 * ldc0, (T)7);
+    Dev<T> dA0(A0.size()), dB0(B0.size()), dCin(Cin.size()), dC0(C0.size()), dA1(A1.size()), dC1(C1.size());
+    Dev<unsigned> ctrl(32);
+    dA0.up(A0); dB0.up(B0); dCin.up(Cin); dC0.up(C0); dA1.up(A1); dC1.up(C1);
+    gpk_update_t u[2];
+    u[0] = gpk_update_t{M0, N0, K, dA0.p, lda0, dB0.p, ldb0, dCin.p, ldcin, dC0.p, ldc0, 0};
+    u[1] = gpk_update_t{M1, M1, K, dA1.p, lda1, dA1.p, lda1, dC1.p, ldc1, dC1.p, ldc1, 1};
+    const int st = gpk_gemm_update2(DT<T>::v, u, 2, -1.0, ctrl.p, reserve, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto g0 = dC0.down(), g1 = dC1.down();
+    double num = 0, den = 0;
+    bool ok = true;
+    for (int i = 0; i < M0; ++i)
+        for (int j = 0; j < N0; ++j) {
+            double r = Cin[(size_t)i * ldcin + j];
+            for (int k = 0; k < K; ++k) r -= (double)A0[(size_t)i * lda0 + k] * (double)B0[(size_t)j * ldb0 + k];
+            const double g = g0[(size_t)i * ldc0 + j];
+            if (!std::isfinite(g)) ok = false;
+            num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
+        }
+    const int ts = 64;   // tiles strictly above the diagonal (at the finest tile size) must be untouched
+    for (int i = 0; i < M1; ++i)
+        for (int j = 0; j < M1; ++j) {
+            double r = C1[(size_t)i * ldc1 + j];
+            const double g = g1[(size_t)i * ldc1 + j];
+            if (j <= i) {
+                for (int k = 0; k < K; ++k) r -= (double)A1[(size_t)i * lda1 + k] * (double)A1[(size_t)j * lda1 + k];
+            } else if (j / 128 > i / 128 || (j / ts > i / ts && g == r)) {
+                // untouched (above the tile diagonal for whichever tile size ran)
+            } else {
+                for (int k = 0; k < K; ++k) r -= (double)A1[(size_t)i * lda1 + k] * (double)A1[(size_t)j * lda1 + k];
+            }
+            if (!std::isfinite(g)) ok = false;
+            num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
+        }
+    char nm[160];
+    snprintf(nm, sizeof nm, "update2_%s %dx%d+%d^2 k%d reserve%d pad%d st%d", DT<T>::name(), M0, N0, M1, K, reserve, pad, st);
+    report(nm, (st || !ok) ? INFINITY : num / den, DT<T>::eps * 100);
+}
+
+template <typename T>
+static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_t tail_rows = 0) {
+    const int64_t ld = n + (n % 2);
+    auto A = make_spd<T>(n, 1, ld);
+    const int64_t de = gpk_dinv_elems(n);
+    const int nblk = (n + nb - 1) / nb;
+    Dev<T> dA(A.size()), dRef(A.size()), dinv((size_t)de), dinv2((size_t)de), dbig((size_t)nblk * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+    Dev<int> info(1), info2(1);
+    dA.up(A); dRef.up(A); info.zero(); info2.zero();
+    gpk_tune(7, mode); gpk_tune(6, min_rows); gpk_tune(9, tail_rows);
+    const int st = gpk_potrf_la(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
+    gpk_tune(7, 1); gpk_tune(6, 2048); gpk_tune(9, 5120);
+    const int st2 = gpk_potrf(DT<T>::v, dRef.p, n, ld, 0, 1, dinv2.p, info2.p, 0, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto L = dA.down(), R = dRef.down();
+    double num = 0, den = 0;
+    bool finite = true;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            const double g = L[(size_t)i * ld + j], r = R[(size_t)i * ld + j];
+            if (!std::isfinite(g)) finite = false;
+            num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
+        }
+    char nm[160];
+    snprintf(nm, sizeof nm, "potrf_la_%s n%d nb%d mode%d minrows%lld tail%lld st%d/%d info%d", DT<T>::name(), n, nb, mode, (long long)min_rows, (long long)tail_rows, st, st2, info.down()[0]);
+    report(nm, (st || st2 || !finite || info.down()[0]) ? INFINITY : num / den, DT<T>::eps * 100);
+    // upper triangle untouched
+    {
+        double worst = 0;
+        for (int i = 0; i < n; ++i) for (int j = (i / 128 + 1) * 128; j < n; ++j) worst = std::max(worst, std::fabs((double)L[(size_t)i * ld + j] - (double)A[(size_t)i * ld + j]));
+        snprintf(nm, sizeof nm, "potrf_la_%s n%d above the 128-block diagonal untouched", DT<T>::name(), n);
+        report(nm, worst, 0.0);
+    }
+    // merged inverses: W_j L_jj = I on the first and the last block; 128-block inverses equal the plain path's
+    {
+        auto W = dbig.down();
+        double worst = 0;
+        for (int blk : {0, nblk - 1}) {
+            const int o = blk * nb, nv = std::min(nb, n - o);
+            for (int i = 0; i < nv; i += 7)
+                for (int j = 0; j < nv; ++j) {
+                    double sacc = 0;
+                    for (int k = j; k <= i; ++k) sacc += (double)W[(size_t)blk * nb * nb + (size_t)i * nb + k] * (double)R[(size_t)(o + k) * ld + o + j];
+                    worst = std::max(worst, std::fabs(sacc - (i == j ? 1.0 : 0.0)));
+                }
+        }
+        snprintf(nm, sizeof nm, "potrf_la_%s n%d nb%d dinv_nb", DT<T>::name(), n, nb);
+        report(nm, worst, DT<T>::eps * 1000);
+        auto d1 = dinv.down(), d2 = dinv2.down();
+        double nu = 0, dn = 0;
+        for (size_t i = 0; i < d1.size(); ++i) { nu = std::max(nu, std::fabs((double)d1[i] - (double)d2[i])); dn = std::max(dn, std::fabs((double)d2[i])); }
+        snprintf(nm, sizeof nm, "potrf_la_%s n%d nb%d dinv128", DT<T>::name(), n, nb);
+        report(nm, nu / dn, DT<T>::eps * 1000);
+    }
+}
+
+template <typename T>
+static void test_lookahead() {
+    for (int pass = 0; pass < 2; ++pass) {      // 128-tile kernels forced, then 64-tile kernels forced
+        gpk_tune(1, pass == 0 ? 0 : ((int64_t)1 << 40));
+        test_update2_case<T>(300, 200, 260, 70, 0, 0);
+        test_update2_case<T>(384, 128, 512, 64, 1, 0);
+        test_update2_case<T>(1000, 256, 1100, 128, 1, 2);
+        test_update2_case<T>(129, 1, 5, 3, 1, 1);
+    }
+    gpk_tune(1, 1024);
+    test_potrf_la_case<T>(700, 256, 1, 0);
+    test_potrf_la_case<T>(1024, 256, 1, 0);
+    test_potrf_la_case<T>(1200, 512, 1, 0);
+    test_potrf_la_case<T>(1664, 256, 0, 0);
+    test_potrf_la_case<T>(3000, 512, 1, 0);
+    test_potrf_la_case<T>(3000, 1024, 1, 1024);
+    test_potrf_la_case<T>(4096, 1024, 1, 0);
+    test_potrf_la_case<T>(5000, 512, 1, 2048);
+    test_potrf_la_case<T>(10, 256, 1, 0, 5120);        // all plain + merge
+    test_potrf_la_case<T>(1200, 512, 1, 0, 5120);
+    test_potrf_la_case<T>(1664, 256, 1, 0, 700);       // look-ahead, then a plain tail
+    test_potrf_la_case<T>(3000, 512, 1, 0, 1500);
+    test_potrf_la_case<T>(4096, 1024, 1, 0, 2048);
+    test_potrf_la_case<T>(5000, 1024, 1, 1024, 1000);
+    // a non-positive-definite matrix is reported with the global pivot order
+    {
+        const int n = 1500, nb = 512, bad = 1111;
+        const int64_t ld = n;
+        auto A = make_spd<T>(n, 1, ld);
+        A[(size_t)bad * ld + bad] = (T)(-5);
+        Dev<T> dA(A.size()), dinv((size_t)gpk_dinv_elems(n)), dbig((size_t)3 * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+        Dev<int> info(1);
+        dA.up(A); info.zero();
+        for (int64_t tail : {0, 700}) {
+            dA.up(A); info.zero();
+            gpk_tune(6, 0); gpk_tune(9, tail);
+            const int st = gpk_potrf_la(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
+            gpk_tune(6, 2048); gpk_tune(9, 5120);
+            HIPCHK(hipDeviceSynchronize());
+            char nm[160];
+            snprintf(nm, sizeof nm, "potrf_la_%s not PD (tail %lld): info %d (expect %d) st%d", DT<T>::name(), (long long)tail, info.down()[0], bad + 1, st);
+            report(nm, (st == 0 && info.down()[0] == bad + 1) ? 0.0 : INFINITY, 0.0);
+        }
+    }
+}
+
+// where do workgroups land?  (XCC id, SE/SH/CU fields of HW_ID) of a 2048-workgroup grid
+__global__ void census_kernel(unsigned* out) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw; }
+    // stay a little so that the grid spreads over every CU
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 2000) {}
+}
+static void census() {
+    const int nb = 2048;
+    Dev<unsigned> out(2 * nb);
+    hipLaunchKernelGGL(census_kernel, dim3(nb), dim3(256), 0, 0, out.p);
+    HIPCHK(hipDeviceSynchronize());
+    auto h = out.down();
+    std::vector<int> cnt(8 * 256, 0);
+    int b2x = 0;
+    for (int b = 0; b < nb; ++b) {
+        const unsigned xcc = h[2 * b] & 0xf, key = (h[2 * b + 1] >> 8) & 0xff;
+        if ((int)(xcc & 7) == b % 8) ++b2x;
+        cnt[(xcc & 7) * 256 + key]++;
+    }
+    printf("CENSUS block b on XCC b%%8 for %d of %d blocks; raw xcc/hw_id of blocks 0..7:", b2x, nb);
+    for (int b = 0; b < 8; ++b) printf(" %x/%08x", h[2 * b], h[2 * b + 1]);
+    printf("\n");
+    for (int x = 0; x < 8; ++x) {
+        int cus = 0;
+        printf("CENSUS xcc %d keys(se.sh.cu:count):", x);
+        for (int k = 0; k < 256; ++k)
+            if (cnt[x * 256 + k]) { ++cus; printf(" %d.%d.%d:%d", (k >> 5) & 7, (k >> 4) & 1, k & 15, cnt[x * 256 + k]); }
+        printf("  => %d distinct CUs\n", cus);
+    }
+}
+
 // ----------------------------------------------------------------------------
 // reductions / misc
 // ----------------------------------------------------------------------------
@@ -650,6 +837,112 @@ static void perf() {
     }
 }
 
+
+// look-ahead Cholesky and persistent update, timed:  --perf-la
+template <typename T>
+static void perf_la(int nmax) {
+    Timer tm;
+    const double peak = sizeof(T) == 8 ? 78.6 : 157.3;
+    // trailing-update shape of the first outer step at N = 16384, nbo = 1024
+    {
+        const int n = std::min(15360, nmax - 1024), k = 1024;
+        Dev<T> P((size_t)(n + 1024) * k), C((size_t)n * n), Tn((size_t)n * 1024), Cs((size_t)n * 1024);
+        Dev<unsigned> ctrl(32);
+        P.up(randv<T>((size_t)(n + 1024) * k, 0.01)); C.zero(); Cs.zero();
+        for (int rep = 0; rep < 2; ++rep) {
+            tm.start();
+            gpk_gemm(DT<T>::v, 1, 1, n, n, k, -1.0, P.p, k, 0, P.p, k, 0, 1.0, C.p, n, 0, 1, 1, nullptr);
+            float ms = tm.stop();
+            if (rep) printf("PERFLA trail_%s n=%d k=%d plain kernel        %.3f ms  %.2f TFLOP/s (%.1f%%)\n", DT<T>::name(), n, k, ms, 1.0 * n * (double)n * k / ms * 1e-9, 100.0 * n * (double)n * k / ms * 1e-9 / peak);
+        }
+        for (int reserve = 0; reserve < 2; ++reserve)
+            for (int rep = 0; rep < 2; ++rep) {
+                gpk_update_t u{n, n, k, P.p, k, P.p, k, C.p, n, C.p, n, 1};
+                tm.start();
+                gpk_gemm_update2(DT<T>::v, &u, 1, -1.0, ctrl.p, reserve, nullptr);
+                float ms = tm.stop();
+                if (rep) printf("PERFLA trail_%s n=%d k=%d persistent reserve=%d %.3f ms  %.2f TFLOP/s (%.1f%%)\n", DT<T>::name(), n, k, reserve, ms, 1.0 * n * (double)n * k / ms * 1e-9, 100.0 * n * (double)n * k / ms * 1e-9 / peak);
+            }
+        for (int rep = 0; rep < 2; ++rep) {   // strip (out of place) + triangle in one launch
+            gpk_update_t u[2];
+            u[0] = gpk_update_t{n, 1024, k, P.p + (size_t)1024 * k, k, P.p, k, Cs.p, 1024, Tn.p, 1024, 0};
+            u[1] = gpk_update_t{n, n, k, P.p + (size_t)1024 * k, k, P.p + (size_t)1024 * k, k, C.p, n, C.p, n, 1};
+            tm.start();
+            gpk_gemm_update2(DT<T>::v, u, 2, -1.0, ctrl.p, 1, nullptr);
+            float ms = tm.stop();
+            const double fl = 1.0 * n * (double)n * k + 2.0 * n * 1024.0 * k;
+            if (rep) printf("PERFLA trail_%s n=%d k=%d persistent strip+triangle reserve=1 %.3f ms  %.2f TFLOP/s (%.1f%%)\n", DT<T>::name(), n, k, ms, fl / ms * 1e-9, 100 * fl / ms * 1e-9 / peak);
+        }
+    }
+    for (int n : {2048, 4096, 8192, 16384}) {
+        if (n > nmax) continue;
+        const int d = 8;
+        auto hx = randv<T>((size_t)n * d);
+        Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n));
+        Dev<int> info(1);
+        X.up(hx);
+        int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+        for (int rep = 0; rep < 2; ++rep) {
+            info.zero();
+            gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+            tm.start();
+            gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, 0, nullptr);
+            const float ms = tm.stop();
+            if (rep) printf("PERFLA potrf_%s n=%d plain            %.3f ms  %.2f TFLOP/s (%.1f%%)\n", DT<T>::name(), n, ms, (double)n * n * n / 3.0 / ms * 1e-9, 100 * (double)n * n * n / 3.0 / ms * 1e-9 / peak);
+        }
+        for (int nb : {512, 1024}) {
+            Dev<T> dbig((size_t)((n + nb - 1) / nb) * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+            for (int cfg = 0; cfg < 4; ++cfg) {
+                const int mode = cfg == 0 ? 0 : 1;
+                const int64_t minrows = cfg == 1 ? 0 : (cfg == 2 ? 2048 : 4096);
+                gpk_tune(7, mode); gpk_tune(6, minrows);
+                float best = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    info.zero();
+                    gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+                    tm.start();
+                    gpk_potrf_la(DT<T>::v, K.p, n, n, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
+                    const float ms = tm.stop();
+                    if (rep) best = std::min(best, ms);
+                }
+                printf("PERFLA potrf_%s n=%d look-ahead nb=%d mode=%d minrows=%lld  %.3f ms  %.2f TFLOP/s (%.1f%%) info=%d\n", DT<T>::name(), n, nb, mode, (long long)minrows, best,
+                       (double)n * n * n / 3.0 / best * 1e-9, 100 * (double)n * n * n / 3.0 / best * 1e-9 / peak, info.down()[0]);
+            }
+            gpk_tune(7, 1); gpk_tune(6, 2048);
+        }
+    }
+}
+
+
+// one look-ahead factorisation on an explicit stream, for rocprofv3 traces:  --la-one f64|f32 N NB MODE MINROWS
+template <typename T>
+static void la_one(int n, int nb, int mode, int64_t minrows, int reps, int ldpad = 0) {
+    const int64_t ld = n + ldpad;
+    const int d = 8;
+    auto hx = randv<T>((size_t)n * d);
+    Dev<T> X(hx.size()), K((size_t)n * ld), dinv(gpk_dinv_elems(n));
+    Dev<T> dbig((size_t)((n + nb - 1) / nb) * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+    Dev<int> info(1);
+    X.up(hx);
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    gpk_tune(7, mode); gpk_tune(6, minrows);
+    for (int rep = 0; rep < reps; ++rep) {
+        HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st));
+        gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, ld, 0, 1, 1, 1, 0.1, nullptr, 0, 0, st);
+        hipEventRecord(a, st);
+        if (mode >= 0) gpk_potrf_la(DT<T>::v, K.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, st);
+        else gpk_potrf(DT<T>::v, K.p, n, ld, 0, 1, dinv.p, info.p, 0, st);
+        hipEventRecord(b, st);
+        HIPCHK(hipStreamSynchronize(st));
+        float ms; hipEventElapsedTime(&ms, a, b);
+        printf("LAONE ldpad=%d potrf_%s n=%d nb=%d mode=%d minrows=%lld  %.3f ms  %.2f TFLOP/s info=%d\n", ldpad, DT<T>::name(), n, nb, mode, (long long)minrows, ms, (double)n * n * n / 3.0 / ms * 1e-9, info.down()[0]);
+    }
+}
+
 // one problem, for rocprofv3: kmat + potrf (+ trsv, merge, trsm) at order n
 template <typename T>
 static void profile_one(int n, int nbo, int reps) {
@@ -679,16 +972,17 @@ static void profile_one(int n, int nbo, int reps) {
 
 // one GEMM shape, timed alone:  --gemm f64|f32 M N K [lower]   (k-major operands, C = C - A B^T)
 template <typename T>
-static void gemm_one(int M, int N, int K, int flags, int reps) {
+static void gemm_one(int M, int N, int K, int flags, int reps, int64_t lda = -1) {
+    if (lda < 0) lda = K;
     Dev<T> A((size_t)M * K), B((size_t)N * K), C((size_t)M * N);
     A.up(randv<T>((size_t)M * K, 0.01)); B.up(randv<T>((size_t)N * K, 0.01)); C.zero();
     Timer tm;
     for (int rep = 0; rep < reps; ++rep) {
         tm.start();
-        gpk_gemm(DT<T>::v, 1, 1, M, N, K, -1.0, A.p, K, 0, B.p, K, 0, 1.0, C.p, N, 0, 1, flags, nullptr);
+        gpk_gemm(DT<T>::v, 1, 1, M, N, K, -1.0, A.p, lda, 0, B.p, K, 0, (flags & 32) ? 0.0 : 1.0, C.p, N, 0, 1, flags & 15, nullptr);
         const float ms = tm.stop();
-        const double fl = ((flags & 1) ? 1.0 : 2.0) * M * (double)N * K;
-        printf("GEMM %s M=%d N=%d K=%d flags=%d  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), M, N, K, flags, ms, fl / ms * 1e-9);
+        const double fl = ((flags & 9) ? 1.0 : 2.0) * M * (double)N * K;
+        printf("GEMM %s M=%d N=%d K=%d flags=%d lda=%lld  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), M, N, K, flags, (long long)lda, ms, fl / ms * 1e-9);
     }
 }
 
@@ -711,7 +1005,6 @@ static void rsq_precision() {
     printf("RSQ_F64 max relative error of v_rsq_f64: %.3e (= 2^%.1f)\n", worst, std::log2(worst));
 }
 
-extern "C" void gpk_debug_set(int key, int64_t value);
 
 // pure-register MFMA ceiling: every wave runs `iters` x 16 independent v_mfma (no memory)
 __global__ __launch_bounds__(256) void mfma_peak64(double* out, int iters, long long* clk) {
@@ -783,6 +1076,128 @@ __global__ __launch_bounds__(256) void lds_hog(double* out, int iters) {
     out[threadIdx.x] = acc;
 }
 
+
+// ---------------------------------------------------------------------------
+// experiment: where and when does the dispatcher place a one-workgroup kernel of a second stream while a
+// resident grid holds every CU but a few?   --dispatch
+// ---------------------------------------------------------------------------
+struct HogArgs { unsigned keys[8]; unsigned* ctrl; long long* t_start; long long spin_ticks; int mode; };   // mode 0: stay, 1: first arrival per XCC leaves, 2: static keys leave
+__global__ __launch_bounds__(256, 2) void hog_kernel(HogArgs p) {
+    __shared__ char pad[72 * 1024];
+    __shared__ int leave;
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        xcc &= 7u;
+        const unsigned key = ((hw >> 8) & 0xffu) + 1u;
+        int lv = 0;
+        if (p.mode == 1) { const unsigned old = atomicCAS(&p.ctrl[1 + xcc], 0u, key); lv = (old == 0u || old == key); }
+        if (p.mode == 2) lv = (p.keys[xcc] == key);
+        if (lv) atomicAdd(&p.ctrl[9 + xcc], 1u);
+        if (blockIdx.x == 0) *p.t_start = wall_clock64();
+        leave = lv;
+        pad[threadIdx.x] = (char)lv;
+    }
+    __syncthreads();
+    if (leave) return;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < p.spin_ticks) {}
+    if (pad[1] == 77) p.ctrl[31] = 1;
+}
+__global__ __launch_bounds__(256, 1) void probe_kernel(unsigned long long* out, int idx) {
+    extern __shared__ char big[];
+    if (threadIdx.x == 0) {
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        out[2 * (idx * gridDim.x + blockIdx.x)] = ((unsigned long long)(xcc & 7u) << 32) | ((hw >> 8) & 0xffu);
+        out[2 * (idx * gridDim.x + blockIdx.x) + 1] = (unsigned long long)wall_clock64();
+        big[0] = 1;
+    }
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < 2000) {}    // 20 us
+}
+static void masked_census(const char* nm, const uint32_t* mask) {
+    hipStream_t st;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, 8, mask);
+    if (e != hipSuccess) { printf("MASK %s: create failed: %s\n", nm, hipGetErrorString(e)); return; }
+    const int nb = 256;
+    Dev<unsigned> out(2 * nb);
+    hipLaunchKernelGGL(census_kernel, dim3(nb), dim3(256), 0, st, out.p);
+    HIPCHK(hipStreamSynchronize(st));
+    auto h = out.down();
+    std::vector<int> cnt(8 * 256, 0);
+    for (int b = 0; b < nb; ++b) cnt[(h[2 * b] & 7) * 256 + ((h[2 * b + 1] >> 8) & 0xff)]++;
+    printf("MASK %-28s ->", nm);
+    for (int x = 0; x < 8; ++x) for (int k = 0; k < 256; ++k) if (cnt[x * 256 + k]) printf(" x%d:%d.%d(%d)", x, (k >> 5) & 7, k & 15, cnt[x * 256 + k]);
+    printf("\n");
+    hipStreamDestroy(st);
+}
+static void dispatch_experiment() {
+    HIPCHK(hipFuncSetAttribute((const void*)probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 134144));
+    // 1. which CUs does a CU-mask bit enable?
+    { uint32_t m[8] = {1, 0, 0, 0, 0, 0, 0, 0}; masked_census("bit 0", m); }
+    { uint32_t m[8] = {2, 0, 0, 0, 0, 0, 0, 0}; masked_census("bit 1", m); }
+    { uint32_t m[8] = {0x100, 0, 0, 0, 0, 0, 0, 0}; masked_census("bit 8", m); }
+    { uint32_t m[8] = {0, 1, 0, 0, 0, 0, 0, 0}; masked_census("bit 32", m); }
+    { uint32_t m[8] = {0xff, 0, 0, 0, 0, 0, 0, 0}; masked_census("bits 0..7", m); }
+    { uint32_t m[8] = {1, 1, 1, 1, 1, 1, 1, 1}; masked_census("bit 0 of every word", m); }
+    { uint32_t m[8] = {0x01010101, 0x01010101, 0, 0, 0, 0, 0, 0}; masked_census("bits 0,8,..,56", m); }
+    { uint32_t m[8] = {0x11111111, 0, 0, 0, 0, 0, 0, 0}; masked_census("bits 0,4,..,28", m); }
+    // 2. probes beside a resident grid
+    hipStream_t s_main, s_aux, s_mask;
+    HIPCHK(hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s_aux, hipStreamNonBlocking));
+    uint32_t mk[8] = {0xff, 0, 0, 0, 0, 0, 0, 0};
+    const bool have_mask = hipExtStreamCreateWithCUMask(&s_mask, 8, mk) == hipSuccess;
+    // keys the masked stream can reach
+    unsigned keys[8] = {0};
+    if (have_mask) {
+        Dev<unsigned> out(2 * 256);
+        hipLaunchKernelGGL(census_kernel, dim3(256), dim3(256), 0, s_mask, out.p);
+        HIPCHK(hipStreamSynchronize(s_mask));
+        auto h = out.down();
+        for (int b = 0; b < 256; ++b) keys[h[2 * b] & 7] = ((h[2 * b + 1] >> 8) & 0xff) + 1;
+        printf("DISPATCH masked stream keys:");
+        for (int x = 0; x < 8; ++x) printf(" x%d:%d.%d", x, ((keys[x] - 1) >> 5) & 7, (keys[x] - 1) & 15);
+        printf("\n");
+    }
+    Dev<unsigned> ctrl(32);
+    Dev<long long> tstart(1);
+    const int nprobe = 12;
+    for (int cfg = 0; cfg < 6; ++cfg) {
+        // cfg 0: hog stays everywhere, probes unmasked; 1: first-arrival reserve, probes unmasked; 2: static keys, probes unmasked;
+        // 3: static keys, probes on the masked stream; 4: static keys, 64-workgroup small probes (40 KB) unmasked; 5: the same, masked
+        const int mode = cfg == 0 ? 0 : (cfg == 1 ? 1 : 2);
+        hipStream_t sp = (cfg == 3 || cfg == 5) ? s_mask : s_aux;
+        if ((cfg == 3 || cfg == 5) && !have_mask) continue;
+        const int pgrid = cfg >= 4 ? 64 : 1;
+        const size_t plds = cfg >= 4 ? 40960 : 134144;
+        Dev<unsigned long long> out(2 * nprobe * pgrid);
+        ctrl.zero();
+        HogArgs ha;
+        for (int x = 0; x < 8; ++x) ha.keys[x] = keys[x];
+        ha.ctrl = ctrl.p; ha.t_start = tstart.p; ha.spin_ticks = 200000; ha.mode = mode;   // 2 ms
+        HIPCHK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(hog_kernel, dim3(512), dim3(256), 0, s_main, ha);
+        for (int i = 0; i < nprobe; ++i) hipLaunchKernelGGL(probe_kernel, dim3(pgrid), dim3(256), plds, sp, out.p, i);
+        HIPCHK(hipDeviceSynchronize());
+        auto h = out.down();
+        auto c = ctrl.down();
+        const long long t0 = tstart.down()[0];
+        int left = 0; for (int x = 0; x < 8; ++x) left += c[9 + x];
+        printf("DISPATCH cfg %d (hog mode %d, %d workgroups left; probes: grid %d, %zu B LDS, %s stream):", cfg, mode, left, pgrid, plds, (sp == s_mask) ? "masked" : "plain");
+        for (int i = 0; i < nprobe; ++i) {
+            long long tmin = (long long)h[2 * (i * pgrid) + 1], tmax = tmin;
+            for (int b = 0; b < pgrid; ++b) { tmin = std::min(tmin, (long long)h[2 * (i * pgrid + b) + 1]); tmax = std::max(tmax, (long long)h[2 * (i * pgrid + b) + 1]); }
+            const unsigned long long loc = h[2 * (i * pgrid)];
+            printf(" [%lld..%lld us @x%llu:%llu.%llu]", (tmin - t0) / 100, (tmax - t0) / 100, loc >> 32, ((loc & 0xff) >> 5) & 7, loc & 15);
+        }
+        printf("\n");
+    }
+}
+
 // experiment: CU-masked streams (does a reserved CU let a small kernel overlap a big GEMM?)
 static void cumask_experiment() {
     const int n = 8192;
@@ -843,15 +1258,15 @@ static void cumask_experiment() {
             hipStream_t st;
             if (hipExtStreamCreateWithCUMask(&st, 8, w) == hipSuccess) {
                 time_gemm(st, m.nm);
-                gpk_debug_set(2, 1 << 30);
+                gpk_tune(2, 1 << 30);
                 time_gemm(st, (std::string(m.nm) + " noswz").c_str());
-                gpk_debug_set(2, 1024);
+                gpk_tune(2, 1024);
                 hipStreamDestroy(st);
             }
         }
-        gpk_debug_set(2, 1 << 30);
+        gpk_tune(2, 1 << 30);
         time_gemm(s_def, "default noswz");
-        gpk_debug_set(2, 1024);
+        gpk_tune(2, 1024);
     }
     overlap(s_def, "default");
     if (e1 == hipSuccess) overlap(s_m8, "mask-8");
@@ -908,15 +1323,14 @@ static void cumask_experiment() {
     if (e1 == hipSuccess) overlap_diag(s_m8, "mask-8", true);
 }
 
-extern "C" void gpk_debug_diag_prof(long long* dev_buf);
 template <typename T>
 static void diag_phase_profile(int n) {
     const int nblk = (n + 127) / 128;
     Dev<long long> prof((size_t)nblk * 16);
     prof.zero();
-    gpk_debug_diag_prof(prof.p);
+    gpk_tune_diag_prof(prof.p);
     profile_one<T>(n, 0, 1);
-    gpk_debug_diag_prof(nullptr);
+    gpk_tune_diag_prof(nullptr);
     auto h = prof.down();
     for (int blk : {0, nblk / 2, nblk - 1}) {
         const long long* q = &h[(size_t)blk * 16];
@@ -928,7 +1342,7 @@ static void diag_phase_profile(int n) {
 int main(int argc, char** argv) {
     bool do_perf = false, only_perf = false;
     for (int i = 1; i + 2 < argc; ++i)     // --set KEY VALUE: tuning knobs (gpk_debug_set)
-        if (!strcmp(argv[i], "--set")) gpk_debug_set(atoi(argv[i + 1]), atoll(argv[i + 2]));
+        if (!strcmp(argv[i], "--set")) gpk_tune(atoi(argv[i + 1]), atoll(argv[i + 2]));
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--batched") && i + 1 < argc) {   // 512 x 2048 f32 potrf with outer block NBO
             const int nbo = atoi(argv[i + 1]);
@@ -950,6 +1364,7 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (!strcmp(argv[i], "--cumask")) { cumask_experiment(); return 0; }
+        if (!strcmp(argv[i], "--dispatch")) { dispatch_experiment(); return 0; }
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
             rsq_precision();
@@ -965,7 +1380,27 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--gemm") && i + 4 < argc) {      // --gemm f64|f32 M N K [flags]
             const int M = atoi(argv[i + 2]), N = atoi(argv[i + 3]), K = atoi(argv[i + 4]);
             const int flags = (i + 5 < argc) ? atoi(argv[i + 5]) : 0;
-            if (!strcmp(argv[i + 1], "f64")) gemm_one<double>(M, N, K, flags, 4); else gemm_one<float>(M, N, K, flags, 4);
+            const int64_t lda = (i + 6 < argc) ? atoll(argv[i + 6]) : -1;
+            if (!strcmp(argv[i + 1], "f64")) gemm_one<double>(M, N, K, flags, 4, lda); else gemm_one<float>(M, N, K, flags, 4, lda);
+            return 0;
+        }
+        if (!strcmp(argv[i], "--census")) { census(); return 0; }
+        if (!strcmp(argv[i], "--lookahead")) {                 // only the look-ahead / persistent-update checks
+            test_lookahead<double>(); test_lookahead<float>();
+            printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
+            return g_fail ? 1 : 0;
+        }
+        if (!strcmp(argv[i], "--la-one") && i + 5 < argc) {      // --la-one f64|f32 N NB MODE(-1 = plain potrf) MINROWS [REPS]
+            const int n = atoi(argv[i + 2]), nb = atoi(argv[i + 3]), mode = atoi(argv[i + 4]);
+            const int64_t mr = atoll(argv[i + 5]);
+            const int reps = (i + 6 < argc) ? atoi(argv[i + 6]) : 3;
+            const int ldpad = (i + 7 < argc) ? atoi(argv[i + 7]) : 0;
+            if (!strcmp(argv[i + 1], "f64")) la_one<double>(n, nb, mode, mr, reps, ldpad); else la_one<float>(n, nb, mode, mr, reps, ldpad);
+            return 0;
+        }
+        if (!strcmp(argv[i], "--perf-la")) {                   // --perf-la [NMAX]
+            const int nmax = (i + 1 < argc && atoi(argv[i + 1]) > 0) ? atoi(argv[i + 1]) : 16384;
+            perf_la<double>(nmax); perf_la<float>(nmax);
             return 0;
         }
         if (!strcmp(argv[i], "--perf")) do_perf = true;
@@ -976,19 +1411,20 @@ int main(int argc, char** argv) {
     printf("device: %s  arch=%s  CUs=%d  clock=%d MHz  gpk_version=%d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000, gpk_version());
     if (!only_perf) {
         test_probe<double>(); test_probe<float>();
-        gpk_debug_set(1, 0);                 // force the 128x128-tile kernels
+        gpk_tune(1, 0);                 // force the 128x128-tile kernels
         test_gemm<double>(); test_gemm<float>();
-        gpk_debug_set(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
+        gpk_tune(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
         test_gemm<double>(); test_gemm<float>();
-        gpk_debug_set(1, 1024);              // library default
-        gpk_debug_set(2, 64);                // the (default-off) XCD super-tile order
+        gpk_tune(1, 1024);              // library default
+        gpk_tune(2, 64);                // the (default-off) XCD super-tile order
         test_gemm<double>(); test_gemm<float>();
-        gpk_debug_set(2, (int64_t)1 << 30);
-        gpk_debug_set(4, 1);                 // the (default-off) row-pair triangular order
+        gpk_tune(2, (int64_t)1 << 30);
+        gpk_tune(4, 1);                 // the (default-off) row-pair triangular order
         test_gemm<double>(); test_gemm<float>();
-        gpk_debug_set(4, (int64_t)1 << 30);
+        gpk_tune(4, (int64_t)1 << 30);
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
+        test_lookahead<double>(); test_lookahead<float>();
         test_misc<double>(); test_misc<float>();
         test_vjp_dense<double>(); test_vjp_dense<float>();
         printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);

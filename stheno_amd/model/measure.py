@@ -132,10 +132,15 @@ class Measure:
                 self.kernels[p1] + self.kernels[p2] + self.kernels[p1, p2] + self.kernels[p2, p1],
                 lambda j: wself().kernels[i1, j] + wself().kernels[i2, j],
             )
+        if torch.is_tensor(other) and other.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("a learnable constant added to a process would be detached here: pass it as the mean")
         wself, pid = weakref.ref(self), id(p)
         return self._update(p_sum, self.means[p] + other, self.kernels[p], lambda j: wself().kernels[pid, j])
 
     def mul(self, p_mul, p, other):
+        if torch.is_tensor(other) and other.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("a learnable scale of a process would be detached here: put it on the kernel "
+                                      "(`GP(c**2 * EQ())`), where variances are differentiable")
         v = float(other)
         wself, pid = weakref.ref(self), id(p)
         return self._update(p_mul, self.means[p] * v, self.kernels[p] * v**2, lambda j: wself().kernels[pid, j] * v)
@@ -171,12 +176,12 @@ class Measure:
         return self.condition(*args) if isinstance(args, tuple) and not isinstance(args[0], FDD) else self.condition(args)
 
     # -- sampling / logpdf (measure.py:425-489) -----------------------------------
-    def sample(self, *args, generator=None):
+    def sample(self, *args, generator=None, xi=None):
         n = 1
         if args and isinstance(args[0], int):
             n, args = args[0], args[1:]
         fdd = combine(*args)
-        sample = self(fdd).sample(n, generator=generator)
+        sample = self(fdd).sample(n, generator=generator, xi=xi)
         if len(args) == 1:
             return sample
         # several FDDs are sampled jointly and handed back one by one (measure.py:440-447)

@@ -47,6 +47,13 @@ class RandomVector(Random):
     """A random vector."""
 
 
+def _x_requires_grad(x):
+    """Whether (any component of) an input specification carries gradients."""
+    if torch.is_tensor(x):
+        return x.requires_grad
+    return any(_x_requires_grad(q) for _, q in getattr(x, "parts", ()))
+
+
 def _is_zero(x):
     return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 0
 
@@ -163,11 +170,6 @@ class Normal(RandomVector):
     def dim(self):
         return self.var.shape[-1]
 
-    @property
-    def m2(self):
-        m = self.mean
-        return self.var.dense() + m @ m.transpose(-1, -2)
-
     # -- marginals (random.py:204-238) -----------------------------------------
     def marginals(self):
         """Marginal means and variances (the covariance is not formed when a
@@ -198,9 +200,6 @@ class Normal(RandomVector):
         error = 1.96 * torch.sqrt(var)
         return mean, mean - error, mean + error
 
-    def diagonalise(self):
-        return Normal(self.mean, Diagonal(self.var_diag))
-
     # -- logpdf (random.py:248-280) --------------------------------------------
     def logpdf(self, x):
         """Log-density at ``x``: ``(N,)``/``(N, 1)`` -> scalar tensor, ``(N, C)`` -> ``(C,)``,
@@ -216,8 +215,20 @@ class Normal(RandomVector):
             if not bool(available.all()):
                 idx = torch.nonzero(available)[:, 0]
                 mean = self.mean[idx]
-                var = self.var.dense()[idx][:, idx]
-                return Normal(mean, var).logpdf(x[idx])
+                var = self.var
+                if isinstance(var, KernelDense) and torch.is_tensor(var.x) and var.x.dim() == 2 and var._mat is None and not isinstance(var.noise, Dense) \
+                        and var.kernel.num_outputs(var.x) == var.x.shape[0]:
+                    # a kernel matrix restricted to the observed points is the kernel matrix OF those points:
+                    # stay lazy (lower-only build, in-place factor) and differentiable
+                    noise = var.noise
+                    if isinstance(noise, Diagonal):
+                        noise = Diagonal(noise.diag()[idx])
+                    elif isinstance(noise, Zero):
+                        noise = Zero(noise.dtype, idx.numel(), idx.numel(), device=noise.device)
+                    sub = KernelDense(var.kernel, var.x[idx], noise)
+                else:
+                    sub = var.dense()[idx][:, idx]
+                return Normal(mean, sub).logpdf(x[idx])
 
         var = self.var
         n = self.dim
@@ -228,6 +239,9 @@ class Normal(RandomVector):
 
             noise_vec = var.differentiable_noise()
             tt = var.kernel.tensor_terms()
+            if torch.is_grad_enabled() and _x_requires_grad(var.x):
+                raise NotImplementedError("gradients with respect to the inputs x of a GP are not implemented "
+                                          "(detach x, or wrap the call in torch.no_grad())")
             if noise_vec is not NotImplemented and tt is not None and _ag.needs_grad(tt, noise_vec, r):
                 lp = _ag.gp_logpdf(var.kernel, var.x, noise_vec, r)
                 return lp[0] if lp.shape[0] == 1 else lp
@@ -237,7 +251,7 @@ class Normal(RandomVector):
             nz = var.noise
             noisy = (isinstance(nz, Diagonal) and nz.diag().requires_grad) or (isinstance(nz, Dense) and nz.mat is not None
                                                                                and nz.mat.requires_grad)
-            if noisy or r.requires_grad or _ag.kernel_requires_grad(var.kernel):
+            if noisy or r.requires_grad or _x_requires_grad(var.x) or _ag.kernel_requires_grad(var.kernel):
                 raise NotImplementedError(
                     "gradients of logpdf are implemented for one unbatched process whose kernel is a sum of "
                     "primitives with scalar or per-point noise; this call (batched, multi-process, posterior or "
@@ -257,8 +271,9 @@ class Normal(RandomVector):
     @property
     def m2(self):
         """Second moment ``V + m m^T`` (``random.py:200-202``)."""
-        m = self.mean
-        return Dense(self.var.dense() + m @ m.transpose(-1, -2))
+        m = self.mean.contiguous()
+        be = ops.get_backend()
+        return Dense(be.gemm(m, m, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=1.0, out=be.copy(self.var.dense())))
 
     def diagonalise(self):
         """The distribution with its correlations set to zero (``random.py:240-246``)."""
@@ -277,20 +292,32 @@ class Normal(RandomVector):
         return (iqf + ratio + vo.logdet() - vs.logdet() - self.dim) / 2
 
     # -- sampling (random.py:331-363; adjacent to the hot path) ----------------
-    def sample(self, num=1, noise=None, generator=None):
-        """Samples as column vectors (..., N, num): ``chol(var) @ xi`` on the MFMA GEMM."""
+    def sample(self, num=1, noise=None, generator=None, xi=None):
+        """Samples as column vectors (..., N, num): ``chol(var) @ xi`` on the MFMA GEMM.
+
+        ``xi``: the standard-normal draws to transform, (..., N, num) -- what ``B.randn`` produces inside the
+        reference's ``B.sample`` (``random.py:351``); given, the result is a deterministic function of the
+        distribution (used to compare samples with the oracle)."""
         var = self.var
+        if xi is not None:
+            if xi.dim() == 1:
+                xi = xi[:, None]
+            if xi.shape[-2] != self.dim:
+                raise ValueError(f"xi has {xi.shape[-2]} rows, the distribution has dimension {self.dim}")
+            num = xi.shape[-1]
         if isinstance(var, Diagonal):
             d = var.diag() + (noise if noise is not None else 0)
-            xi = torch.randn(d.shape + (num,), dtype=d.dtype, device=d.device, generator=generator)
+            if xi is None:
+                xi = torch.randn(d.shape + (num,), dtype=d.dtype, device=d.device, generator=generator)
             out = torch.sqrt(d)[..., None] * xi
         else:
             if noise is not None:
                 var = var + Diagonal(torch.full(tuple(var.shape[:-1]), float(noise), dtype=var.dtype, device=var.device))
             chol = var.chol() if isinstance(var, Dense) else to_matrix(var.dense()).chol()
             l = chol.lower()
-            xi = torch.randn(tuple(var.shape[:-1]) + (num,), dtype=var.dtype, device=var.device, generator=generator)
-            out = ops.get_backend().gemm(l, xi, a_kmajor=True, b_kmajor=False)
+            if xi is None:
+                xi = torch.randn(tuple(var.shape[:-1]) + (num,), dtype=var.dtype, device=var.device, generator=generator)
+            out = ops.get_backend().gemm(l, xi.to(var.dtype), a_kmajor=True, b_kmajor=False)
         if not self.mean_is_zero:
             out = out + self.mean
         return out
