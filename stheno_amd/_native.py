@@ -23,6 +23,7 @@ DIAG_BLOCK = 128
 #: name -> (restype, argtypes); mirrors include/gpk.h declaration by declaration.
 SIGNATURES = {
     "gpk_version": (_c_int, []),
+    "gpk_init": (_c_int, []),
     "gpk_dinv_elems": (_c_i64, [_c_i64]),
     "gpk_colreduce_chunks": (_c_i64, [_c_i64]),
     "gpk_kmat": (
@@ -37,6 +38,11 @@ SIGNATURES = {
          _c_i64, _c_ptr],
     ),
     "gpk_potrf": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr]),
+    "gpk_potrf_la_ws_elems": (_c_i64, [_c_i64, _c_int]),
+    "gpk_potrf_la": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]),
+    "gpk_gemm_update2": (_c_int, [_c_int, _c_ptr, _c_int, _c_dbl, _c_ptr, _c_int, _c_ptr]),
+    "gpk_tune": (None, [_c_int, _c_i64]),
+    "gpk_tune_diag_prof": (None, [_c_ptr]),
     "gpk_trtri_merge": (
         _c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]
     ),

@@ -82,5 +82,10 @@ def sharded_elbo(obs, measure, group=None):
         if world > 1:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
 
+    if torch.is_grad_enabled() and obs._differentiable_requested(measure):
+        raise NotImplementedError(
+            "gradients of the observation-sharded bound are not implemented (every rank would differentiate its own "
+            "shard's bound): take them of `obs.elbo(measure)` on one rank, or wrap this call in torch.no_grad()"
+        )
     obs._compute(measure, reduce=reduce)
-    return obs.elbo(measure)
+    return obs._elbo[measure]        # the all-reduced bound (NOT obs.elbo(): that may re-enter the local autograd path)

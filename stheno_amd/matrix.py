@@ -24,6 +24,10 @@ class _Config:
     check_info = True
     #: outer block of the blocked Cholesky (0 = library default)
     potrf_nbo = 0
+    #: single matrices of at least this order take the look-ahead factorisation (``gpk_potrf_la``); 0 disables it
+    potrf_lookahead_from = 6144
+    #: its outer block = the order of the explicitly inverted diagonal blocks
+    potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 1024}
 
 
 config = _Config()
@@ -69,8 +73,17 @@ class Chol:
     def factor_(cls, a):
         """Factorise ``a`` (..., n, n; lower triangle read) IN PLACE."""
         be = ops.get_backend()
-        dinv, info = be.potrf_(a, config.potrf_nbo)
-        c = cls(a, dinv, info)
+        n = a.shape[-1]
+        nb = 0
+        if a.dim() == 2 and config.potrf_lookahead_from and n >= config.potrf_lookahead_from and getattr(be, "name", "") == "hip":
+            nb = config.potrf_lookahead_nb.get(a.dtype, 0)
+        if nb:
+            dinv, info, dnb = be.potrf_(a, config.potrf_nbo, lookahead_nb=nb)
+            c = cls(a, dinv, info)
+            c._dinv_sb[nb] = dnb          # the merged inverses the solves want come for free
+        else:
+            dinv, info = be.potrf_(a, config.potrf_nbo)
+            c = cls(a, dinv, info)
         if config.check_info:
             c.check()
         return c

@@ -190,6 +190,18 @@ class AbstractPseudoObservations(AbstractObservations):
             self._compute(measure)
         return self._elbo[measure]
 
+    def _differentiable_requested(self, measure):
+        """Whether anything the bound depends on carries a gradient (kernel hyper-parameters, noise, inducing inputs, y)."""
+        from .. import autograd
+
+        p_x, x, noise_x = self.fdd.p, self.fdd._xr, self.fdd.noise
+        z = self.u._xr
+        k = measure.kernels[self.u.p]
+        tt = k.tensor_terms() if hasattr(k, "tensor_terms") else None
+        if tt is None or isinstance(x, _k.MultiInput) or isinstance(z, _k.MultiInput) or not isinstance(noise_x, Diagonal):
+            return autograd.kernel_requires_grad(k) or self.y.requires_grad
+        return autograd.elbo_needs_grad(tt, noise_x.diag(), z, self.y - measure.means[p_x](x))
+
     def _differentiable(self, measure):
         from .. import autograd
 
@@ -217,7 +229,8 @@ class AbstractPseudoObservations(AbstractObservations):
     def mu(self, measure):
         """Mean of the optimal approximating distribution (``observations.py:224-237``)."""
         if measure not in self._mu:
-            self.elbo(measure)
+            if measure not in self._parts:      # (elbo() may have taken the differentiable path, which caches nothing)
+                self._compute(measure)
             be = ops.get_backend()
             p = self._parts[measure]
             l_z = p["K_z"].chol().lower()
@@ -232,7 +245,8 @@ class AbstractPseudoObservations(AbstractObservations):
         ``L_z L_A`` -- already known -- so the returned ``Dense`` carries that factor in
         product form and only forms the M x M product if its entries are asked for."""
         if measure not in self._A:
-            self.elbo(measure)
+            if measure not in self._parts:
+                self._compute(measure)
             be = ops.get_backend()
             p = self._parts[measure]
             chol_z = p["K_z"].chol()
@@ -244,7 +258,22 @@ class AbstractPseudoObservations(AbstractObservations):
                 return be.gemm(l_z, w, a_kmajor=True, b_kmajor=False)           # L_z (A L_z^T)
 
             a = p["A"]
-            self._A[measure] = FactoredDense(build, ChainChol(chol_z, p["chol_A"]), a.shape, a.dtype, a.device)
+            # The reference factorises the Dense matrix L_z A L_z^T through `B.cholesky(B.reg(.))`, i.e. WITH the
+            # epsilon-jitter (mlkernels.SubspaceKernel -> B.iqf).  In product form that is exactly
+            #   L_z A L_z^T + eps I = L_z (A + eps L_z^{-1} L_z^{-T}) L_z^T,
+            # so the factor stays L_z chol(A + eps W W^T), W = L_z^{-1}: same numbers as the reference at every
+            # epsilon (1e-3 of the posterior variance at the fp32 setting 1e-6 on ill-conditioned K_z), without
+            # re-factorising a product whose condition number is squared.
+            chol_post = p["chol_A"]
+            if config.epsilon:
+                if chol_z.l.dim() == 2:
+                    w = chol_z.inverse_lower()
+                else:
+                    eye = torch.eye(chol_z.n, dtype=a.dtype, device=a.device).expand(tuple(chol_z.l.shape[:-2]) + (chol_z.n, chol_z.n))
+                    w = chol_z.solve(eye)
+                a_reg = be.gemm(w, w, a_kmajor=True, b_kmajor=True, alpha=config.epsilon, beta=1.0, out=be.copy(a), lower_only=True)
+                chol_post = Chol.factor_(a_reg)
+            self._A[measure] = FactoredDense(build, ChainChol(chol_z, chol_post), a.shape, a.dtype, a.device)
         return self._A[measure]
 
     def posterior_kernel(self, measure, p_i, p_j):
@@ -300,19 +329,20 @@ class AbstractPseudoObservations(AbstractObservations):
         s = torch.rsqrt(K_n)
         be.scale_cols_(v, s)                                                  # V K_n^{-1/2}
         m = z.shape[-2]
-        # stats: [ V K_n^{-1} V^T (lower) | V K_n^{-1} y | logdet(2 pi K_n), y^T K_n^{-1} y, trace ]
-        stats = torch.zeros(v.shape[:-2] + (m, m + 2), dtype=x.dtype, device=x.device)
-        A = stats[..., :, :m]
+        # stats: rows 0..m-1 = [ V K_n^{-1} V^T (lower) | V K_n^{-1} y ]; row m = logdet(2 pi K_n), y^T K_n^{-1} y, trace
+        # (ONE buffer, so that the sharded path needs one all-reduce; the scalars have a row of their own: any m >= 1)
+        stats = torch.zeros(v.shape[:-2] + (m + 1, max(m + 1, 3)), dtype=x.dtype, device=x.device)
+        A = stats[..., :m, :m]
         _syrk_lower(be, v, A)                                                 # :322 (lower triangle)
         y_bar = self.y - measure.means[p_x](x)                                # :326
-        be.gemv(v, y_bar * s[..., None], out=stats[..., :, m : m + 1])        # :327
-        stats[..., 0, m + 1] = torch.log(2 * math.pi * K_n).sum(-1)
-        stats[..., 1, m + 1] = (y_bar[..., 0] ** 2 / K_n).sum(-1)
-        stats[..., 2, m + 1] = trace_part
+        be.gemv(v, y_bar * s[..., None], out=stats[..., :m, m : m + 1])       # :327
+        stats[..., m, 0] = torch.log(2 * math.pi * K_n).sum(-1)
+        stats[..., m, 1] = (y_bar[..., 0] ** 2 / K_n).sum(-1)
+        stats[..., m, 2] = trace_part
         if reduce is not None:
             reduce(stats)
-        prod_y_bar = stats[..., :, m : m + 1].contiguous()
-        logdet_noise, yky, trace_part = stats[..., 0, m + 1], stats[..., 1, m + 1], stats[..., 2, m + 1]
+        prod_y_bar = stats[..., :m, m : m + 1].contiguous()
+        logdet_noise, yky, trace_part = stats[..., m, 0], stats[..., m, 1], stats[..., m, 2]
         A = be.add_diag_(be.copy(A), 1.0)                                     # I + V K_n^{-1} V^T
         a_fac = be.copy(A)
         if config.epsilon:

@@ -107,8 +107,40 @@ def _bs(t3):
     return t3.stride(0) if t3.shape[0] > 1 else 0
 
 
+def _tensors_of(args):
+    for a in args:
+        if torch.is_tensor(a):
+            yield a
+        elif isinstance(a, (list, tuple)):
+            yield from _tensors_of(a)
+
+
+def _on_operand_device(fn):
+    """Run ``fn`` with the operands' device as the current device: ``libgpk`` launches on the CURRENT HIP
+    device and ``torch.cuda.current_stream()`` is per device, so a call made while another device is current
+    would run on that device's stream against this device's memory.  Operands on different devices are refused."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = None
+        for t in _tensors_of(list(args) + list(kwargs.values())):
+            if not t.is_cuda:
+                continue
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RuntimeError(f"operands live on different devices ({dev} and {t.device})")
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+
+    return wrapped
+
+
 class HipBackend:
-    """ctypes calls into ``libgpk.so`` on the current torch HIP stream."""
+    """ctypes calls into ``libgpk.so`` on the current torch HIP stream of the operands' device."""
 
     name = "hip"
 
@@ -141,6 +173,7 @@ class HipBackend:
             raise RuntimeError(f"libgpk {what} failed with status {code}")
 
     # -- kernel matrices -----------------------------------------------------
+    @_on_operand_device
     def kmat(self, terms, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, out=None, accumulate=False):
         """``out[b, i, j] (+)= k(x[b, i], y[b, j])``; ``y is None`` means the symmetric case
         (then ``diag_add`` / ``diag_vec`` go on the diagonal)."""
@@ -167,6 +200,7 @@ class HipBackend:
         self._st(code, "gpk_kmat")
         return out
 
+    @_on_operand_device
     def kdiag(self, terms, x):
         x3, bshape = _as3(x)
         self._check(x3)
@@ -179,8 +213,12 @@ class HipBackend:
         return out
 
     # -- factorisation -------------------------------------------------------
-    def potrf_(self, a, nbo=0):
-        """In-place lower Cholesky of ``a`` (..., n, n).  Returns ``(dinv, info)``."""
+    @_on_operand_device
+    def potrf_(self, a, nbo=0, lookahead_nb=0):
+        """In-place lower Cholesky of ``a`` (..., n, n).  Returns ``(dinv, info)``, or
+        ``(dinv, info, dinv_nb)`` when ``lookahead_nb`` (256 ... 4096) selects the look-ahead
+        factorisation of ONE large matrix: ``dinv_nb`` are the inverses of the ``nb x nb`` diagonal
+        blocks of the factor (what ``trtri_merge(l, dinv, nb)`` would compute)."""
         a3, _ = _as3(a)
         if a3.data_ptr() != a.data_ptr():
             raise ValueError("potrf_ needs a tensor with unit inner stride (it factorises in place)")
@@ -189,11 +227,24 @@ class HipBackend:
         nblk = (max(n, 1) + 127) // 128
         dinv = torch.empty((B, nblk, 128, 128), dtype=a.dtype, device=a.device)
         info = torch.zeros((B,), dtype=torch.int32, device=a.device)
+        if lookahead_nb:
+            if B != 1:
+                raise ValueError("the look-ahead factorisation takes one matrix")
+            nb = int(lookahead_nb)
+            dnb = torch.empty((1, (n + nb - 1) // nb, nb, nb), dtype=a.dtype, device=a.device)
+            ws = torch.empty((int(self.lib.gpk_potrf_la_ws_elems(n, nb)),), dtype=a.dtype, device=a.device)
+            code = self.lib.gpk_potrf_la(_dtype_id(a3), self._ptr(a3), n, _ld(a3), self._ptr(dinv), self._ptr(dnb), nb,
+                                         self._ptr(ws), self._ptr(info), self._stream())
+            self._st(code, "gpk_potrf_la")
+            # `ws` is freed here while the factorisation may still be running: torch's caching allocator only reuses the
+            # block for work enqueued later on this same stream, and the helper stream has joined it by then
+            return dinv, info, dnb
         code = self.lib.gpk_potrf(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._ptr(dinv),
                                   self._ptr(info), int(nbo), self._stream())
         self._st(code, "gpk_potrf")
         return dinv, info
 
+    @_on_operand_device
     def trtri_merge(self, l, dinv, sb):
         l3, _ = _as3(l)
         self._check(l3, dinv)
@@ -206,6 +257,7 @@ class HipBackend:
         self._st(code, "gpk_trtri_merge")
         return dsb
 
+    @_on_operand_device
     def tri_solve_(self, l, dinv_sb, sb, b):
         """``b <- L^{-1} b`` in place; ``b`` is (..., n, nrhs) with unit inner stride."""
         l3, _ = _as3(l)
@@ -231,6 +283,7 @@ class HipBackend:
         return b
 
     # -- products ------------------------------------------------------------
+    @_on_operand_device
     def trtri(self, l, dinv_sb, sb):
         """``L^{-1}`` of an unbatched factor as a full (n, n) lower-triangular matrix."""
         self._check(l, dinv_sb)
@@ -242,6 +295,7 @@ class HipBackend:
         self._st(code, "gpk_trtri_lower")
         return w
 
+    @_on_operand_device
     def gemm(self, a, b, *, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=None, lower_only=False,
              tri_k=False, tri_k_lower=False):
         """``out[m, n] = alpha * sum_k a(m, k) b(n, k) + beta * out``.
@@ -268,6 +322,7 @@ class HipBackend:
         self._st(code, "gpk_gemm")
         return out
 
+    @_on_operand_device
     def gemv(self, a, x, *, alpha=1.0, beta=0.0, out=None):
         """``out = alpha * a @ x + beta * out`` for (..., M, K) @ (..., K, nrhs <= 8)."""
         a3, bshape = _as3(a)
@@ -285,6 +340,7 @@ class HipBackend:
         return out
 
     # -- reductions ----------------------------------------------------------
+    @_on_operand_device
     def logdet_chol(self, l):
         l3, bshape = _as3(l)
         self._check(l3)
@@ -295,6 +351,7 @@ class HipBackend:
         self._st(code, "gpk_logdet_chol")
         return out.reshape(bshape)
 
+    @_on_operand_device
     def colreduce(self, v, w=None, *, want_dot=False, want_ss=True):
         """Column reductions of ``v`` (..., R, C): ``(v^T w, colsumsq(v))`` (``None`` for the
         one not requested).  ``w``: (..., R) or (..., R, 1)."""
@@ -321,6 +378,7 @@ class HipBackend:
             ss = ss.reshape(bshape + (C,))
         return dot, ss
 
+    @_on_operand_device
     def kmat_vjp(self, terms, x, kinv, alpha, g):
         """Sums for the hyper-parameter gradient of the log-density (see gpk_kmat_vjp):
         returns ``(S, trace_G, diag_G)`` with ``S[t] = (sum G kappa_t, sum G kappa_t' q)``.
@@ -342,6 +400,7 @@ class HipBackend:
         tot = partial.sum(0)
         return tot[: 2 * nt].reshape(nt, 2), tot[2 * _native.MAX_TERMS], diag_g
 
+    @_on_operand_device
     def kmat_vjp_dense(self, terms, x, y, g, colscale=None, w=None, b=None, want_colsum=False, want_gradx=False):
         """Sums over an explicit cotangent ``Geff = g * colscale[None, :] + w[:, None] b[None, :]`` of
         ``K = k(x, y)`` (see gpk_kmat_vjp_dense): returns ``(S, colsum, gradx)`` with
@@ -374,6 +433,7 @@ class HipBackend:
                 gradx.sum(0) if want_gradx else None)
 
     # -- in-place odds and ends ------------------------------------------------
+    @_on_operand_device
     def tril_(self, a):
         a3, _ = _as3_out(a)
         self._check(a3)
@@ -381,6 +441,7 @@ class HipBackend:
         self._st(self.lib.gpk_tril(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._stream()), "gpk_tril")
         return a
 
+    @_on_operand_device
     def symmetrize_(self, a):
         a3, _ = _as3_out(a)
         self._check(a3)
@@ -389,6 +450,7 @@ class HipBackend:
                  "gpk_symmetrize")
         return a
 
+    @_on_operand_device
     def add_diag_(self, a, s=0.0, v=None):
         a3, _ = _as3_out(a)
         self._check(a3, v)
@@ -398,6 +460,7 @@ class HipBackend:
                                        n if v2 is not None else 0, B, self._stream()), "gpk_add_diag")
         return a
 
+    @_on_operand_device
     def scale_cols_(self, v, s):
         v3, _ = _as3_out(v)
         self._check(v3, s)
@@ -407,6 +470,7 @@ class HipBackend:
                                          self._stream()), "gpk_scale_cols")
         return v
 
+    @_on_operand_device
     def copy(self, src):
         """Fresh copy of a (..., R, C) tensor (strided 2-D copy kernel; rows 16-byte aligned)."""
         s3, bshape = _as3(src)

@@ -231,5 +231,33 @@ def hip_backend():
     ops.set_backend(prev)
 
 
+#: device new test tensors go to under ``any_backend`` ("cpu" with the oracle backend, "cuda" with the HIP one)
+DEVICE = ["cpu"]
+
+
+@pytest.fixture(params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def any_backend(request):
+    """Run a test twice: over the test-only oracle backend on the CPU box, over ``libgpk.so`` on the MI355X."""
+    if request.param == "oracle":
+        prev = ops.set_backend(OracleBackend())
+        DEVICE[0] = "cpu"
+        yield request.param
+        ops.set_backend(prev)
+    else:
+        prev = ops.set_backend(None)
+        assert ops.get_backend().name == "hip"
+        DEVICE[0] = "cuda"
+        try:
+            yield request.param
+        finally:
+            DEVICE[0] = "cpu"
+            ops.set_backend(prev)
+
+
+def T(a, dtype=torch.float64):
+    """Tensor on the device of the active ``any_backend``."""
+    return torch.as_tensor(np.asarray(a), dtype=dtype, device=DEVICE[0])
+
+
 def golden(name):
     return np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)

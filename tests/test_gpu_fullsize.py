@@ -101,7 +101,7 @@ def test_config3_sum_kernel_f32_n32768():
         lp64 = fd64.logpdf(y32.double())
         m64, v64 = (f | (fd64, y32.double()))(xs32.double()).marginals()
         assert abs(float(lp32) - float(lp64)) <= 1e-3 * abs(float(lp64))
-        assert rel(m32, m64) < 1e-3 and rel(v32, v64) < 2e-3
+        assert rel(m32, m64) < 1e-3 and rel(v32, v64) < 1e-3
         # oracle at N = 1024
         n1 = 1024
         ref = O.gp_logpdf([("eq", 1.0, 1.0), ("linear", 1.0, 1.0)], x32[:n1].double().cpu().numpy(), NOISE,

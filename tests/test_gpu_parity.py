@@ -178,11 +178,11 @@ def test_batched_golden(dtype):
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_sparse_golden(dtype):
     g = golden("sparse_eq_n400_m50_d2.npz")
-    # fp32: K_z of 50 clustered inducing points has kappa ~ 1e8, so fp32 needs a visible jitter
-    # (1e-4), and the ELBO depends on that jitter: the fp32 run is compared with the oracle
-    # evaluated in fp64 at the SAME epsilon (the fixture itself was made with 1e-10).
-    e = float(g["epsilon"]) if dtype == torch.float64 else 1e-4
-    tol = TOL[dtype] if dtype == torch.float64 else 3e-3
+    # fp32 runs at the reference's own fp32 jitter (1e-6, README.md:887-888) and is held to the 1e-3 bar against the
+    # oracle evaluated in fp64 at the SAME epsilon (the bound and the posterior depend on the jitter: K_z of 50
+    # clustered inducing points has kappa ~ 1e8; the fixture itself was made with 1e-10).
+    e = float(g["epsilon"]) if dtype == torch.float64 else 1e-6
+    tol = TOL[dtype]
     terms = list(zip(g["kinds"], g["variances"], g["scales"]))
     with eps(e):
         m = st.Measure()
@@ -201,7 +201,7 @@ def test_sparse_golden(dtype):
             assert rel(obs.elbo(m).reshape(1), ref_elbo) < tol
             mean, vd = (m | obs)(f)(xs).marginals()
             assert rel(mean, ref_mean) < max(tol, 1e-5)
-            assert rel(vd, np.maximum(ref_vd, 0)) < max(5 * tol, 1e-5)
+            assert rel(vd, np.maximum(ref_vd, 0)) < max(tol, 1e-5)
         with pytest.raises(RuntimeError):
             st.PseudoObs(f(z), (f(x, torch.eye(400, dtype=dtype, device=DEV)), y)).elbo(m)
 

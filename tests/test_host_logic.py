@@ -1,9 +1,9 @@
 """Host-side model logic (GP / Measure / FDD / Normal / Obs / PseudoObs) on the CPU box.
 
-The op backend here is the TEST-ONLY ``OracleBackend`` from conftest.py, so these tests
-pin what the Python layer composes -- lazy resolution, caching, shapes, errors, the
-formulas above the kernels -- mirroring the reference's own tests (cited per test).
-The same scenarios run through the HIP kernels in tests/test_gpu_*.py.
+Every test runs TWICE: on the CPU box (``-m "not gpu"``) over the TEST-ONLY ``OracleBackend`` from
+conftest.py, pinning what the Python layer composes -- lazy resolution, caching, shapes, errors, the
+formulas above the kernels -- and on the MI355X (``-m gpu``) over ``libgpk.so`` with every tensor on the
+device, mirroring the reference's own tests (cited per test) on the product path.
 """
 import time
 
@@ -17,14 +17,41 @@ from oracle import gp_oracle as O
 from stheno_amd import B
 from stheno_amd.matrix import Dense, Diagonal, KernelDense, Zero
 
-from .conftest import golden
+from stheno_amd import ops
 
-pytestmark = pytest.mark.usefixtures("oracle_backend")
+from .conftest import OracleBackend, golden
+
 f64 = torch.float64
+_DEV = ["cpu"]
+
+
+@pytest.fixture(autouse=True, params=["oracle", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request):
+    """The op backend (and the device new tensors are created on) for one test."""
+    if request.param == "oracle":
+        prev = ops.set_backend(OracleBackend())
+        _DEV[0] = "cpu"
+        yield request.param
+        ops.set_backend(prev)
+    else:
+        prev = ops.set_backend(None)
+        assert ops.get_backend().name == "hip"
+        _DEV[0] = "cuda"
+        torch.set_default_device("cuda")
+        try:
+            yield request.param
+        finally:
+            torch.set_default_device("cpu")
+            _DEV[0] = "cpu"
+            ops.set_backend(prev)
 
 
 def t(a):
-    return torch.as_tensor(np.asarray(a), dtype=f64)
+    return torch.as_tensor(np.asarray(a), dtype=f64, device=_DEV[0])
+
+
+def gen(seed):
+    return torch.Generator(device=_DEV[0]).manual_seed(seed)
 
 
 def approx(a, b, atol=1e-8, rtol=1e-8):
@@ -88,7 +115,7 @@ def test_normal_lazy_mean_var_diag():      # test_random.py:136-158
 
 @pytest.fixture()
 def normal1():
-    g = torch.Generator().manual_seed(0)
+    g = gen(0)
     mean = torch.randn(3, 1, dtype=f64, generator=g)
     chol = torch.randn(3, 3, dtype=f64, generator=g)
     return st.Normal(mean, chol @ chol.T)
@@ -106,7 +133,7 @@ def test_normal_logpdf_vs_scipy(normal1):          # test_random.py:185-192
     B.epsilon = 0.0
     try:
         sp = multivariate_normal(B.to_numpy(normal1.mean)[:, 0], B.to_numpy(normal1.var))
-        x = torch.randn(3, 10, dtype=f64, generator=torch.Generator().manual_seed(1))
+        x = torch.randn(3, 10, dtype=f64, generator=gen(1))
         approx(normal1.logpdf(x), sp.logpdf(B.to_numpy(x).T), rtol=1e-6)
         assert normal1.logpdf(torch.ones(3, 1, dtype=f64)).shape == ()
         assert normal1.logpdf(torch.ones(3, 2, dtype=f64)).shape == (2,)
@@ -281,18 +308,21 @@ def test_sparse_golden_through_the_api():
 # ---------------------------------------------------------------- golden / batched / misc
 @pytest.mark.parametrize("name", ["dense_eq_n256_d8", "dense_eq_n300_d1_c3", "dense_matern12_n200_d3",
                                   "dense_matern32_n200_d3", "dense_matern52_n333_d5", "dense_eq_linear_n512_d4"])
-def test_dense_golden_through_the_api(name):
+def test_dense_golden_through_the_api(name, backend):
     g = golden(name + ".npz")
+    # the fixtures follow upstream's |a|^2 + |b|^2 - 2ab distances (as the oracle backend does); the HIP kernel takes direct
+    # differences: <= 3e-8 relative on Matern diagonals -- the device run is held to the 1e-6 bar
+    loose = dict(atol=1e-6, rtol=1e-6) if backend == "hip" else {}
     kinds = {"eq": st.EQ, "matern12": st.Matern12, "matern32": st.Matern32, "matern52": st.Matern52, "linear": st.Linear}
     k = sum(float(v) * kinds[str(kd)]().stretch(float(s)) for kd, v, s in zip(g["kinds"], g["variances"], g["scales"]))
     f = st.GP(k)
     x, xs, y = t(g["x"]), t(g["xs"]), t(g["y"])
-    approx(np.atleast_1d(B.to_numpy(f(x, float(g["noise"])).logpdf(y))), g["logpdf"], rtol=1e-10)
+    approx(np.atleast_1d(B.to_numpy(f(x, float(g["noise"])).logpdf(y))), g["logpdf"], rtol=1e-6 if backend == "hip" else 1e-10)
     post = f | (f(x, float(g["noise"])), y[:, :1])
     mean, vd = post(xs).marginals()
-    approx(mean, g["post_mean"], atol=1e-9); approx(vd, np.maximum(g["post_var_diag"], 0), atol=1e-9)
-    approx(post(xs).var, g["post_var"], atol=1e-9)
-    approx(f.kernel.elwise(x)[:, 0], g["kdiag"]); approx(f.kernel(x[:8], xs[:8]), g["k_corner"])
+    approx(mean, g["post_mean"], **(loose or dict(atol=1e-9))); approx(vd, np.maximum(g["post_var_diag"], 0), **(loose or dict(atol=1e-9)))
+    approx(post(xs).var, g["post_var"], **(loose or dict(atol=1e-9)))
+    approx(f.kernel.elwise(x)[:, 0], g["kdiag"], **loose); approx(f.kernel(x[:8], xs[:8]), g["k_corner"], **loose)
 
 
 def test_batched_shapes_and_values():      # tests/model/test_cases.py:134-155, README.md:744-766
@@ -332,12 +362,14 @@ def test_non_positive_definite_raises():
         st.Normal(torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=f64)).logpdf(torch.zeros(2, 1, dtype=f64))
 
 
-def test_epsilon_is_read_at_factorisation_time():    # README.md:820-831
+def test_epsilon_is_read_at_factorisation_time(backend):    # README.md:820-831
     x = t(np.linspace(0, 2, 10))
     f = st.GP(st.EQ())
     y = x**2
     mean = (f | (f(x), y))(t([1.0, 2.0, 3.0])).mean
-    approx(mean[:, 0], [1.00000068, 3.99999999, 8.4825932], rtol=2e-7)
+    # kappa(K) ~ 1e12 (noise-free conditioning): LAPACK builds agree to ~1e-7 here; the device is
+    # held to the 1e-6 bar
+    approx(mean[:, 0], [1.00000068, 3.99999999, 8.4825932], rtol=1e-6 if backend == "hip" else 2e-7)
     B.epsilon = 1e-8
     try:
         mean8 = (f | (f(x), y))(t([1.0, 2.0, 3.0])).mean
@@ -522,7 +554,7 @@ def test_normal_mean_is_zero_entropy_and_sampling(normal1):   # test_random.py:5
     assert not st.Normal(torch.randn(3, 1, dtype=f64), torch.eye(3, dtype=f64)).mean_is_zero
     sp = multivariate_normal(B.to_numpy(normal1.mean)[:, 0], B.to_numpy(B.dense(normal1.var)))
     approx(normal1.entropy(), sp.entropy(), rtol=1e-10)
-    g = torch.Generator().manual_seed(0)
+    g = gen(0)
     for mean in (0.0, 1.0):
         dist = st.Normal(mean * torch.ones(200, 1, dtype=f64), 3 * torch.eye(200, dtype=f64))
         s = dist.sample(2000, generator=g)
@@ -530,8 +562,8 @@ def test_normal_mean_is_zero_entropy_and_sampling(normal1):   # test_random.py:5
         assert abs(float(s.mean()) - mean) < 5e-2 and abs(float(s.std()) ** 2 - 3) < 5e-2
         s = dist.sample(2000, noise=2, generator=g)
         assert abs(float(s.mean()) - mean) < 5e-2 and abs(float(s.std()) ** 2 - 5) < 5e-2
-    a = dist.sample(generator=torch.Generator().manual_seed(7))
-    b = dist.sample(generator=torch.Generator().manual_seed(7))
+    a = dist.sample(generator=gen(7))
+    b = dist.sample(generator=gen(7))
     approx(a, b)
 
 

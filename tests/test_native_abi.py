@@ -34,6 +34,12 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(_native.lib_path())
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/gpk.h but not exported by libgpk.so"
+    # ... and nothing else: every exported gpk_* symbol is declared (no undocumented back doors)
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if re.match(r"^[0-9a-f]+ T gpk_[a-z0-9_]+$", line.strip())})
+    assert exported == _declared()
     assert _native.load().gpk_version() >= 100
     assert _native.load().gpk_dinv_elems(300) == 3 * 128 * 128
 
