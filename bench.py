@@ -16,13 +16,14 @@ the dense workload does not shard (one coupled factorisation), so every rank run
 independent replica ("replicas only"); ``batched_f32`` shards its 512 GPs over the ranks
 and all-gathers the log-densities (stheno_amd/dist.py).
 
-Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel (the MFMA GEMM that
-performs the Cholesky trailing update, ``gemm_kernel<double, 128, true, true, false>``):
+Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel -- the MFMA GEMM variant with the
+largest summed duration in a step; for the dense workloads that is the persistent two-segment
+trailing update of the look-ahead Cholesky, ``gemm_persist_kernel<double, 128, false>`` --:
 algorithmic flops of its launches in one step / their summed duration, measured with HIP
 events on the launch stream (gpk_prof_* hooks) in extra, untimed steps right after the
-timed region.  ``cpu_baseline`` is the NumPy/SciPy oracle (a restatement of Stheno's
-NumPy path) timed on the host cores on a bounded sample -- a reported baseline, not
-the target.
+timed region; ``whole_step`` prices the entire step (all kernels, all gaps) the same way.
+``cpu_baseline`` is the NumPy/SciPy oracle (a restatement of Stheno's NumPy path) timed on
+the host cores on a bounded sample -- a reported baseline, not the target.
 """
 import argparse
 import json
@@ -116,59 +117,113 @@ def make_step(name, w, t):
     return step
 
 
-def pmc_traffic(name, w):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` run separately on this same
-    command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC
-    collection cannot run inside the timed process, so the figure is read from
-    ``profiles/``; ``None`` if no pass exists for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % name)
-    if not os.path.exists(path) or w["n"] != WORKLOADS[name]["n"]:
+def pmc_traffic(name, w, kernel):
+    """HBM-side bytes per launch of ``kernel`` from the committed PMC passes (``rocprofv3 --pmc FETCH_SIZE`` and
+    ``--pmc WRITE_SIZE`` run separately on this same command by scripts/collect_pmc.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC collection cannot run inside the timed process, so the
+    figure is read from ``profiles/``; ``None`` if no pass exists for this workload / kernel."""
+    if w["n"] != WORKLOADS[name]["n"]:
         return None
-    with open(path) as f:
-        d = json.load(f)
-    k = d["kernels"].get("gemm_kernel<%s, 128, true, true, false, 1>" % ("double" if w["dtype"] == "f64" else "float"))
-    return None if k is None else k["hbm_bytes_per_launch"]
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
+        if os.path.exists(path):
+            with open(path) as f:
+                k = json.load(f)["kernels"].get(kernel)
+            if k is not None:
+                return k["hbm_bytes_per_launch"]
+    return None
 
 
-def cpu_baseline(name):
-    """The oracle (NumPy/SciPy restatement of Stheno's NumPy path) on the host cores, on a
-    bounded sample of the same workload."""
-    from oracle import gp_oracle as O
+def _variant_name(code, dtype):
+    """Kernel behind a gpk_prof variant code (see gpk_prof_stop in include/gpk.h)."""
+    t = "double" if dtype == "f64" else "float"
+    ts = 64 if code & 16 else 128
+    edge = "true" if code & 1 else "false"
+    if code & 32:
+        return f"gemm_persist_kernel<{t}, {ts}, {edge}>"
+    return f"gemm_kernel<{t}, {ts}, {'true' if code & 4 else 'false'}, {'true' if code & 2 else 'false'}, {edge}, 1>"
 
+
+#: algorithmic flops of ONE step (SURVEY 8(d)): POTRF N^3/3 + posterior TRSM N^2 N* + the O(N^2) rest (kernel
+#: matrices, TRSV, reductions: < 1 %, not counted)
+def step_flops(name, w):
+    n = float(w["n"])
+    if name in ("dense_f64", "sum_f32"):
+        return n ** 3 / 3 + n * n * w["ns"]
+    if name == "batched_f32":
+        return w["b"] * n ** 3 / 3
+    m = float(w["m"])
+    return 2 * m * m * n + 2 * m ** 3 / 3          # TRSM M^2 N + SYRK M^2 N (symmetric count) + two POTRF(M)
+
+
+def _host_threads():
     try:
         from threadpoolctl import threadpool_info
 
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] or [1]))
     except Exception:
-        threads = os.cpu_count() or 1
-    if name != "dense_f64":
-        return None
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(name):
+    """The oracle (NumPy/SciPy restatement of Stheno's NumPy path) on the host cores, on a bounded sample of
+    the same workload (stated in ``sample``); the same op sequence as the GPU step, one shared factorisation."""
+    from oracle import gp_oracle as O
+
     w = WORKLOADS[name]
-    n_s = 8192
     rng = np.random.default_rng(0)
-    x, y = rng.standard_normal((n_s, w["d"])), rng.standard_normal((n_s, 1))
-    xs = rng.standard_normal((w["ns"], w["d"]))
-    terms = [("eq", 1.0, 1.0)]
+    np_dt = np.float64 if w["dtype"] == "f64" else np.float32
+    eps = 1e-12 if w["dtype"] == "f64" else 1e-6
+    if name in ("dense_f64", "sum_f32"):
+        n_s = 8192
+        terms = [("eq", 1.0, 1.0)] if name == "dense_f64" else [("eq", 1.0, 1.0), ("linear", 1.0, 1.0)]
+        x, y = rng.standard_normal((n_s, w["d"])).astype(np_dt), rng.standard_normal((n_s, 1)).astype(np_dt)
+        xs = rng.standard_normal((w["ns"], w["d"])).astype(np_dt)
+        t0 = time.perf_counter()
+        k = O.kernel_matrix(terms, x) + NOISE * np.eye(n_s, dtype=np_dt)
+        t_k = time.perf_counter() - t0
+        chol = O.cholesky(k, eps)
+        lp = -(O.logdet_chol(chol) + n_s * O.LOG_2_PI + O.iqf_diag(chol, y)) / 2
+        v = O.solve_lower(chol, O.kernel_matrix(terms, x, xs))
+        mean = v.T @ O.solve_lower(chol, y)
+        var = O.kernel_diag(terms, xs) - np.sum(v * v, axis=0)
+        dt = time.perf_counter() - t0
+        assert np.isfinite(lp).all() and np.isfinite(mean).all() and np.isfinite(var).all()
+        # the kernel-matrix build and the solves against N* scale with N^2, the factorisation with N^3
+        r = w["n"] / n_s
+        t_fac = dt - t_k
+        full = t_k * r * r + t_fac * r ** 3
+        return {"value": 1.0 / full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
+                "sample": f"oracle/gp_oracle.py (NumPy/SciPy, {w['dtype']}) at N={n_s}, D={w['d']}, N*={w['ns']}: {dt:.2f} s per eval "
+                          f"measured ({t_k:.2f} s of it the N^2 kernel-matrix build); extrapolated to N={w['n']} with the build "
+                          f"scaled by (N/{n_s})^2 and the rest by (N/{n_s})^3"}
+    if name == "batched_f32":
+        n_g = 4
+        x = rng.standard_normal((n_g, w["n"], w["d"])).astype(np_dt)
+        y = rng.standard_normal((n_g, w["n"], 1)).astype(np_dt)
+        t0 = time.perf_counter()
+        for b in range(n_g):
+            lp = O.gp_logpdf([("eq", 1.0, 1.0)], x[b], NOISE, y[b], eps=eps)
+        dt = time.perf_counter() - t0
+        assert np.isfinite(lp)
+        return {"value": n_g / dt, "unit": "GPs/s", "cores": _host_threads(), "kind": "port",
+                "sample": f"oracle/gp_oracle.py gp_logpdf (NumPy/SciPy, fp32 inputs) on {n_g} of the 512 GPs (N={w['n']}, D={w['d']}), one after "
+                          f"the other as NumPy's batched path does: {dt:.2f} s"}
+    n_s = 20000
+    x, y = rng.standard_normal((n_s, w["d"])).astype(np_dt), rng.standard_normal((n_s, 1)).astype(np_dt)
+    z = rng.standard_normal((w["m"], w["d"])).astype(np_dt)
     t0 = time.perf_counter()
-    # one eval with ONE shared factorisation (the same op sequence as the GPU step)
-    k = O.kernel_matrix(terms, x) + NOISE * np.eye(n_s)
-    chol = O.cholesky(k, 1e-12)
-    lp = -(O.logdet_chol(chol) + n_s * O.LOG_2_PI + O.iqf_diag(chol, y)) / 2
-    v = O.solve_lower(chol, O.kernel_matrix(terms, x, xs))
-    mean = v.T @ O.solve_lower(chol, y)
-    var = O.kernel_diag(terms, xs) - np.sum(v * v, axis=0)
+    elbo = O.pseudo_obs([("eq", 1.0, 1.0)], x, NOISE, y, z, method="vfe", eps=eps)["elbo"]
     dt = time.perf_counter() - t0
-    assert np.isfinite(lp).all() and np.isfinite(mean).all() and np.isfinite(var).all()
-    scale = (w["n"] / n_s) ** 3
-    return {
-        "value": 1.0 / (dt * scale),
-        "unit": "evals/s",
-        "cores": int(threads),
-        "kind": "port",
-        "sample": f"oracle/gp_oracle.py (NumPy/SciPy, fp64) at N={n_s}, D={w['d']}, N*={w['ns']}: "
-                  f"{dt:.2f} s per eval measured; value extrapolated to N={w['n']} by (N/{n_s})^3 = x{scale:.0f}",
-    }
+    assert np.isfinite(elbo)
+    # the M^3 part (two factorisations) does not grow with N: measure it alone and scale only the rest
+    t1 = time.perf_counter()
+    O.cholesky(O.kernel_matrix([("eq", 1.0, 1.0)], z) + 0.1 * np.eye(w["m"], dtype=np_dt), eps)
+    t_m3 = 2 * (time.perf_counter() - t1)
+    full = t_m3 + max(dt - t_m3, 0.0) * (w["n"] / n_s)
+    return {"value": 1.0 / full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
+            "sample": f"oracle/gp_oracle.py pseudo_obs (VFE; NumPy/SciPy, fp32 inputs) at N={n_s}, M={w['m']}: {dt:.2f} s measured; the two "
+                      f"M^3 factorisations ({t_m3:.2f} s) kept, the O(N M^2) rest scaled by N/{n_s} = x{w['n'] // n_s}"}
 
 
 def main():
@@ -225,26 +280,36 @@ def main():
     lib = _native.load()
     import ctypes
 
-    variant = (8 if w["dtype"] == "f64" else 0) + 4 + 2     # NT, non-edge: the potrf trailing/panel GEMM
     prof_steps = 2
     lib.gpk_prof_start()
     for _ in range(prof_steps):
         keep = step()
     torch.cuda.synchronize()
     ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    lib.gpk_prof_stop(variant, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
-    if nl.value > 0 and ms.value > 0:
-        achieved = fl.value / (ms.value * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[w["dtype"]]
+    best = None
+    for code in range(64):            # every GEMM kernel variant: the dominant one is the one with the most time
+        lib.gpk_prof_stop(code, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
+        if nl.value > 0 and (best is None or ms.value > best[1]):
+            best = (code, ms.value, nl.value, fl.value)
+    peak = PEAK_TFLOPS[w["dtype"]]
+    if best is not None and best[1] > 0:
+        code, tms, launches, flops = best
+        achieved = flops / (tms * 1e-3) / 1e12
+        kname = _variant_name(code, w["dtype"])
         roofline = {
-            "kernel": f"gemm_kernel<{'double' if w['dtype'] == 'f64' else 'float'}, 128, true, true, false, 1>",
+            "kernel": kname,
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": pmc_traffic(name, w),
-            "launches_per_step": nl.value // prof_steps,
-            "avg_launch_us": ms.value * 1e3 / nl.value,
-            "algorithmic_flops_per_step": fl.value / prof_steps,
-            "kernel_ms_per_step": ms.value / prof_steps,
+            "traffic": pmc_traffic(name, w, kname),
+            "launches_per_step": launches // prof_steps,
+            "avg_launch_us": tms * 1e3 / launches,
+            "algorithmic_flops_per_step": flops / prof_steps,
+            "kernel_ms_per_step": tms / prof_steps,
         }
+    whole = {"algorithmic_flops_per_step": step_flops(name, w), "unit": "TFLOP/s", "peak": peak}
+    # per GPU: replicas run `world` steps at once, the batched workload splits one step over the ranks
+    per_gpu = 1.0 if name != "batched_f32" else 1.0 / world
+    whole["achieved"] = whole["algorithmic_flops_per_step"] * per_gpu * args.steps / elapsed / 1e12
+    whole["frac"] = whole["achieved"] / peak
 
     if rank == 0:
         units = args.steps * (world if name != "batched_f32" else 1)
@@ -264,6 +329,8 @@ def main():
                        "parallelism": ("replicas only (%d independent evals in flight)" % world) if name != "batched_f32"
                        else "GPs sharded over %d ranks, all-gather of log-densities" % world},
             "roofline": roofline,
+            "whole_step": whole,
+            "rccl_world_size": (dist.get_world_size() if use_dist else 0),
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.n) else cpu_baseline(name),
         }
         line = json.dumps(out)

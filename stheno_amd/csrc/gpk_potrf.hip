@@ -556,12 +556,13 @@ namespace {
 
 struct LaDevice {
     hipStream_t aux = nullptr;
+    hipStream_t priv = nullptr;      // stands in for the legacy default stream (see gpk_potrf_la_launch)
     std::vector<hipEvent_t> events;
 };
 std::mutex g_la_mutex;
 LaDevice g_la_dev[64];
 int64_t g_la_min_rows = 2048;     // tuning knob (gpk_tune(6, v)): overlap while the trailing matrix has >= this many rows
-int64_t g_la_tail_rows = 5120;    // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path
+int64_t g_la_tail_rows = 6144;    // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path
 int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
 int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
 int g_la_mode = 1;                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
@@ -618,6 +619,10 @@ int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb) {
 }
 
 template <typename T>
+static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
+                         hipStream_t stream);
+
+template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
                         hipStream_t stream) {
     if (n <= 0) return GPK_OK;
@@ -629,6 +634,28 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     std::lock_guard<std::mutex> lock(g_la_mutex);
     LaDevice* dev = la_device();
     if (dev == nullptr) return GPK_ERR_LAUNCH;
+    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, ws, info, stream);
+
+    // The legacy default stream (what torch's default stream is) synchronises implicitly with every BLOCKING
+    // stream -- and the CU-masked helper stream is one (hipExtStreamCreateWithCUMask takes no flags): each
+    // launch on either would wait for the other, the overlap would be gone and then some (measured: 56 instead
+    // of 41 ms per eval).  So a private non-blocking stream stands in for it: forked from the default stream
+    // here, joined to it at the end; nothing else is enqueued on the default stream in between.
+    if (dev->priv == nullptr && hipStreamCreateWithFlags(&dev->priv, hipStreamNonBlocking) != hipSuccess) {
+        dev->priv = nullptr;
+        return GPK_ERR_LAUNCH;
+    }
+    hipEvent_t e_in = la_event(*dev, 0), e_out = la_event(*dev, 1);
+    if (e_in == nullptr || e_out == nullptr) return GPK_ERR_LAUNCH;
+    if (hipEventRecord(e_in, nullptr) != hipSuccess || hipStreamWaitEvent(dev->priv, e_in, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, ws, info, dev->priv);
+    if (hipEventRecord(e_out, dev->priv) != hipSuccess || hipStreamWaitEvent(nullptr, e_out, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+    return st;
+}
+
+template <typename T>
+static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
+                         hipStream_t stream) {
     unsigned* ctrl = reinterpret_cast<unsigned*>(ws);                   // 64 elements reserved
     // n x nb, leading dimension nb + 16: with a power-of-two pitch the rows of a tile sit on a few memory channels and
     // the panel GEMM, which streams this buffer once, crawls (measured 2x)
@@ -637,7 +664,7 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     T* tmp = Tp + (n > nb ? n : nb) * ldt;
     const int64_t nblk = gpk_cdiv(n, nb);
     const int64_t per = (int64_t)nb * nb;
-    size_t ev = 0;
+    size_t ev = 2;                       // (events 0 and 1 belong to the default-stream stand-in)
 
     // Small matrices, and the tail of big ones, are chain-bound: there the plain right-looking recursion
     // (no explicit block inverse, no separate panel GEMM) is faster -- measured crossover ~5000 rows.
