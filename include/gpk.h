@@ -253,6 +253,9 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);
+/* device buffer (grid x 8 tiles x 4 int64, or NULL): wall-clock stamps (10 ns ticks) of the persistent update's tiles:
+ * entry / C tile requested / k loop done / stores retired. */
+void gpk_tune_tile_prof(long long* dev_buf);
 
 /* Strided 2-D copy (rows x cols). */
 int gpk_copy2d(int dtype, const void* src, int64_t lds, int64_t ss, void* dst, int64_t ldd, int64_t sd,

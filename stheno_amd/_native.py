@@ -43,6 +43,7 @@ SIGNATURES = {
     "gpk_gemm_update2": (_c_int, [_c_int, _c_ptr, _c_int, _c_dbl, _c_ptr, _c_int, _c_ptr]),
     "gpk_tune": (None, [_c_int, _c_i64]),
     "gpk_tune_diag_prof": (None, [_c_ptr]),
+    "gpk_tune_tile_prof": (None, [_c_ptr]),
     "gpk_trtri_merge": (
         _c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]
     ),

@@ -82,6 +82,8 @@ void gpk_tune(int key, int64_t value) {
 
 void gpk_tune_diag_prof(long long* dev_buf) { gpk_set_diag_prof(dev_buf); }
 
+void gpk_tune_tile_prof(long long* dev_buf) { gpk_set_tile_prof(dev_buf); }
+
 int gpk_trtri_merge(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
                     const void* dinv128, int sb, void* dinv_sb, void* tmp, void* stream) {
     D1(dtype, gpk_trtri_merge_launch<T>((const T*)l, n, ld, batch, sl, (const T*)dinv128, sb, (T*)dinv_sb,

@@ -134,6 +134,7 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
 void gpk_tune_gemm(int key, int64_t value);
 void gpk_tune_potrf(int key, int64_t value);
 void gpk_set_diag_prof(long long* dev_buf);
+void gpk_set_tile_prof(long long* dev_buf);
 
 template <typename T>
 int gpk_copy2d_launch(const T* src, int64_t lds, int64_t ss, T* dst, int64_t ldd, int64_t sd,

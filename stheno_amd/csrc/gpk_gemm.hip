@@ -218,7 +218,9 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // 2 * (1 + NCT) * op_bytes(TS) bytes of LDS, free on entry; every wave has passed a barrier after its
 // last LDS read when the function returns.
 template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT>
-__device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
+                                          long long* prof = nullptr) {
+    if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
@@ -354,6 +356,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, PF2 ? 1 : 0> S1;
 
+    if (prof != nullptr && threadIdx.x == 0) prof[1] = wall_clock64();      // C tile requested, accumulators being initialised
     if (PF2) {
         issue(S0{}, kc0);
         if (kc0 + 1 < nk) issue(S1{}, kc0 + 1);
@@ -385,6 +388,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         }
     }
 
+    if (prof != nullptr && threadIdx.x == 0) prof[2] = wall_clock64();      // k loop done
     // (in-place use: every global read of this workgroup's rows of A happened above)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -399,6 +403,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                     if (!EDGE || (row < p.M && col < p.N))
                         C[(int64_t)row * p.ldc + col] = p.alpha * acc[c][fi][fj][i];
                 }
+    if (prof != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);          // (profiling only) stores retired
+        if (threadIdx.x == 0) prof[3] = wall_clock64();
+    }
 }
 
 // NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
@@ -435,6 +443,7 @@ struct PersistArgs {
     int reserve;
     int max_leave;
     unsigned rkeys[8];
+    long long* prof;          // development aid: 4 stamps for each of the first 8 tiles of every workgroup (nullable)
 };
 
 template <typename T, int TS, bool EDGE>
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_kernel(
         if (s_tile < 0) return;
         __syncthreads();
     }
-    int t = 0;
+    int t = 0, nlocal = 0;
     if (tid == 0) s_tile = (int)atomicAdd(&p.ctrl[0], 1u);
     __syncthreads();
     t = __builtin_amdgcn_readfirstlane(s_tile);     // uniform by construction; tell the compiler (scalar loads of the segment)
@@ -488,9 +497,11 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_kernel(
             ok = decode_tile(g, tl, ti, tj);
         }
         if (ok) {
+            long long* pr = (p.prof != nullptr && nlocal < 8) ? p.prof + ((int64_t)blockIdx.x * 8 + nlocal) * 4 : nullptr;
+            ++nlocal;
 #pragma unroll 1
             for (int r = 0; r < reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
-                gemm_tile<T, TS, true, true, EDGE, 1>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem);
+                gemm_tile<T, TS, true, true, EDGE, 1>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem, pr);
         }
         if (tid == 0) s_tile = nxt;
         __syncthreads();
@@ -547,6 +558,7 @@ int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: 
 }  // namespace
 
 namespace {
+long long* g_tile_prof = nullptr;       // development aid (gpk_tune_tile_prof)
 int64_t g_persist_small_below = 512;   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
 int g_cu_count[64] = {0};
 int device_cus() {
@@ -560,6 +572,8 @@ int device_cus() {
     return g_cu_count[dev];
 }
 }  // namespace
+
+void gpk_set_tile_prof(long long* dev_buf) { g_tile_prof = dev_buf; }
 
 // Tuning knobs of this file (gpk_tune in include/gpk.h): A/B runs on the GPU box.
 void gpk_tune_gemm(int key, int64_t value) {
@@ -837,6 +851,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     if (total > INT32_MAX / 2) return GPK_ERR_ARG(1);
     pa.ntiles = (int)total;
     pa.ctrl = ctrl;
+    pa.prof = g_tile_prof;
     if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
 
     const int per_cu = (ts == 128) ? 2 : 4;

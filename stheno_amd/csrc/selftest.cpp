@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <random>
 #include <string>
@@ -1198,6 +1199,43 @@ static void dispatch_experiment() {
     }
 }
 
+
+// where does a tile of the persistent trailing update spend its time?   --tileprof
+static void tile_profile() {
+    const int n = 15360, k = 1024, grid = 512;
+    Dev<double> P((size_t)n * k), C((size_t)n * n);
+    Dev<unsigned> ctrl(32);
+    Dev<long long> prof((size_t)grid * 8 * 4);
+    P.up(randv<double>((size_t)n * k, 0.01)); C.zero();
+    Timer tm;
+    for (int rep = 0; rep < 2; ++rep) {
+        prof.zero();
+        gpk_tune_tile_prof(rep ? prof.p : nullptr);
+        gpk_update_t u{n, n, k, P.p, k, P.p, k, C.p, n, C.p, n, 1};
+        tm.start();
+        gpk_gemm_update2(GPK_F64, &u, 1, -1.0, ctrl.p, 0, nullptr);
+        const float ms = tm.stop();
+        printf("TILEPROF update 15360^2 lower k=1024 %s: %.3f ms\n", rep ? "with stamps" : "plain", ms);
+    }
+    gpk_tune_tile_prof(nullptr);
+    auto h = prof.down();
+    for (int ti = 0; ti < 8; ++ti) {
+        double a = 0, b = 0, c = 0, gap = 0; int cnt = 0, cg = 0;
+        for (int w = 0; w < grid; ++w) {
+            const long long* q = &h[((size_t)w * 8 + ti) * 4];
+            if (q[3] == 0) continue;
+            a += (q[1] - q[0]) * 0.01; b += (q[2] - q[1]) * 0.01; c += (q[3] - q[2]) * 0.01; ++cnt;
+            if (ti > 0) { const long long* pq = &h[((size_t)w * 8 + ti - 1) * 4]; gap += (q[0] - pq[3]) * 0.01; ++cg; }
+        }
+        if (cnt) printf("TILEPROF tile #%d of a workgroup (%d workgroups): request C %.1f us | k loop (incl. C arrival, first chunk) %.1f us | stores retired %.1f us | gap to previous tile %.1f us\n",
+                        ti, cnt, a / cnt, b / cnt, c / cnt, cg ? gap / cg : 0.0);
+    }
+    // start-time spread of the first tiles and of the last stamps
+    long long t0 = LLONG_MAX, t1 = 0, e0 = LLONG_MAX, e1 = 0;
+    for (int w = 0; w < grid; ++w) { const long long* q = &h[(size_t)w * 8 * 4]; if (q[3]) { t0 = std::min(t0, q[0]); t1 = std::max(t1, q[0]); } }
+    printf("TILEPROF first tiles start within %.1f us of each other\n", (t1 - t0) * 0.01);
+}
+
 // experiment: CU-masked streams (does a reserved CU let a small kernel overlap a big GEMM?)
 static void cumask_experiment() {
     const int n = 8192;
@@ -1365,6 +1403,7 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--cumask")) { cumask_experiment(); return 0; }
         if (!strcmp(argv[i], "--dispatch")) { dispatch_experiment(); return 0; }
+        if (!strcmp(argv[i], "--tileprof")) { tile_profile(); return 0; }
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
             rsq_precision();

@@ -117,6 +117,8 @@ def main():
     dense_case("dense_eq_linear_n512_d4", [("eq", 1.0, 1.0), ("linear", 1.0, 1.0)], 512, 4, 96, 0.1, 5)
     batched_case("batched_eq_b16_n100_d3", [("eq", 2.0, 0.5)], 16, 100, 3, 0.1, 6)
     sparse_case("sparse_eq_n400_m50_d2", [("eq", 1.0, 1.0)], 400, 50, 2, 30, 0.1, 7)
+    sparse_case("sparse_matern32_linear_n300_m40_d3", [("matern32", 1.2, 0.9), ("linear", 0.4, 2.0)], 300, 40, 3, 25, 0.2, 8)
+    sparse_case("sparse_matern52_n350_m45_d2", [("matern52", 0.8, 1.1)], 350, 45, 2, 25, 0.15, 9)
 
 
 if __name__ == "__main__":

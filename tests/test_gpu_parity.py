@@ -176,8 +176,9 @@ def test_batched_golden(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
-def test_sparse_golden(dtype):
-    g = golden("sparse_eq_n400_m50_d2.npz")
+@pytest.mark.parametrize("name", ["sparse_eq_n400_m50_d2", "sparse_matern32_linear_n300_m40_d3", "sparse_matern52_n350_m45_d2"])
+def test_sparse_golden(name, dtype):
+    g = golden(name + ".npz")
     # fp32 runs at the reference's own fp32 jitter (1e-6, README.md:887-888) and is held to the 1e-3 bar against the
     # oracle evaluated in fp64 at the SAME epsilon (the bound and the posterior depend on the jitter: K_z of 50
     # clustered inducing points has kappa ~ 1e8; the fixture itself was made with 1e-10).
@@ -186,7 +187,7 @@ def test_sparse_golden(dtype):
     terms = list(zip(g["kinds"], g["variances"], g["scales"]))
     with eps(e):
         m = st.Measure()
-        f = st.GP(st.EQ(), measure=m)
+        f = st.GP(kernel_from(g), measure=m)
         x, z, xs, y = (dev(g[k], dtype) for k in ("x", "z", "xs", "y"))
         for cls, tag in [(st.PseudoObs, "vfe"), (st.PseudoObsFITC, "fitc"), (st.PseudoObsDTC, "dtc")]:
             obs = cls(f(z), f(x, float(g["noise"])), y)
@@ -203,7 +204,7 @@ def test_sparse_golden(dtype):
             assert rel(mean, ref_mean) < max(tol, 1e-5)
             assert rel(vd, np.maximum(ref_vd, 0)) < max(tol, 1e-5)
         with pytest.raises(RuntimeError):
-            st.PseudoObs(f(z), (f(x, torch.eye(400, dtype=dtype, device=DEV)), y)).elbo(m)
+            st.PseudoObs(f(z), (f(x, torch.eye(x.shape[0], dtype=dtype, device=DEV)), y)).elbo(m)
 
 
 def test_readme_known_answers():

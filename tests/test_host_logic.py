@@ -285,12 +285,14 @@ def test_pseudoobs_exact_when_inducing_equals_inputs(cls, noise_form):
         cls(p(x), (p(x, B.dense(p(x).var)), y)).elbo(m)
 
 
-def test_sparse_golden_through_the_api():
-    g = golden("sparse_eq_n400_m50_d2.npz")
+@pytest.mark.parametrize("name", ["sparse_eq_n400_m50_d2", "sparse_matern32_linear_n300_m40_d3", "sparse_matern52_n350_m45_d2"])
+def test_sparse_golden_through_the_api(name):
+    g = golden(name + ".npz")
+    kinds = {"eq": st.EQ, "matern12": st.Matern12, "matern32": st.Matern32, "matern52": st.Matern52, "linear": st.Linear}
     B.epsilon = float(g["epsilon"])
     try:
         m = st.Measure()
-        f = st.GP(st.EQ(), measure=m)
+        f = st.GP(sum(float(v) * kinds[str(kd)]().stretch(float(sc)) for kd, v, sc in zip(g["kinds"], g["variances"], g["scales"])), measure=m)
         x, z, xs, y = (t(g[k]) for k in ("x", "z", "xs", "y"))
         for cls, tag in [(st.PseudoObs, "vfe"), (st.PseudoObsFITC, "fitc"), (st.PseudoObsDTC, "dtc")]:
             obs = cls(f(z), f(x, float(g["noise"])), y)
