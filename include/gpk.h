@@ -249,7 +249,9 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * measured optima, the product path never calls these.  key 1: use 64x64 GEMM tiles below this many 128-tiles;
  * 2: XCD super-tile order from this many tiles; 4: row-pair tile order from this many tiles; 6: look-ahead overlaps while the trailing matrix has at least this many
  * rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the persistent update takes 64x64 tiles
- * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm.
+ * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm;
+ * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
+ * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup.
  * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);

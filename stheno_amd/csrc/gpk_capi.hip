@@ -78,6 +78,7 @@ int gpk_init(void) {
 void gpk_tune(int key, int64_t value) {
     gpk_tune_gemm(key, value);
     gpk_tune_potrf(key, value);
+    gpk_tune_kmat(key, value);
 }
 
 void gpk_tune_diag_prof(long long* dev_buf) { gpk_set_diag_prof(dev_buf); }

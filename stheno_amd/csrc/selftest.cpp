@@ -944,6 +944,43 @@ static void la_one(int n, int nb, int mode, int64_t minrows, int reps, int ldpad
     }
 }
 
+
+// kernel-matrix kernel alone, the shapes of the four GPU configs:  --perf-kmat
+template <typename T>
+static void perf_kmat_case(const char* nm, int nterms, const int* kinds, int64_t n, int64_t m, int d, int batch, int lower) {
+    const bool sym = (m == 0);
+    if (sym) m = n;
+    auto hx = randv<T>((size_t)batch * n * d);
+    Dev<T> X(hx.size()), Y(sym ? 1 : (size_t)m * d), K((size_t)batch * n * m);
+    X.up(hx);
+    if (!sym) Y.up(randv<T>((size_t)m * d));
+    double var[2] = {1.0, 1.0}, il[2] = {1.0, 1.0};
+    Timer tm;
+    for (int band = 1; band >= 0; --band) {
+        gpk_tune(12, band);
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            tm.start();
+            gpk_kmat(DT<T>::v, kinds, var, il, nterms, X.p, n, d, n * d, sym ? X.p : Y.p, m, d, sym ? n * d : 0, d, K.p, m, n * m, batch, lower, sym ? 1 : 0, 0.1, nullptr, 0, 0, nullptr);
+            const float ms = tm.stop();
+            if (rep) best = std::min(best, ms);
+        }
+        const double bytes = (lower ? 0.5 : 1.0) * batch * (double)n * m * sizeof(T);
+        printf("PERFKMAT %-28s %s %s  %.3f ms  %.2f TB/s (%s bytes)\n", nm, DT<T>::name(), band ? "row-band kernel" : "tile kernel    ", best, bytes / best * 1e-9, lower ? "lower" : "all");
+    }
+    gpk_tune(12, 1);
+}
+static void perf_kmat() {
+    const int eq[1] = {GPK_K_EQ}, eql[2] = {GPK_K_EQ, GPK_K_LINEAR}, m52[1] = {GPK_K_MATERN52};
+    perf_kmat_case<double>("cfg2 N=16384 D=8 EQ lower", 1, eq, 16384, 0, 8, 1, 1);
+    perf_kmat_case<float>("N=16384 D=8 EQ lower", 1, eq, 16384, 0, 8, 1, 1);
+    perf_kmat_case<float>("cfg3 N=32768 D=4 EQ+Lin lower", 2, eql, 32768, 0, 4, 1, 1);
+    perf_kmat_case<float>("cfg4 512xN=2048 D=3 EQ lower", 1, eq, 2048, 0, 3, 512, 1);
+    perf_kmat_case<float>("cfg5 4096x200000 D=8 EQ", 1, eq, 4096, 200000, 8, 1, 0);
+    perf_kmat_case<double>("N=16384 D=8 Matern52 lower", 1, m52, 16384, 0, 8, 1, 1);
+    perf_kmat_case<float>("N=16384x2048 D=8 EQ (K_x*)", 1, eq, 16384, 2048, 8, 1, 0);
+}
+
 // one problem, for rocprofv3: kmat + potrf (+ trsv, merge, trsm) at order n
 template <typename T>
 static void profile_one(int n, int nbo, int reps) {
@@ -1424,6 +1461,12 @@ int main(int argc, char** argv) {
             return 0;
         }
         if (!strcmp(argv[i], "--census")) { census(); return 0; }
+        if (!strcmp(argv[i], "--perf-kmat")) { perf_kmat(); return 0; }
+        if (!strcmp(argv[i], "--kmat")) {                      // only the kernel-matrix checks, both kernels
+            for (int band = 1; band >= 0; --band) { gpk_tune(12, band); test_kmat<double>(); test_kmat<float>(); }
+            printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
+            return g_fail ? 1 : 0;
+        }
         if (!strcmp(argv[i], "--lookahead")) {                 // only the look-ahead / persistent-update checks
             test_lookahead<double>(); test_lookahead<float>();
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
