@@ -63,6 +63,11 @@ int gpk_version(void);
  * not happen inside a stream capture. */
 int gpk_init(void);
 
+/* Destroy the helper streams and events again (idempotent; they are re-created on demand).  Call it before the process
+ * exits (the Python binding registers it with atexit): a CU-masked stream that is still alive at exit can crash the
+ * teardown of the runtime / of a profiler wrapped around the process. */
+void gpk_shutdown(void);
+
 /* Kernel matrix  out[i][j] (+)= sum_t variances[t] * kappa_kinds[t](x_i, y_j; inv_ls[t])
  * and, if `symmetric` (x and y are the same points), + diag_add + diag_vec[i] on i == j.
  * Replaces mlkernels `pairwise` + `B.add(K, noise)`:  stheno/model/fdd.py:79,
@@ -251,7 +256,8 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the persistent update takes 64x64 tiles
  * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm;
  * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
- * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup.
+ * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 13: column-major GEMM tile order from this ratio of
+ * tile columns to tile rows (off by default).
  * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);

@@ -16,8 +16,9 @@ cmd = [sys.executable, os.path.join(repo, "bench.py"), "--workload", workload, "
 
 def one_pass(counter):
     d = f"/tmp/pmc_{workload}_{counter}"
+    # (no check=True: the counters are written before the wrapped process tears down)
     subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                   check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = {}
     for r in csv.DictReader(open(f)):

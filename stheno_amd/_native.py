@@ -24,6 +24,7 @@ DIAG_BLOCK = 128
 SIGNATURES = {
     "gpk_version": (_c_int, []),
     "gpk_init": (_c_int, []),
+    "gpk_shutdown": (None, []),
     "gpk_dinv_elems": (_c_i64, [_c_i64]),
     "gpk_colreduce_chunks": (_c_i64, [_c_i64]),
     "gpk_kmat": (
@@ -121,4 +122,7 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
         _LIB = lib
+        import atexit
+
+        atexit.register(lib.gpk_shutdown)      # helper streams must not outlive the HIP runtime's own teardown
     return _LIB

@@ -68,6 +68,61 @@ class _GPLogpdf(torch.autograd.Function):
         return (None, grad_r, grad_noise, None, *grads)
 
 
+class _GPLogpdfBatched(torch.autograd.Function):
+    """The same for stheno's batched computation (``README.md:744-766``): ``x`` (B, N, D), ``r`` (B, N, 1), optional
+    per-point noise (B, N), hyper-parameters SHARED by the B independent GPs -- learning over a batch of data sets
+    (the configuration that shards over GPUs).  Forward = the batched HIP path (one launch sequence for all B);
+    backward walks the batch: ``K_b^{-1}`` from the stored factor of entry b, one ``gpk_kmat_vjp`` pass, sums over b."""
+
+    @staticmethod
+    def forward(ctx, x, r, noise_vec, kinds, *params):
+        be = ops.get_backend()
+        nt = len(kinds)
+        variances, scales = params[:nt], params[nt:]
+        terms = ops.KTerms([(k, float(v), float(s)) for k, v, s in zip(kinds, variances, scales)])
+        n = r.shape[-2]
+        k = be.kmat(terms, x, None, lower=True, diag_add=config.epsilon, diag_vec=noise_vec)
+        chol = Chol.factor_(k)
+        w = chol.solve(r)                                        # (B, N, 1)
+        _, ss = be.colreduce(w, want_ss=True)                    # (B, 1)
+        out = -(chol.logdet() + n * LOG_2_PI + ss[..., 0]) / 2   # (B,)
+        ctx.chol, ctx.w, ctx.x, ctx.terms = chol, w, x, terms
+        ctx.nt, ctx.has_noise = nt, noise_vec is not None
+        ctx.param_meta = [(p.device, p.dtype) for p in params]
+        ctx.values = ([float(v) for v in variances], [float(s) for s in scales])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        be = ops.get_backend()
+        chol, w, x, terms, nt = ctx.chol, ctx.w, ctx.x, ctx.terms, ctx.nt
+        B = x.shape[0]
+        g_host = [float(v) for v in grad_out.reshape(-1).tolist()]            # host sync: B scalars
+        S_tot = None
+        grad_r = torch.empty_like(w)
+        grad_noise = torch.empty(w.shape[:-1], dtype=w.dtype, device=w.device) if ctx.has_noise else None
+        for b in range(B):
+            sl = lambda t: None if t is None else t[b:b + 1]      # noqa: E731
+            cb = Chol(chol.l[b], sl(chol.dinv), sl(chol.info))                 # entry b as an unbatched factor (views)
+            W = cb.inverse_lower()
+            kinv = be.gemm(W, W, a_kmajor=False, b_kmajor=False, lower_only=True, tri_k=True)
+            alpha = be.colreduce(W, w[b, :, 0], want_dot=True, want_ss=False)[0][:, None]
+            S, _, diag_g = be.kmat_vjp(terms, x[b], kinv, alpha, [g_host[b]])
+            S_tot = S if S_tot is None else S_tot + S
+            grad_r[b] = -alpha * g_host[b]
+            if grad_noise is not None:
+                grad_noise[b] = diag_g
+        variances, scales = ctx.values
+        grads = []
+        for t in range(nt):
+            dev, dt = ctx.param_meta[t]
+            grads.append(S_tot[t, 0].to(device=dev, dtype=dt))
+        for t in range(nt):
+            dev, dt = ctx.param_meta[nt + t]
+            grads.append((-2.0 * variances[t] / scales[t] * S_tot[t, 1]).to(device=dev, dtype=dt))
+        return (None, grad_r, grad_noise, None, *grads)
+
+
 def needs_grad(tensor_terms, noise_vec, r):
     if not torch.is_grad_enabled():
         return False
@@ -104,6 +159,8 @@ def gp_logpdf(kernel, x, noise_vec, r):
     kinds = tuple(k for k, _, _ in tt)
     as_t = lambda v: v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64)  # noqa: E731
     params = [as_t(v) for _, v, _ in tt] + [as_t(s) for _, _, s in tt]
+    if x.dim() == 3:
+        return _GPLogpdfBatched.apply(x, r, noise_vec, kinds, *params)
     return _GPLogpdf.apply(x, r, noise_vec, kinds, *params)
 
 

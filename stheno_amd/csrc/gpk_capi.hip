@@ -75,6 +75,11 @@ int gpk_init(void) {
     return gpk_helper_stream(&aux, keys);
 }
 
+void gpk_shutdown(void) {
+    gpk_potrf_shutdown();
+    gpk_helper_shutdown();
+}
+
 void gpk_tune(int key, int64_t value) {
     gpk_tune_gemm(key, value);
     gpk_tune_potrf(key, value);

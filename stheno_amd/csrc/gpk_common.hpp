@@ -105,6 +105,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
 // The library's helper stream (one per device, created on first use): masked to one CU per XCD; keys[x] = the
 // HW_ID key (+1) of that CU on XCD x, 0 if nothing is reserved.
 int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]);
+void gpk_helper_shutdown();
+void gpk_potrf_shutdown();
 template <typename T>
 struct GpkSeg {
     int64_t M, N, K;

@@ -61,6 +61,7 @@ struct GemmArgs {
     int tri_k_lo;     // A (M x K) is lower triangular (zero for k > row): stop at k = m0 + TS; tile rows run
                       // longest-first (bottom rows first)
     int tri_k_lo_b;   // B (N x K) is lower triangular (zero for k > column index n): stop at k = n0 + tile width
+    int colmajor;     // column-major tile order (rectangular problems with many more tile columns than tile rows)
     int pair_cols;    // persistent kernel, tri_k_lo_b: one task = column tiles c and tiles_n - 1 - c of a tile row
     int swizzle;
     int tri_pairs;    // triangular enumeration by row pairs / 8-column chunks (see decode_tile)
@@ -110,6 +111,13 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
             tj = p.tiles_n - 1 - bid / p.tiles_m;
             ti = bid - (bid / p.tiles_m) * p.tiles_m;
             return tj >= 0;
+        }
+        if (p.colmajor) {     // few tile rows, many tile columns: walk down the columns, so that the (large) B operand is
+                              // streamed once while the (small) A operand stays in the L2s
+            tj = bid / p.tiles_m;
+            ti = bid - tj * p.tiles_m;
+            if (p.tri_k_lo) ti = p.tiles_m - 1 - ti;
+            return tj < p.tiles_n && (!p.lower_only || tj <= ti);
         }
         ti = bid / p.tiles_n;
         tj = bid - ti * p.tiles_n;
@@ -559,6 +567,8 @@ int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: 
 
 namespace {
 long long* g_tile_prof = nullptr;       // development aid (gpk_tune_tile_prof)
+int g_colmajor_ratio = INT32_MAX;       // tuning knob (gpk_tune(13, v)): column-major tile order from this many times more tile columns than
+                                        // rows -- OFF: measured 87 vs 64 ms per cfg5 step although it cuts the fabric-side re-reads of K_zx
 int64_t g_persist_small_below = 512;   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
 int g_cu_count[64] = {0};
 int device_cus() {
@@ -581,6 +591,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 2) g_swizzle_from = (int)value;
     if (key == 4) g_tri_pairs_from = (int)value;
     if (key == 8) g_persist_small_below = value;
+    if (key == 13) g_colmajor_ratio = (int)value;
 }
 
 extern "C" int gpk_prof_start(void) {
@@ -658,10 +669,12 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.tri_k_lo = (flags & 4) ? 1 : 0;
     g.tri_k_lo_b = (flags & 8) ? 1 : 0;
     g.pair_cols = 0;
+    g.colmajor = 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
                                      : (int64_t)g.tiles_m * g.tiles_n;
+    g.colmajor = (!lower_only && !g.tri_k_lo_b && g.tiles_n >= g_colmajor_ratio * g.tiles_m) ? 1 : 0;
     int64_t gridx;
     g.swizzle = (total >= g_swizzle_from) ? 1 : 0;
     g.n_super = 0;
@@ -691,7 +704,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     ProfSlot* slot = nullptr;
     if (g_prof.on) {
         // useful (algorithmic) flops: a lower-only update counts the symmetric half
-        const double fl = (lower_only ? 1.0 : 2.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
+        // (a triangular operand halves the multiply-adds actually needed: the TRSM / TRMM count)
+        const double fl = (lower_only ? 1.0 : 2.0) * ((flags & (2 | 4 | 8)) ? 0.5 : 1.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
         slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), fl, stream);
     }
     if (nct == 2) {
@@ -792,6 +806,24 @@ int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]) {
     return GPK_OK;
 }
 
+// Destroy the helper streams (gpk_shutdown): a process that exits with a CU-masked stream still alive can crash in
+// the runtime's / a profiler's own teardown (seen with rocprofv3 around a torch process).
+void gpk_helper_shutdown() {
+    std::lock_guard<std::mutex> lock(g_helper_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int dev = 0; dev < 64; ++dev) {
+        HelperDev& h = g_helper[dev];
+        if (h.aux != nullptr) {
+            (void)hipSetDevice(dev);
+            (void)hipStreamSynchronize(h.aux);
+            (void)hipStreamDestroy(h.aux);
+        }
+        h = HelperDev();
+    }
+    (void)hipSetDevice(cur);
+}
+
 // ---- persistent launch: up to two k-major problems  C = Cin + alpha * A B^T  in one resident grid ----
 
 
@@ -832,6 +864,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         g.tiles_m = (int)gpk_cdiv(q.M, ts); g.tiles_n = (int)gpk_cdiv(q.N, ts);
         g.lower_only = q.lower_only ? 1 : 0;
         g.tri_k = g.tri_k_lo = 0;
+        g.colmajor = 0;
         g.tri_k_lo_b = q.tri_b ? 1 : 0;
         g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1;
         const bool aligned = ((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && (q.lda % VEC == 0) &&

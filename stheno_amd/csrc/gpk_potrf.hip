@@ -605,6 +605,24 @@ int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tm
 
 }  // namespace
 
+void gpk_potrf_shutdown() {
+    std::lock_guard<std::mutex> lock(g_la_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int dev = 0; dev < 64; ++dev) {
+        LaDevice& d = g_la_dev[dev];
+        if (d.aux == nullptr && d.priv == nullptr && d.events.empty()) continue;
+        (void)hipSetDevice(dev);
+        if (d.priv != nullptr) {
+            (void)hipStreamSynchronize(d.priv);
+            (void)hipStreamDestroy(d.priv);
+        }
+        for (hipEvent_t e : d.events) (void)hipEventDestroy(e);
+        d = LaDevice();             // (the helper stream itself belongs to gpk_helper_shutdown)
+    }
+    (void)hipSetDevice(cur);
+}
+
 void gpk_tune_potrf(int key, int64_t value) {
     if (key == 6) g_la_min_rows = value;
     if (key == 7) g_la_mode = (int)value;

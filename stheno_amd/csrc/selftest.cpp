@@ -198,6 +198,8 @@ static void test_gemm() {
     test_gemm_case<T>(true, true, 5 * 128 + 17, 5 * 128 + 17, 128, -1, 1, 2, true, 0);
     test_gemm_case<T>(true, true, 4352, 4352, 32, -1, 1, 1, true, 0);    // 34x34 tiles -> XCD super-tile path
     test_gemm_case<T>(true, false, 4224, 4224, 32, 1, 0, 1, false, 0);   // 33x33 tiles, rectangular super-tiles
+    test_gemm_case<T>(true, false, 300, 3000, 40, 1, 1, 1, false, 1);    // many more tile columns than rows: column-major tile order
+    test_gemm_case<T>(true, true, 260, 2100, 33, -1, 0, 2, false, 0);
 }
 
 // ----------------------------------------------------------------------------

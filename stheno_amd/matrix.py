@@ -385,11 +385,11 @@ class KernelDense(Dense):
         raise TypeError(f"unsupported noise type {type(noise).__name__}")
 
     def differentiable_noise(self):
-        """The noise as a vector (n,) (or ``None``) if it is diagonal, else ``NotImplemented``."""
+        """The noise as a vector (n,) -- (B, n) for batched inputs -- or ``None`` if it is diagonal, else ``NotImplemented``."""
         noise = self.noise
         if noise is None or isinstance(noise, Zero):
             return None
-        if isinstance(noise, Diagonal) and noise.diag().dim() == 1:
+        if isinstance(noise, Diagonal) and noise.diag().dim() in (1, 2):
             return noise.diag()
         return NotImplemented
 

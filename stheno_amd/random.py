@@ -234,16 +234,22 @@ class Normal(RandomVector):
         n = self.dim
         r = x - self.mean
         # hyper-parameter learning: differentiable path for a kernel-matrix variance
-        if isinstance(var, KernelDense) and r.dim() == 2:
+        batched_ok = (r.dim() == 3 and r.shape[-1] == 1 and torch.is_tensor(getattr(var, "x", None)) and var.x.dim() == 3
+                      and tuple(var.x.shape[:-2]) == tuple(r.shape[:-2]))
+        if isinstance(var, KernelDense) and (r.dim() == 2 or batched_ok):
             from . import autograd as _ag
 
             noise_vec = var.differentiable_noise()
+            if noise_vec is not None and noise_vec is not NotImplemented and noise_vec.dim() != r.dim() - 1:
+                noise_vec = NotImplemented
             tt = var.kernel.tensor_terms()
             if torch.is_grad_enabled() and _x_requires_grad(var.x):
                 raise NotImplementedError("gradients with respect to the inputs x of a GP are not implemented "
                                           "(detach x, or wrap the call in torch.no_grad())")
             if noise_vec is not NotImplemented and tt is not None and _ag.needs_grad(tt, noise_vec, r):
                 lp = _ag.gp_logpdf(var.kernel, var.x, noise_vec, r)
+                if r.dim() == 3:
+                    return lp
                 return lp[0] if lp.shape[0] == 1 else lp
         if torch.is_grad_enabled() and isinstance(var, KernelDense):
             from . import autograd as _ag
@@ -253,8 +259,8 @@ class Normal(RandomVector):
                                                                                and nz.mat.requires_grad)
             if noisy or r.requires_grad or _x_requires_grad(var.x) or _ag.kernel_requires_grad(var.kernel):
                 raise NotImplementedError(
-                    "gradients of logpdf are implemented for one unbatched process whose kernel is a sum of "
-                    "primitives with scalar or per-point noise; this call (batched, multi-process, posterior or "
+                    "gradients of logpdf are implemented for one process (or one batch of independent data sets) whose kernel "
+                    "is a sum of primitives with scalar or per-point noise; this call (multi-process, posterior or "
                     "dense-noise) would return a value cut off from the autograd graph -- wrap it in torch.no_grad() "
                     "if that is intended"
                 )

@@ -240,8 +240,10 @@ def test_elbo_gradients_unsupported_cases_are_loud(oracle_backend):
     v = torch.tensor(1.0, dtype=torch.float64, requires_grad=True)
     f = st.GP(v * st.EQ())
     # logpdf cases outside the differentiable path refuse instead of returning a detached value
-    with pytest.raises(NotImplementedError):        # batched
-        f(torch.randn(3, 20, 2, dtype=torch.float64), 0.1).logpdf(torch.randn(3, 20, 1, dtype=torch.float64))
+    lp_b = f(torch.randn(3, 20, 2, dtype=torch.float64), 0.1).logpdf(torch.randn(3, 20, 1, dtype=torch.float64))
+    assert lp_b.shape == (3,) and lp_b.requires_grad        # batched: differentiable since round 2 (tests/test_round2_regressions.py)
+    with pytest.raises(NotImplementedError):        # batched with several columns of y is not
+        f(torch.randn(3, 20, 2, dtype=torch.float64), 0.1).logpdf(torch.randn(3, 20, 2, dtype=torch.float64))
     g = st.GP(st.Matern32(), measure=f.measure)
     with pytest.raises(NotImplementedError):        # several processes observed jointly
         f.measure.logpdf((f(x[:7], 0.1), y[:7]), (g(x[7:12], 0.1), y[7:12]))

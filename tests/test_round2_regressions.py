@@ -208,3 +208,41 @@ def test_sharded_bound_refuses_gradients_and_returns_the_reduced_value():
         val = dist.sharded_elbo(obs, m)
     ref = O.pseudo_obs([("eq", 1.0, 0.8)], x, 0.2, y, z)["elbo"]
     assert not val.requires_grad and abs(float(val) - ref) <= 1e-8 * abs(ref)
+
+
+# ------------------------------------------------------------------ gradients through the BATCHED logpdf (README.md:744-766)
+@pytest.mark.parametrize("b,n,d,kinds", [(3, 40, 2, ("eq",)), (8, 300, 3, ("eq", "matern32"))])
+def test_batched_logpdf_gradients(b, n, d, kinds):
+    """Hyper-parameters shared by B independent data sets (the configuration that shards over GPUs): gradients w.r.t.
+    variances, length scales, the noise and y against central finite differences of the oracle, entry by entry."""
+    from .test_autograd import KINDS, fd_grad, logpdf_direct
+
+    rng = np.random.default_rng(b * n)
+    x, y = rng.standard_normal((b, n, d)), rng.standard_normal((b, n, 1))
+    var0, sc0, noise0 = rng.uniform(0.5, 1.5, len(kinds)), rng.uniform(0.7, 1.6, len(kinds)), 0.3
+    wts = rng.uniform(0.5, 1.5, b)
+
+    def oracle(params):
+        v, s, nz = params[: len(kinds)], params[len(kinds): 2 * len(kinds)], params[-1]
+        terms = [(k, v[i], s[i]) for i, k in enumerate(kinds)]
+        return float(sum(wts[i] * logpdf_direct(terms, x[i], nz, y[i]) for i in range(b)))
+
+    p0 = np.concatenate([var0, sc0, [noise0]])
+    ref = fd_grad(oracle, p0)
+    dev = DEVICE[0]
+    vs = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in var0]
+    ss = [torch.tensor(s, dtype=torch.float64, requires_grad=True) for s in sc0]
+    nz = torch.tensor(noise0, dtype=torch.float64, requires_grad=True)
+    ty = torch.tensor(y, dtype=torch.float64, device=dev, requires_grad=True)
+    f = st.GP(sum(v * KINDS[k]().stretch(s) for v, k, s in zip(vs, kinds, ss)))
+    lp = f(T(x), nz.to(dev)).logpdf(ty)
+    assert lp.shape == (b,) and lp.requires_grad
+    assert abs(float((lp.detach().cpu() * torch.tensor(wts)).sum()) - oracle(p0)) <= 1e-7 * abs(oracle(p0))
+    (lp * torch.tensor(wts, device=dev)).sum().backward()
+    got = np.array([float(v.grad) for v in vs] + [float(s.grad) for s in ss] + [float(nz.grad)])
+    assert np.max(np.abs(got - ref)) <= 5e-6 * max(np.max(np.abs(ref)), 1.0), (got, ref)
+    # d/dy of entry 0 in closed form: -w_0 K_0^{-1} y_0 (entries are independent)
+    t0 = [(k, var0[i], sc0[i]) for i, k in enumerate(kinds)]
+    alpha = np.linalg.solve(sum(v * O._kappa(k, ((x[0][:, None, :] - x[0][None, :, :]) ** 2).sum(-1) / s**2, x[0] @ x[0].T / s**2)
+                                for k, v, s in t0) + noise0 * np.eye(n), y[0])
+    assert rel(ty.grad[0], -wts[0] * alpha) < 1e-6
