@@ -202,8 +202,18 @@ __global__ __launch_bounds__(256) void kmat_kernel(KmatArgs<T> p) {
 // ---------------------------------------------------------------------------
 enum { PROG_GENERIC = -1, PROG_EQ = 0, PROG_M12 = 1, PROG_M32 = 2, PROG_M52 = 3, PROG_EQ_LINEAR = 6 };
 
-__device__ __forceinline__ float gpk_exp_neg(float a) {   // exp(a) for a <= 0 via v_exp_f32 (2^x)
-    return __builtin_amdgcn_exp2f(a * 1.44269504088896340736f);
+// exp(a), a <= 0, through v_exp_f32 (2^x) at libm accuracy: the product a * log2(e) is formed with its rounding error
+// (two FMAs), split into an integer and a fraction in [-0.5, 0.5], and only the fraction (plus the error) goes through the
+// hardware 2^x; the integer part is applied exactly by v_ldexp_f32.  (The bare exp2(a * log2e) is 3+ ulp off for |a| ~ 10 --
+// enough to cost the fp32 posterior mean of cfg3 its 1e-3: the solve amplifies kernel-matrix errors by kappa ~ 1e5.)
+__device__ __forceinline__ float gpk_exp_neg(float a) {
+    const float L = 1.44269502162933349609375f, Ll = 1.925963033500011e-8f;     // log2(e) = L + Ll
+    const float t = a * L;
+    float e = fmaf(a, L, -t);
+    e = fmaf(a, Ll, e);
+    const float n = rintf(t);
+    const float f = (t - n) + e;
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 __device__ __forceinline__ double gpk_exp_neg(double a) { return exp(a); }
 
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
             for (int v = 0; v < VEC; ++v) ya[j][v] = w[v];
         }
         const int colb = col0 + lane * VEC;
+        const bool has_diag = p.symmetric && col0 <= row0 + TM - 1 && col0 + TN > row0;   // (uniform) only such tiles touch the diagonal
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int row = row0 + wave * RW + r;
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
                     if (DOT) dt += xr[j] * ya[j][v];
                 }
                 T val = eval_prog<T, PROG>(p, r2, dt);
-                if (p.symmetric && colb + v == row) {
+                if (has_diag && colb + v == row) {
                     val += p.diag_add;
                     if (p.diag_vec != nullptr) val += p.diag_vec[b * p.sDiag + row];
                 }
