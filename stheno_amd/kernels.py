@@ -23,7 +23,7 @@ __all__ = [
     "Kernel", "EQ", "Exp", "Matern12", "Matern32", "Matern52", "Linear", "OneKernel", "ZeroKernel",
     "Mean", "ZeroMean", "OneMean", "PosteriorKernel", "PosteriorMean", "SubspaceKernel",
     "mean_var", "mean_var_diag", "uprank", "num_elements",
-    "MultiInput", "MultiOutputKernel", "MultiOutputMean",
+    "MultiInput", "MultiOutputKernel", "MultiOutputMean", "InputScaled",
 ]
 
 
@@ -185,6 +185,9 @@ class Kernel:
     __rmul__ = __mul__
 
     def stretch(self, scale):
+        """``k.stretch(l)``: ``k(x / l, y / l)``.  ``l``: a scalar, or one length scale per input dimension."""
+        if (torch.is_tensor(scale) and scale.numel() > 1) or isinstance(scale, (list, tuple)):
+            return InputScaled(self, scale)
         return Stretched(self, _as_param(scale))
 
     def __reversed__(self):
@@ -311,6 +314,56 @@ class Stretched(Kernel):
 
     def __repr__(self):
         return f"({self.k!r} > {self.scale})"
+
+
+class InputScaled(Kernel):
+    """``k.stretch(l)`` with one length scale per input dimension (mlkernels' ``Stretched`` with a vector:
+    ``k(x / l, y / l)``).  The inputs are divided once -- O(N D) -- and the inner kernel (a sum of primitives) runs
+    its fused kernel-matrix launch on them, lower-triangle-only / in-place-factorisable like any other; sums of
+    kernels with DIFFERENT per-dimension scales are evaluated term group by term group (``Sum.pairwise``)."""
+
+    def __init__(self, k, scales):
+        if k.terms() is None:
+            raise NotImplementedError("stretch is implemented for sums of primitive kernels")
+        scales = torch.as_tensor(scales)
+        if scales.dim() != 1:
+            raise ValueError("per-dimension length scales are a vector (one entry per input dimension)")
+        if not bool((scales > 0).all()):
+            raise ValueError("length scales must be positive")
+        self.k, self.scales = k, scales
+        self.stationary = k.stationary
+
+    def _scaled(self, x):
+        x = uprank(x)
+        if isinstance(x, MultiInput):
+            raise ValueError("InputScaled is a single-output kernel; it cannot take multi-process inputs")
+        if x.shape[-1] != self.scales.numel():
+            raise ValueError(f"inputs have {x.shape[-1]} dimensions, the kernel has {self.scales.numel()} length scales")
+        if torch.is_grad_enabled() and self.scales.requires_grad:
+            raise NotImplementedError("gradients with respect to per-dimension length scales are not implemented")
+        return x / self.scales.to(dtype=x.dtype, device=x.device)
+
+    def num_outputs(self, x):
+        return self.k.num_outputs(x)
+
+    def pairwise(self, x, y=None, **kw):
+        return self.k.pairwise(self._scaled(x), None if y is None else self._scaled(y), **kw)
+
+    def elwise(self, x, y=None, **kw):
+        if y is not None and y is not x:
+            raise NotImplementedError("elwise is implemented for identical inputs")
+        return self.k.elwise(self._scaled(x), **kw)
+
+    def stretch(self, scale):
+        if (torch.is_tensor(scale) and scale.numel() > 1) or isinstance(scale, (list, tuple)):
+            return InputScaled(self.k, self.scales * torch.as_tensor(scale).to(self.scales))
+        return InputScaled(self.k, self.scales * _as_float(scale))
+
+    def __reversed__(self):
+        return self                      # k(x / l, y / l) of a symmetric k is symmetric
+
+    def __repr__(self):
+        return f"({self.k!r} > {self.scales.tolist()})"
 
 
 def _merge_terms(terms):

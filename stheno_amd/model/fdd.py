@@ -70,7 +70,7 @@ class FDD(Normal):
 
         def var():
             k = p.kernel
-            if k.terms() is not None or isinstance(k, _k.MultiOutputKernel):
+            if k.terms() is not None or isinstance(k, (_k.MultiOutputKernel, _k.InputScaled)):
                 return KernelDense(k, xr, nz)      # K + noise fused, factorised in place
             return k(xr) + nz
 

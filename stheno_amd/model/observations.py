@@ -81,7 +81,7 @@ def _syrk_lower(be, v, out):
 
 def _kernel_matrix(kernel, x, noise):
     """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``)."""
-    if kernel.terms() is not None or isinstance(kernel, _k.MultiOutputKernel):
+    if kernel.terms() is not None or isinstance(kernel, (_k.MultiOutputKernel, _k.InputScaled)):
         return KernelDense(kernel, x, noise)
     return kernel(x) + noise
 

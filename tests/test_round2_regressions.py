@@ -246,3 +246,37 @@ def test_batched_logpdf_gradients(b, n, d, kinds):
     alpha = np.linalg.solve(sum(v * O._kappa(k, ((x[0][:, None, :] - x[0][None, :, :]) ** 2).sum(-1) / s**2, x[0] @ x[0].T / s**2)
                                 for k, v, s in t0) + noise0 * np.eye(n), y[0])
     assert rel(ty.grad[0], -wts[0] * alpha) < 1e-6
+
+
+# ------------------------------------------------------------------ per-dimension length scales (k.stretch(vector))
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_per_dimension_length_scales(dtype):
+    """``EQ().stretch([l_1, ..., l_D])`` = the EQ kernel on ``x / l`` (mlkernels' Stretched with a vector): log-density and
+    posterior against the oracle evaluated on explicitly rescaled inputs; a sum with a differently scaled term."""
+    rng = np.random.default_rng(21)
+    n, ns, d, noise = 200, 30, 3, 0.2
+    x, xs, y = rng.standard_normal((n, d)), rng.standard_normal((ns, d)), rng.standard_normal((n, 1))
+    ell = np.array([0.5, 1.5, 3.0])
+    e = 1e-12 if dtype == torch.float64 else 1e-6
+    with eps(e):
+        f = st.GP(1.3 * st.EQ().stretch(T(ell, dtype)))
+        ref_lp = O.gp_logpdf([("eq", 1.3, 1.0)], x / ell, noise, y, eps=e)
+        fd = f(T(x, dtype), noise)
+        assert abs(float(fd.logpdf(T(y, dtype))) - ref_lp) <= TOL[dtype] * abs(ref_lp)
+        mean, var = (f | (fd, T(y, dtype)))(T(xs, dtype)).marginals()
+        rm, _, rv = O.gp_posterior([("eq", 1.3, 1.0)], x / ell, noise, y, xs / ell, full_cov=False, eps=e)
+        assert rel(mean, rm) < TOL[dtype] and rel(var, np.maximum(rv, 0)) < TOL[dtype]
+        # kernel values, diagonal, scalar re-stretch on top, sum with a scalar-stretched Matern term
+        k2 = st.EQ().stretch(T(ell, dtype)).stretch(2.0) + 0.5 * st.Matern32().stretch(0.7)
+        want = O.kernel_matrix([("eq", 1.0, 1.0)], x / (2 * ell), xs / (2 * ell)) + O.kernel_matrix([("matern32", 0.5, 0.7)], x, xs)
+        assert rel(k2.pairwise(T(x, dtype), T(xs, dtype)), want) < (1e-6 if dtype == torch.float64 else 1e-5)
+        assert rel(k2.elwise(T(x, dtype))[:, 0], 1.5 * np.ones(n)) < 1e-6
+        g = st.GP(k2)
+        want_k = O.kernel_matrix([("eq", 1.0, 1.0)], x / (2 * ell)) + O.kernel_matrix([("matern32", 0.5, 0.7)], x) + noise * np.eye(n)
+        ref2 = O.normal_logpdf(None, want_k, y, eps=e)
+        assert abs(float(g(T(x, dtype), noise).logpdf(T(y, dtype))) - ref2) <= TOL[dtype] * abs(ref2)
+    with pytest.raises(ValueError):
+        st.EQ().stretch(T([1.0, 2.0], dtype)).pairwise(T(x, dtype))           # 2 scales, 3 input dimensions
+    ls = torch.tensor([1.0, 2.0, 3.0], dtype=dtype, device=DEVICE[0], requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        st.GP(st.EQ().stretch(ls))(T(x, dtype), noise).logpdf(T(y, dtype))    # loud, not silently detached
