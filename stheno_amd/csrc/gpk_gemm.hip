@@ -674,7 +674,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
                                      : (int64_t)g.tiles_m * g.tiles_n;
-    g.colmajor = (!lower_only && !g.tri_k_lo_b && g.tiles_n >= g_colmajor_ratio * g.tiles_m) ? 1 : 0;
+    g.colmajor = (!lower_only && !g.tri_k_lo_b && (int64_t)g.tiles_n >= (int64_t)g_colmajor_ratio * g.tiles_m) ? 1 : 0;
     int64_t gridx;
     g.swizzle = (total >= g_swizzle_from) ? 1 : 0;
     g.n_super = 0;

@@ -319,3 +319,31 @@ def test_normal_arithmetic_and_kl_on_device():
                   + np.linalg.slogdet(v2)[1] - np.linalg.slogdet(v1)[1])
     assert abs(float(n1.kl(n2)) - want) < 1e-9 * abs(want) and float(n1.kl(n1)) < 1e-9
     assert rel(B.dense(n1.m2), v1 + m1 @ m1.T) < 1e-13
+
+
+@pytest.mark.parametrize("dtype,n", [(torch.float64, 6144 + 37), (torch.float32, 6144 + 128)])
+def test_lookahead_factorisation_through_the_api(dtype, n):
+    """Orders from 6144 take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
+    against LAPACK, the merged block inverses it returns against what the solves then compute, ragged order included."""
+    from stheno_amd import matrix
+
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((n, 4))
+    k = O.kernel_matrix([("eq", 1.0, 1.0)], x) + 0.5 * np.eye(n)
+    c = Chol.factor_(dev(k, dtype).clone())
+    nb = matrix.config.potrf_lookahead_nb[dtype]
+    assert nb in c._dinv_sb and c._dinv_sb[nb].shape[-3] == (n + nb - 1) // nb      # the look-ahead path ran
+    l_ref = np.linalg.cholesky(k)
+    tol = 1e-10 if dtype == torch.float64 else 2e-4
+    assert rel(torch.tril(c.l), l_ref) < tol
+    assert abs(float(c.logdet()) - O.logdet_chol(l_ref)) < tol * abs(O.logdet_chol(l_ref))
+    b = rng.standard_normal((n, 40))
+    assert rel(c.solve(dev(b, dtype)), O.solve_lower(l_ref, b)) < tol * 10
+    # the plain factorisation of the same matrix agrees to round-off
+    old = matrix.config.potrf_lookahead_from
+    matrix.config.potrf_lookahead_from = 0
+    try:
+        c2 = Chol.factor_(dev(k, dtype).clone())
+    finally:
+        matrix.config.potrf_lookahead_from = old
+    assert nb not in c2._dinv_sb and rel(torch.tril(c.l), torch.tril(c2.l).double().cpu().numpy()) < tol
