@@ -84,6 +84,7 @@ void gpk_tune(int key, int64_t value) {
     gpk_tune_gemm(key, value);
     gpk_tune_potrf(key, value);
     gpk_tune_kmat(key, value);
+    gpk_tune_solve(key, value);
 }
 
 void gpk_tune_diag_prof(long long* dev_buf) { gpk_set_diag_prof(dev_buf); }

@@ -136,6 +136,7 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
 void gpk_tune_gemm(int key, int64_t value);
 void gpk_tune_potrf(int key, int64_t value);
 void gpk_tune_kmat(int key, int64_t value);
+void gpk_tune_solve(int key, int64_t value);
 void gpk_set_diag_prof(long long* dev_buf);
 void gpk_set_tile_prof(long long* dev_buf);
 

@@ -17,6 +17,11 @@
 // so every update is an MFMA GEMM with K = SB, not a rank-128 one.
 #include "gpk_common.hpp"
 
+int g_trsv_batched = 1;      // tuning knob (gpk_tune(17, v)): one-workgroup-per-matrix TRSV for batches of small factors
+void gpk_tune_solve(int key, int64_t value) {
+    if (key == 17) g_trsv_batched = (int)value;
+}
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -201,6 +206,111 @@ int gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda
     return GPK_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// Batched TRSV, one workgroup per matrix (many small independent factors: stheno's batched computation): the whole solve of
+// one right-hand-side set runs inside ONE workgroup -- no inter-workgroup dependency, one launch instead of 2 x n/128 --
+// left-looking over 128-blocks:   r_q -= L[q, 0:q] x[0:q]  (rows read once, contiguously),   x_q = inv(L_qq) r_q.
+// x lives in LDS; a wave owns a row at a time (lanes across the columns, 16-byte loads, wave reduction).  HBM-bound: the
+// lower triangle and the inverted diagonal blocks are read once.  nrhs <= NR.
+// ---------------------------------------------------------------------------
+template <typename T, int NR>
+__global__ __launch_bounds__(256) void trsv_batched_kernel(const T* __restrict__ L, int64_t ld, int64_t sL, const T* __restrict__ dinv,
+                                                            int64_t sD, T* __restrict__ B, int64_t ldb, int64_t sB, int n, int nrhs) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) char trsv_smem[];
+    T* xs = reinterpret_cast<T*>(trsv_smem);                 // [n_pad][NR]: the right-hand sides, overwritten by the solution
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.x;
+    const T* __restrict__ Lb = L + b * sL;
+    const T* __restrict__ Wb = dinv + b * sD;
+    T* __restrict__ Bb = B + b * sB;
+    const int nblk = (n + GPK_DB - 1) / GPK_DB;
+    for (int idx = tid; idx < nblk * GPK_DB * NR; idx += 256) {
+        const int i = idx / NR, c = idx % NR;
+        xs[idx] = (i < n && c < nrhs) ? Bb[(int64_t)i * ldb + c] : T(0);
+    }
+    __syncthreads();
+    const bool vec_ok = ((uintptr_t)Lb % 16 == 0) && (ld % VEC == 0);
+    for (int q = 0; q < nblk; ++q) {
+        const int r0 = q * GPK_DB;
+        // 1. r_q -= L[q-block rows, 0:r0] x[0:r0]
+        if (q > 0) {
+            for (int rr = wave; rr < GPK_DB; rr += 4) {
+                const int row = r0 + rr;
+                if (row >= n) break;                           // (uniform per wave)
+                T acc[NR];
+#pragma unroll
+                for (int c = 0; c < NR; ++c) acc[c] = T(0);
+                const T* __restrict__ lrow = Lb + (int64_t)row * ld;
+                if (vec_ok) {
+                    for (int k = lane * VEC; k < r0; k += 64 * VEC) {
+                        const vec_t lv = *reinterpret_cast<const vec_t*>(lrow + k);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) acc[c] += lv[v] * xs[(k + v) * NR + c];
+                    }
+                } else {
+                    for (int k = lane; k < r0; k += 64)
+#pragma unroll
+                        for (int c = 0; c < NR; ++c) acc[c] += lrow[k] * xs[k * NR + c];
+                }
+#pragma unroll
+                for (int c = 0; c < NR; ++c) {
+                    T v = acc[c];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    acc[c] = v;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) xs[row * NR + c] -= acc[c];
+                }
+            }
+            __syncthreads();
+        }
+        // 2. x_q = inv(L_qq) r_q   (128 x 128 block, identity-padded past n): results held until every wave has read r_q
+        const T* __restrict__ Wq = Wb + (int64_t)q * GPK_DB * GPK_DB;
+        T res[GPK_DB / 4][NR];
+#pragma unroll
+        for (int j = 0; j < GPK_DB / 4; ++j) {
+            const int rr = wave + 4 * j;
+            T acc[NR];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) acc[c] = T(0);
+            for (int k = lane * VEC; k < GPK_DB; k += 64 * VEC) {
+                const vec_t wv = *reinterpret_cast<const vec_t*>(Wq + (int64_t)rr * GPK_DB + k);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) acc[c] += wv[v] * xs[(r0 + k + v) * NR + c];
+            }
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                T v = acc[c];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                res[j][c] = v;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < GPK_DB / 4; ++j)
+#pragma unroll
+                for (int c = 0; c < NR; ++c) xs[(r0 + wave + 4 * j) * NR + c] = res[j][c];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n * nrhs; idx += 256) {
+        const int i = idx / nrhs, c = idx % nrhs;
+        Bb[(int64_t)i * ldb + c] = xs[i * NR + c];
+    }
+}
+
 }  // namespace
 
 // y[M x nrhs] = alpha * A[M x K] x[K x nrhs] + beta * y, nrhs <= 8, A row-major (k contiguous)
@@ -324,6 +434,22 @@ int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv
     const int nsb = (int)gpk_cdiv(n, sb);
     const int64_t per = (int64_t)sb * sb, ssb = (int64_t)nsb * per;
     const int64_t st_tmp = (int64_t)sb * nrhs;
+    // many small factors with the 128-block inverses: one workgroup per matrix, one launch
+    if (g_trsv_batched && sb == GPK_DB && batch >= 64 && nrhs <= (sizeof(T) == 8 ? 2 : 4)) {      // (fp64 x 4 columns would spill)
+        const int NRv = nrhs == 1 ? 1 : (nrhs == 2 ? 2 : 4);
+        const size_t lds = (size_t)nsb * GPK_DB * NRv * sizeof(T);
+        if (lds <= 64 * 1024) {
+            dim3 grid((unsigned)batch);
+            if (NRv == 1)
+                hipLaunchKernelGGL((trsv_batched_kernel<T, 1>), grid, dim3(256), lds, stream, L, ld, sL, dinv_sb, ssb, B, ldb, sB, (int)n, nrhs);
+            else if (NRv == 2)
+                hipLaunchKernelGGL((trsv_batched_kernel<T, 2>), grid, dim3(256), lds, stream, L, ld, sL, dinv_sb, ssb, B, ldb, sB, (int)n, nrhs);
+            else
+                hipLaunchKernelGGL((trsv_batched_kernel<T, 4>), grid, dim3(256), lds, stream, L, ld, sL, dinv_sb, ssb, B, ldb, sB, (int)n, nrhs);
+            GPK_CHECK_LAUNCH();
+            return GPK_OK;
+        }
+    }
     for (int q = 0; q < nsb; ++q) {
         const int64_t r0 = (int64_t)q * sb;
         const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
