@@ -257,7 +257,8 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm;
  * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
  * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 13: column-major GEMM tile order from this ratio of
- * tile columns to tile rows (off by default); 17: 1 = one-workgroup-per-matrix TRSV for batches of small factors.
+ * tile columns to tile rows (off by default); 17: 1 = one-workgroup-per-matrix TRSV for batches of small factors;
+ * 18: 1 = the CUs reserved for the look-ahead chain rejoin the trailing update once the chain is done (default).
  * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);

@@ -118,9 +118,15 @@ struct GpkSeg {
     int tri_b;      // B (N x K) is lower triangular: k stops at the column tile's last column (2: pair column tiles c, n-1-c)
 };
 // Cin == nullptr: C = alpha * A B^T (nothing is read from C)
+struct GpkPersistSaved {       // what a reserving launch was made of, for gpk_gemm_persist_rejoin
+    alignas(16) char bytes[768];
+    int ts, edge, per_cu, valid;
+};
 template <typename T>
 int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,
-                            hipStream_t stream);
+                            hipStream_t stream, GpkPersistSaved* saved = nullptr, bool ctrl_zeroed = false);
+template <typename T>
+int gpk_gemm_persist_rejoin(const GpkPersistSaved* saved, hipStream_t helper_stream);
 
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,

@@ -34,6 +34,7 @@
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
 #include <type_traits>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -829,7 +830,8 @@ void gpk_helper_shutdown() {
 
 template <typename T>
 int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,
-                            hipStream_t stream) {
+                            hipStream_t stream, GpkPersistSaved* saved, bool ctrl_zeroed) {
+    if (saved != nullptr) saved->valid = 0;
     if (nseg < 1 || nseg > 2) return GPK_ERR_ARG(2);
     if (ctrl == nullptr) return GPK_ERR_ARG(4);
     if (alpha == T(0)) return GPK_ERR_ARG(3);
@@ -885,7 +887,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     pa.ntiles = (int)total;
     pa.ctrl = ctrl;
     pa.prof = g_tile_prof;
-    if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
+    if (!ctrl_zeroed && hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
 
     const int per_cu = (ts == 128) ? 2 : 4;
     int64_t slots = (int64_t)device_cus() * per_cu;
@@ -916,6 +918,36 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     }
     if (slot) g_prof.end(slot, stream);
     GPK_CHECK_LAUNCH();
+    if (saved != nullptr && pa.reserve) {
+        static_assert(sizeof(PersistArgs<T>) <= sizeof(saved->bytes), "GpkPersistSaved too small");
+        memcpy(saved->bytes, &pa, sizeof(pa));
+        saved->ts = ts;
+        saved->edge = edge ? 1 : 0;
+        saved->per_cu = per_cu;
+        saved->valid = 1;
+    }
+    return GPK_OK;
+}
+
+// The CUs a reserving update keeps clear REJOIN it once the helper stream has nothing else to do: the same kernel, the
+// same tile counter, a grid of just the reserved slots, enqueued on the (CU-masked) helper stream behind the chain.  Tiles
+// are claimed atomically, so whoever runs takes what is left; results do not depend on it.
+template <typename T>
+int gpk_gemm_persist_rejoin(const GpkPersistSaved* saved, hipStream_t helper_stream) {
+    if (saved == nullptr || !saved->valid) return GPK_OK;
+    PersistArgs<T> pa;
+    memcpy(&pa, saved->bytes, sizeof(pa));
+    pa.reserve = 0;
+    pa.prof = nullptr;
+    dim3 grid((unsigned)(8 * saved->per_cu));
+    if (saved->ts == 128) {
+        if (saved->edge) hipLaunchKernelGGL((gemm_persist_kernel<T, 128, true>), grid, dim3(256), 0, helper_stream, pa);
+        else hipLaunchKernelGGL((gemm_persist_kernel<T, 128, false>), grid, dim3(256), 0, helper_stream, pa);
+    } else {
+        if (saved->edge) hipLaunchKernelGGL((gemm_persist_kernel<T, 64, true>), grid, dim3(256), 0, helper_stream, pa);
+        else hipLaunchKernelGGL((gemm_persist_kernel<T, 64, false>), grid, dim3(256), 0, helper_stream, pa);
+    }
+    GPK_CHECK_LAUNCH();
     return GPK_OK;
 }
 
@@ -926,6 +958,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     template int gpk_gemm_launch<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,     \
                                     int64_t, const T*, int64_t, int64_t, T, T*, int64_t, int64_t,    \
                                     int64_t, int, hipStream_t);                                      \
-    template int gpk_gemm_persist_launch<T>(const GpkSeg<T>*, int, T, unsigned*, int, hipStream_t);
+    template int gpk_gemm_persist_launch<T>(const GpkSeg<T>*, int, T, unsigned*, int, hipStream_t, GpkPersistSaved*, bool); \
+    template int gpk_gemm_persist_rejoin<T>(const GpkPersistSaved*, hipStream_t);
 GPK_INST(double)
 GPK_INST(float)

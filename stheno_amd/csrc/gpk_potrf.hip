@@ -565,6 +565,7 @@ int64_t g_la_min_rows = 2048;     // tuning knob (gpk_tune(6, v)): overlap while
 int64_t g_la_tail_rows = 6144;    // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path
 int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
 int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
+int g_la_rejoin = 1;              // tuning knob (gpk_tune(18, v)): reserved CUs rejoin the trailing update after the chain
 int g_la_mode = 1;                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
 
 LaDevice* la_device() {
@@ -628,6 +629,7 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 7) g_la_mode = (int)value;
     if (key == 9) g_la_tail_rows = value;
     if (key == 10) g_la_ps_mode = (int)value;
+    if (key == 18) g_la_rejoin = (int)value;
     if (key == 11) g_la_strip_last = (int)value;
 }
 
@@ -731,11 +733,15 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             e_fork = la_event(*dev, ev++);
             e_join = la_event(*dev, ev++);
             if (e_fork == nullptr || e_join == nullptr) return GPK_ERR_LAUNCH;
+            // the tile counter is zeroed BEFORE the fork: the helper stream's rejoin launch reads it, so it must be ordered behind
+            if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
             if (hipEventRecord(e_fork, stream) != hipSuccess) return GPK_ERR_LAUNCH;
         } else {
             st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, stream);
             if (st) return st;
         }
+        GpkPersistSaved saved;
+        saved.valid = 0;
         // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
         // ~0.3 ms for those, which the main stream would otherwise spend idle
         if (k2 < n) {
@@ -744,13 +750,17 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             const int so = g_la_strip_last ? 1 : 0;   // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
             seg[so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
             seg[1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
-            st = gpk_gemm_persist_launch<T>(seg, 2, T(-1), ctrl, overlap ? 1 : 0, stream);
+            st = gpk_gemm_persist_launch<T>(seg, 2, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
             if (st) return st;
         }
         if (overlap) {
             if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
             st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux);
             if (st) return st;
+            if (g_la_rejoin && saved.valid) {       // chain done: the reserved CUs take tiles of the update that is still running
+                st = gpk_gemm_persist_rejoin<T>(&saved, dev->aux);
+                if (st) return st;
+            }
             if (hipEventRecord(e_join, dev->aux) != hipSuccess) return GPK_ERR_LAUNCH;
             if (hipStreamWaitEvent(stream, e_join, 0) != hipSuccess) return GPK_ERR_LAUNCH;
         }
