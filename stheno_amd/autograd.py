@@ -9,7 +9,10 @@ sweep).  Backward, from the stored factor:
 ``K^{-1} = W^T W`` with ``W = L^{-1}`` (blocked TRSM on the identity + lower SYRK, both on the
 MFMA GEMM), then ONE pass over the lower triangle of ``K^{-1}`` (``gpk_kmat_vjp``) yields the
 gradients w.r.t. every variance, length scale and the noise; ``d/d(y - m) = -A g``.
-Gradients w.r.t. the inputs ``x`` are not provided.
+Gradients w.r.t. the inputs ``x`` (learnt input warps, latent inputs, per-dimension length scales --
+``k.stretch(vector)`` divides the inputs) take one more pass: the explicit symmetric cotangent
+``G`` is formed in the buffer of ``K^{-1}`` (a rank-C GEMM update) and ``gpk_kmat_vjp_dense`` reduces it
+against ``dK_ij/dx_i``; both arguments of ``k(x, x)`` move with ``x``, hence the factor two.
 """
 import math
 
@@ -19,6 +22,19 @@ from . import ops
 from .matrix import LOG_2_PI, Chol, config
 
 __all__ = ["gp_logpdf", "sparse_elbo"]
+
+
+def _grad_inputs(be, terms, x, kinv_lower, alpha, g):
+    """``d logpdf / dx`` (n, D) from the lower triangle of ``K^{-1}`` (consumed: its buffer becomes the cotangent),
+    ``alpha = K^{-1} r`` (n, C) and the C output cotangents ``g``:  G = 1/2 (alpha diag(g) alpha^T - sum(g) K^{-1}),
+    ``dx_i = 2 sum_j G_ij dk(x_i, x_j)/dx_i``."""
+    if x.shape[-1] > 8:
+        raise NotImplementedError("gradients with respect to the inputs are implemented for at most 8 input dimensions")
+    gt = torch.as_tensor(g, dtype=alpha.dtype, device=alpha.device)
+    G = be.symmetrize_(kinv_lower)
+    be.gemm(alpha * gt[None, :], alpha, a_kmajor=True, b_kmajor=True, alpha=0.5, beta=-0.5 * float(sum(g)), out=G)
+    _, _, gx = be.kmat_vjp_dense(terms, x, x, G, want_gradx=True)
+    return 2.0 * gx
 
 
 class _GPLogpdf(torch.autograd.Function):
@@ -65,7 +81,8 @@ class _GPLogpdf(torch.autograd.Function):
             grads.append((-2.0 * variances[t] / scales[t] * S[t, 1]).to(device=dev, dtype=dt))
         grad_r = -(alpha * grad_out.reshape(1, -1).to(alpha.dtype))
         grad_noise = diag_g if ctx.has_noise else None
-        return (None, grad_r, grad_noise, None, *grads)
+        grad_x = _grad_inputs(be, terms, x, kinv, alpha, g) if ctx.needs_input_grad[0] else None
+        return (grad_x, grad_r, grad_noise, None, *grads)
 
 
 class _GPLogpdfBatched(torch.autograd.Function):
@@ -101,6 +118,7 @@ class _GPLogpdfBatched(torch.autograd.Function):
         S_tot = None
         grad_r = torch.empty_like(w)
         grad_noise = torch.empty(w.shape[:-1], dtype=w.dtype, device=w.device) if ctx.has_noise else None
+        grad_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         for b in range(B):
             sl = lambda t: None if t is None else t[b:b + 1]      # noqa: E731
             cb = Chol(chol.l[b], sl(chol.dinv), sl(chol.info))                 # entry b as an unbatched factor (views)
@@ -112,6 +130,8 @@ class _GPLogpdfBatched(torch.autograd.Function):
             grad_r[b] = -alpha * g_host[b]
             if grad_noise is not None:
                 grad_noise[b] = diag_g
+            if grad_x is not None:
+                grad_x[b] = _grad_inputs(be, terms, x[b], kinv, alpha, [g_host[b]])
         variances, scales = ctx.values
         grads = []
         for t in range(nt):
@@ -120,12 +140,14 @@ class _GPLogpdfBatched(torch.autograd.Function):
         for t in range(nt):
             dev, dt = ctx.param_meta[nt + t]
             grads.append((-2.0 * variances[t] / scales[t] * S_tot[t, 1]).to(device=dev, dtype=dt))
-        return (None, grad_r, grad_noise, None, *grads)
+        return (grad_x, grad_r, grad_noise, None, *grads)
 
 
-def needs_grad(tensor_terms, noise_vec, r):
+def needs_grad(tensor_terms, noise_vec, r, x=None):
     if not torch.is_grad_enabled():
         return False
+    if x is not None and torch.is_tensor(x) and x.requires_grad:
+        return True
     for _, v, s in tensor_terms:
         if (torch.is_tensor(v) and v.requires_grad) or (torch.is_tensor(s) and s.requires_grad):
             return True
@@ -239,7 +261,7 @@ class _SparseELBO(torch.autograd.Function):
         h = be.gemm(w_z, tau * eye - a_inv, a_kmajor=False, b_kmajor=True)     # L^{-T} (tau I - A^{-1})
         w = be.colreduce(w_z, c, want_dot=True, want_ss=False)[0]              # L^{-T} c
         g_k = be.gemm(h, v, a_kmajor=True, b_kmajor=False)                     # M x N, the one big GEMM
-        need_z = ctx.needs_input_grad[1]
+        need_z, need_x = ctx.needs_input_grad[1], ctx.needs_input_grad[0]
         fitc = sv["fitc"]
         s_k, colsum, gz_k = be.kmat_vjp_dense(terms, z, x, g_k, colscale=s, w=w, b=b, want_colsum=True,
                                               want_gradx=need_z and not fitc)
@@ -258,7 +280,18 @@ class _SparseELBO(torch.autograd.Function):
             vgv = be.symmetrize_(be.gemm(rr, v, a_kmajor=True, b_kmajor=True, lower_only=True))
             mid = mid - 2.0 * vgv
             del rr
-        del g_k
+        gx_k = None
+        if need_x:
+            # d/dx through K_zx: the same reduction with the roles of the arguments swapped, on the explicit N x M
+            # transpose of the effective cotangent  g_k diag(s) + w b^T  (one extra N x M buffer, backward only)
+            be.scale_cols_(g_k, s)
+            g_t = g_k.t().contiguous()
+            del g_k
+            g_t.addcmul_(b[:, None], w[None, :])
+            _, _, gx_k = be.kmat_vjp_dense(terms, x, z, g_t, want_gradx=True)
+            del g_t
+        else:
+            del g_k
         t1 = be.gemm(mid, w_z, a_kmajor=True, b_kmajor=False)
         g_kz = be.gemm(w_z, t1, a_kmajor=False, b_kmajor=False, alpha=-0.5)
         s_kz, _, gz_kz = be.kmat_vjp_dense(terms, z, z, g_kz, want_gradx=need_z)
@@ -274,20 +307,25 @@ class _SparseELBO(torch.autograd.Function):
                 if ctx.kinds[t] == "linear":
                     xx = ((x * x).sum(-1) * g_kd).sum() / scales[t] ** 2
                     gv, gs = gv + xx, gs - 2.0 * variances[t] / scales[t] * xx
+                    if need_x:      # k(x_j, x_j) = v |x_j|^2 / l^2 moves with x_j (stationary terms are constant there)
+                        gx_k = gx_k + (2.0 * variances[t] / scales[t] ** 2) * g_kd[:, None] * x
                 else:
                     gv = gv + g_kd.sum()
             grads_v.append(gv * go)
             grads_s.append(gs * go)
         grads = [g_.to(device=dev, dtype=dt) for g_, (dev, dt) in zip(grads_v + grads_s, ctx.param_meta)]
         grad_z = (gz_k + 2.0 * gz_kz) * go if need_z else None
+        grad_x = gx_k * go if need_x else None
         grad_r = (-b * go)[:, None] if ctx.needs_input_grad[2] else None
         grad_noise = g_d * go if ctx.needs_input_grad[3] else None
-        return (None, grad_z, grad_r, grad_noise, None, None, *grads)
+        return (grad_x, grad_z, grad_r, grad_noise, None, None, *grads)
 
 
-def elbo_needs_grad(tensor_terms, noise_vec, z, r):
+def elbo_needs_grad(tensor_terms, noise_vec, z, r, x=None):
     if not torch.is_grad_enabled():
         return False
+    if x is not None and torch.is_tensor(x) and x.requires_grad:
+        return True
     for _, v, s in tensor_terms:
         if (torch.is_tensor(v) and v.requires_grad) or (torch.is_tensor(s) and s.requires_grad):
             return True

@@ -129,6 +129,13 @@ class Kernel:
     def num_outputs(self, x):
         return num_elements(x)
 
+    def input_scaled_view(self):
+        """``(k, scales)`` such that ``self(x, y) == k(x / scales, y / scales)`` with ``k`` a sum of primitives
+        (``k.terms()`` is not None) and ``scales`` a vector of per-dimension length scales, or None for "inputs as they
+        are"; None when the kernel has no such form.  The differentiable paths run ``k`` on the divided inputs and
+        leave the division to torch, which carries the gradient to the length scales (and to ``x``)."""
+        return (self, None) if self.terms() is not None else None
+
     # -- evaluation ------------------------------------------------------------
     def pairwise(self, x, y=None, *, lower=False, diag_add=0.0, diag_vec=None, cache=None, out=None):
         """``k(x, y)`` as a tensor (..., N, M); ``y is None``: symmetric case, where
@@ -283,9 +290,16 @@ class Scaled(Kernel):
         t = self.k.tensor_terms()
         return None if t is None else [(kind, var * self.v, s) for kind, var, s in t]
 
+    def input_scaled_view(self):
+        v = self.k.input_scaled_view()
+        return None if v is None else (Scaled(v[0], self.v), v[1])
+
     def pairwise(self, x, y=None, **kw):
         if self.terms() is not None:
             return super().pairwise(x, y, **kw)
+        view = self.input_scaled_view()
+        if view is not None:                       # v * k0(x / l): still ONE fused launch, on the divided inputs
+            return InputScaled(*view).pairwise(x, y, **kw)
         da, dv = kw.pop("diag_add", 0.0), kw.pop("diag_vec", None)
         out = _as_float(self.v) * self.k.pairwise(x, y, **kw)
         return _add_diag(out, da, dv) if y is None else out
@@ -293,6 +307,9 @@ class Scaled(Kernel):
     def elwise(self, x, y=None, **kw):
         if self.terms() is not None:
             return super().elwise(x, y, **kw)
+        view = self.input_scaled_view()
+        if view is not None:
+            return InputScaled(*view).elwise(x, y, **kw)
         return _as_float(self.v) * self.k.elwise(x, y, **kw)
 
     def __repr__(self):
@@ -339,9 +356,12 @@ class InputScaled(Kernel):
             raise ValueError("InputScaled is a single-output kernel; it cannot take multi-process inputs")
         if x.shape[-1] != self.scales.numel():
             raise ValueError(f"inputs have {x.shape[-1]} dimensions, the kernel has {self.scales.numel()} length scales")
-        if torch.is_grad_enabled() and self.scales.requires_grad:
-            raise NotImplementedError("gradients with respect to per-dimension length scales are not implemented")
-        return x / self.scales.to(dtype=x.dtype, device=x.device)
+        # (values only: the differentiable log-density / bound take the kernel apart through `input_scaled_view`
+        # and divide the inputs themselves; everything that is not covered there refuses loudly at its own entry)
+        return x.detach() / self.scales.detach().to(dtype=x.dtype, device=x.device)
+
+    def input_scaled_view(self):
+        return (self.k, self.scales)
 
     def num_outputs(self, x):
         return self.k.num_outputs(x)
@@ -401,9 +421,21 @@ class Sum(Kernel):
             return None
         return _merge_terms(ta + tb)
 
+    def input_scaled_view(self):
+        va, vb = self.a.input_scaled_view(), self.b.input_scaled_view()
+        if va is None or vb is None:
+            return None
+        sa, sb = va[1], vb[1]
+        same = (sa is sb) or (sa is not None and sb is not None and sa.shape == sb.shape and not sa.requires_grad
+                              and not sb.requires_grad and bool(torch.equal(sa, sb.to(sa))))
+        return (Sum(va[0], vb[0]), sa) if same else None      # different length-scale vectors: no common division
+
     def pairwise(self, x, y=None, **kw):
         if self.terms() is not None:
             return super().pairwise(x, y, **kw)
+        view = self.input_scaled_view()
+        if view is not None:                       # both summands divide the inputs by the same length scales
+            return InputScaled(*view).pairwise(x, y, **kw)
         da, dv = kw.pop("diag_add", 0.0), kw.pop("diag_vec", None)
         kw.pop("lower", None)
         out = self.a.pairwise(x, y, **kw) + self.b.pairwise(x, y, **kw)
@@ -412,6 +444,9 @@ class Sum(Kernel):
     def elwise(self, x, y=None, **kw):
         if self.terms() is not None:
             return super().elwise(x, y, **kw)
+        view = self.input_scaled_view()
+        if view is not None:
+            return InputScaled(*view).elwise(x, y, **kw)
         return self.a.elwise(x, y, **kw) + self.b.elwise(x, y, **kw)
 
     def __repr__(self):

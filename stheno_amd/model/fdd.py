@@ -70,12 +70,32 @@ class FDD(Normal):
 
         def var():
             k = p.kernel
-            if k.terms() is not None or isinstance(k, (_k.MultiOutputKernel, _k.InputScaled)):
+            if k.input_scaled_view() is not None or isinstance(k, _k.MultiOutputKernel):
                 return KernelDense(k, xr, nz)      # K + noise fused, factorised in place
             return k(xr) + nz
 
         Normal.__init__(self, lambda: p.mean(xr), var, var_diag=var_diag, mean_var=mean_var,
                         mean_var_diag=mean_var_diag)
+
+    def logpdf(self, x):
+        """``Normal.logpdf`` plus a guard: a value that came out cut off from the autograd graph although the process
+        has learnable quantities (a posterior / multi-process / dense-noise case outside the differentiable paths)
+        is refused, never returned silently detached."""
+        lp = Normal.logpdf(self, x)
+        if torch.is_grad_enabled() and not isinstance(self.p, int) and torch.is_tensor(lp) and not lp.requires_grad:
+            from .. import autograd as _ag
+            from ..random import _x_requires_grad
+
+            nz = self.noise
+            noisy = ((isinstance(nz, Diagonal) and nz.diag().requires_grad)
+                     or (isinstance(nz, Dense) and nz.mat is not None and nz.mat.requires_grad))
+            if noisy or _x_requires_grad(self._xr) or _ag.kernel_requires_grad(self.p.kernel):
+                raise NotImplementedError(
+                    "this log-density is outside the differentiable paths (one process -- or one batch of independent "
+                    "data sets -- whose kernel is a sum of primitives, scalar / per-point noise): its value would be "
+                    "cut off from the autograd graph.  Wrap the call in torch.no_grad() if that is intended"
+                )
+        return lp
 
     @property
     def dtype(self):

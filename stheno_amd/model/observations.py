@@ -81,7 +81,7 @@ def _syrk_lower(be, v, out):
 
 def _kernel_matrix(kernel, x, noise):
     """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``)."""
-    if kernel.terms() is not None or isinstance(kernel, (_k.MultiOutputKernel, _k.InputScaled)):
+    if kernel.input_scaled_view() is not None or isinstance(kernel, _k.MultiOutputKernel):
         return KernelDense(kernel, x, noise)
     return kernel(x) + noise
 
@@ -197,10 +197,12 @@ class AbstractPseudoObservations(AbstractObservations):
         p_x, x, noise_x = self.fdd.p, self.fdd._xr, self.fdd.noise
         z = self.u._xr
         k = measure.kernels[self.u.p]
-        tt = k.tensor_terms() if hasattr(k, "tensor_terms") else None
-        if tt is None or isinstance(x, _k.MultiInput) or isinstance(z, _k.MultiInput) or not isinstance(noise_x, Diagonal):
+        view = k.input_scaled_view() if hasattr(k, "input_scaled_view") else None
+        if view is None or isinstance(x, _k.MultiInput) or isinstance(z, _k.MultiInput) or not isinstance(noise_x, Diagonal):
             return autograd.kernel_requires_grad(k) or self.y.requires_grad
-        return autograd.elbo_needs_grad(tt, noise_x.diag(), z, self.y - measure.means[p_x](x))
+        kern, scales = view
+        return (autograd.elbo_needs_grad(kern.tensor_terms(), noise_x.diag(), z, self.y - measure.means[p_x](x), x)
+                or (scales is not None and scales.requires_grad))
 
     def _differentiable(self, measure):
         from .. import autograd
@@ -212,11 +214,13 @@ class AbstractPseudoObservations(AbstractObservations):
         if isinstance(x, _k.MultiInput) or isinstance(z, _k.MultiInput) or not isinstance(noise_x, Diagonal):
             return None
         k = measure.kernels[p_z]
-        tt = k.tensor_terms()
-        if tt is None:
+        view = k.input_scaled_view()
+        if view is None:
             return None
+        kern, scales = view                       # k(a, b) = kern(a / scales, b / scales)
+        tt = kern.tensor_terms()
         y_bar = self.y - measure.means[p_x](x)
-        if not autograd.elbo_needs_grad(tt, noise_x.diag(), z, y_bar):
+        if not (autograd.elbo_needs_grad(tt, noise_x.diag(), z, y_bar, x) or (scales is not None and scales.requires_grad)):
             return None
         if not (measure.kernels[p_x] is k and measure.kernels[p_z, p_x] is k and isinstance(noise_z, Zero)
                 and x.dim() == 2 and z.dim() == 2):
@@ -224,7 +228,13 @@ class AbstractPseudoObservations(AbstractObservations):
                 "gradients of the bound are implemented for noise-free inducing points of the observed "
                 "process itself (one kernel that is a sum of primitives), unbatched"
             )
-        return autograd.sparse_elbo(k, x, z, noise_x.diag(), y_bar, self.method)
+        if scales is not None:                    # torch differentiates the division (d/d scales, d/dx, d/dz)
+            sc = scales.to(dtype=x.dtype, device=x.device)
+            x, z = x / sc, z / sc
+        if x.requires_grad and x.shape[-1] > 8:
+            raise NotImplementedError("gradients with respect to the inputs (or per-dimension length scales) are "
+                                      "implemented for at most 8 input dimensions")
+        return autograd.sparse_elbo(kern, x, z, noise_x.diag(), y_bar, self.method)
 
     def mu(self, measure):
         """Mean of the optimal approximating distribution (``observations.py:224-237``)."""

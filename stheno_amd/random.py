@@ -242,15 +242,21 @@ class Normal(RandomVector):
             noise_vec = var.differentiable_noise()
             if noise_vec is not None and noise_vec is not NotImplemented and noise_vec.dim() != r.dim() - 1:
                 noise_vec = NotImplemented
-            tt = var.kernel.tensor_terms()
-            if torch.is_grad_enabled() and _x_requires_grad(var.x):
-                raise NotImplementedError("gradients with respect to the inputs x of a GP are not implemented "
-                                          "(detach x, or wrap the call in torch.no_grad())")
-            if noise_vec is not NotImplemented and tt is not None and _ag.needs_grad(tt, noise_vec, r):
-                lp = _ag.gp_logpdf(var.kernel, var.x, noise_vec, r)
-                if r.dim() == 3:
-                    return lp
-                return lp[0] if lp.shape[0] == 1 else lp
+            # k(x) = k0(x / l) with k0 a sum of primitives (l: per-dimension length scales, or none): the fused path runs
+            # k0 on the divided inputs; torch differentiates the division (d/dl, d/dx)
+            view = var.kernel.input_scaled_view() if torch.is_tensor(var.x) else None
+            if noise_vec is not NotImplemented and view is not None:
+                kern, scales = view
+                xin = var.x if scales is None else var.x / scales.to(dtype=var.x.dtype, device=var.x.device)
+                tt = kern.tensor_terms()
+                if tt is not None and _ag.needs_grad(tt, noise_vec, r, xin):
+                    if xin.requires_grad and torch.is_grad_enabled() and xin.shape[-1] > 8:
+                        raise NotImplementedError("gradients with respect to the inputs (or per-dimension length scales) "
+                                                  "are implemented for at most 8 input dimensions")
+                    lp = _ag.gp_logpdf(kern, xin, noise_vec, r)
+                    if r.dim() == 3:
+                        return lp
+                    return lp[0] if lp.shape[0] == 1 else lp
         if torch.is_grad_enabled() and isinstance(var, KernelDense):
             from . import autograd as _ag
 

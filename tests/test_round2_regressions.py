@@ -170,10 +170,12 @@ def test_gradients_outside_the_differentiable_path_are_refused():
     x = torch.randn(10, 2, dtype=torch.float64, device=DEVICE[0], requires_grad=True)
     y = torch.randn(10, 1, dtype=torch.float64, device=DEVICE[0])
     f = st.GP(st.EQ())
+    assert f(x, 0.1).logpdf(y).requires_grad                 # d/dx: implemented since (tests/test_autograd_inputs.py)
+    post = f | (f(x[:5].detach(), 0.1), y[:5])
     with pytest.raises(NotImplementedError):
-        f(x, 0.1).logpdf(y)                                  # d/dx is not implemented: loud, not silent
+        post(x[5:], 0.1).logpdf(y[5:])                       # d/dx of a POSTERIOR log-density is not: loud, not silent
     with torch.no_grad():
-        assert torch.isfinite(f(x, 0.1).logpdf(y))
+        assert torch.isfinite(post(x[5:], 0.1).logpdf(y[5:]))
     c = torch.tensor(2.0, dtype=torch.float64, device=DEVICE[0], requires_grad=True)
     with pytest.raises(NotImplementedError):
         c * f                                                # a learnable scale belongs on the kernel
@@ -278,5 +280,7 @@ def test_per_dimension_length_scales(dtype):
     with pytest.raises(ValueError):
         st.EQ().stretch(T([1.0, 2.0], dtype)).pairwise(T(x, dtype))           # 2 scales, 3 input dimensions
     ls = torch.tensor([1.0, 2.0, 3.0], dtype=dtype, device=DEVICE[0], requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        st.GP(st.EQ().stretch(ls))(T(x, dtype), noise).logpdf(T(y, dtype))    # loud, not silently detached
+    lp = st.GP(st.EQ().stretch(ls))(T(x, dtype), noise).logpdf(T(y, dtype))     # learnable: tests/test_autograd_inputs.py
+    assert lp.requires_grad
+    lp.backward()
+    assert ls.grad.shape == (3,) and bool(torch.isfinite(ls.grad).all())
