@@ -456,8 +456,7 @@ struct PersistArgs {
 };
 
 template <typename T, int TS, bool EDGE>
-__global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_kernel(PersistArgs<T> p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * op_bytes(TS)];
+__device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem) {
     // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast
     // word lives in the unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel
     // its fourth workgroup per CU)
@@ -517,6 +516,21 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_kernel(
         t = __builtin_amdgcn_readfirstlane(s_tile);
         __syncthreads();
     }
+}
+
+template <typename T, int TS, bool EDGE>
+__global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_kernel(PersistArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * op_bytes(TS)];
+    persist_body<T, TS, EDGE>(p, smem);
+}
+
+// The same body under its own name: the second launch of an update, on the helper stream once the panel chain is
+// done (gpk_gemm_persist_rejoin) -- a few workgroups that pull tiles from the counter of the launch above.  A
+// separate symbol so that kernel traces / rocprofv3 --stats keep the two apart.
+template <typename T, int TS, bool EDGE>
+__global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_helper_kernel(PersistArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * op_bytes(TS)];
+    persist_body<T, TS, EDGE>(p, smem);
 }
 
 template <typename T, int TS, bool EDGE>
@@ -941,11 +955,11 @@ int gpk_gemm_persist_rejoin(const GpkPersistSaved* saved, hipStream_t helper_str
     pa.prof = nullptr;
     dim3 grid((unsigned)(8 * saved->per_cu));
     if (saved->ts == 128) {
-        if (saved->edge) hipLaunchKernelGGL((gemm_persist_kernel<T, 128, true>), grid, dim3(256), 0, helper_stream, pa);
-        else hipLaunchKernelGGL((gemm_persist_kernel<T, 128, false>), grid, dim3(256), 0, helper_stream, pa);
+        if (saved->edge) hipLaunchKernelGGL((gemm_persist_helper_kernel<T, 128, true>), grid, dim3(256), 0, helper_stream, pa);
+        else hipLaunchKernelGGL((gemm_persist_helper_kernel<T, 128, false>), grid, dim3(256), 0, helper_stream, pa);
     } else {
-        if (saved->edge) hipLaunchKernelGGL((gemm_persist_kernel<T, 64, true>), grid, dim3(256), 0, helper_stream, pa);
-        else hipLaunchKernelGGL((gemm_persist_kernel<T, 64, false>), grid, dim3(256), 0, helper_stream, pa);
+        if (saved->edge) hipLaunchKernelGGL((gemm_persist_helper_kernel<T, 64, true>), grid, dim3(256), 0, helper_stream, pa);
+        else hipLaunchKernelGGL((gemm_persist_helper_kernel<T, 64, false>), grid, dim3(256), 0, helper_stream, pa);
     }
     GPK_CHECK_LAUNCH();
     return GPK_OK;
