@@ -365,7 +365,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, PF2 ? 1 : 0> S1;
 
-    if (prof != nullptr && threadIdx.x == 0) prof[1] = wall_clock64();      // C tile requested, accumulators being initialised
+    if (prof != nullptr && threadIdx.x == 0) {      // C tile requested, accumulators being initialised
+        prof[1] = wall_clock64();
+        prof[4] = (long long)__builtin_readcyclecounter();   // shader-clock ticks: with the 100 MHz stamps they give the clock the k loop ran at
+    }
     if (PF2) {
         issue(S0{}, kc0);
         if (kc0 + 1 < nk) issue(S1{}, kc0 + 1);
@@ -397,7 +400,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         }
     }
 
-    if (prof != nullptr && threadIdx.x == 0) prof[2] = wall_clock64();      // k loop done
+    if (prof != nullptr && threadIdx.x == 0) {      // k loop done
+        prof[2] = wall_clock64();
+        prof[5] = (long long)__builtin_readcyclecounter();
+    }
     // (in-place use: every global read of this workgroup's rows of A happened above)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
@@ -452,7 +458,7 @@ struct PersistArgs {
     int reserve;
     int max_leave;
     unsigned rkeys[8];
-    long long* prof;          // development aid: 4 stamps for each of the first 8 tiles of every workgroup (nullable)
+    long long* prof;          // development aid: 8 slots (6 stamps) for each of the first 8 tiles of every workgroup (nullable)
 };
 
 template <typename T, int TS, bool EDGE>
@@ -505,7 +511,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             ok = decode_tile(g, tl, ti, tj);
         }
         if (ok) {
-            long long* pr = (p.prof != nullptr && nlocal < 8) ? p.prof + ((int64_t)blockIdx.x * 8 + nlocal) * 4 : nullptr;
+            long long* pr = (p.prof != nullptr && nlocal < 8) ? p.prof + ((int64_t)blockIdx.x * 8 + nlocal) * 8 : nullptr;
             ++nlocal;
 #pragma unroll 1
             for (int r = 0; r < reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
@@ -582,6 +588,8 @@ int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: 
 
 namespace {
 long long* g_tile_prof = nullptr;       // development aid (gpk_tune_tile_prof)
+int64_t g_tile_prof_only = -1;          // tuning knob (gpk_tune(20, v)): stamp only the v-th persistent launch since the knob was set (-1: every one)
+int64_t g_tile_prof_count = 0;
 int g_colmajor_ratio = INT32_MAX;       // tuning knob (gpk_tune(13, v)): column-major tile order from this many times more tile columns than
                                         // rows -- OFF: measured 87 vs 64 ms per cfg5 step although it cuts the fabric-side re-reads of K_zx
 int64_t g_persist_small_below = 512;   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
@@ -607,6 +615,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 4) g_tri_pairs_from = (int)value;
     if (key == 8) g_persist_small_below = value;
     if (key == 13) g_colmajor_ratio = (int)value;
+    if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
 extern "C" int gpk_prof_start(void) {
@@ -900,7 +909,11 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     if (total > INT32_MAX / 2) return GPK_ERR_ARG(1);
     pa.ntiles = (int)total;
     pa.ctrl = ctrl;
-    pa.prof = g_tile_prof;
+    pa.prof = nullptr;
+    if (g_tile_prof != nullptr) {
+        if (g_tile_prof_only < 0 || g_tile_prof_count == g_tile_prof_only) pa.prof = g_tile_prof;
+        ++g_tile_prof_count;
+    }
     if (!ctrl_zeroed && hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
 
     const int per_cu = (ts == 128) ? 2 : 4;

@@ -947,6 +947,58 @@ static void la_one(int n, int nb, int mode, int64_t minrows, int reps, int ldpad
 }
 
 
+// shader clock and k-loop pace of chosen trailing updates INSIDE a look-ahead factorisation:  --la-clock f64|f32 N NB
+template <typename T>
+static void la_clock(int n, int nb, int warm = 0) {
+    const int d = 8, grid = 512;
+    // `warm` big updates enqueued right before every factorisation (no idle in between): what does the load history do to the clock?
+    Dev<T> WP(warm ? (size_t)15360 * 1024 : 1), WC(warm ? (size_t)15360 * 15360 : 1);
+    Dev<unsigned> wctrl(32);
+    if (warm) { WP.up(randv<T>((size_t)15360 * 1024, 0.01)); WC.zero(); }
+    hipEvent_t ea, eb;
+    hipEventCreate(&ea); hipEventCreate(&eb);
+    auto hx = randv<T>((size_t)n * d);
+    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n));
+    Dev<T> dbig((size_t)((n + nb - 1) / nb) * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+    Dev<int> info(1);
+    Dev<long long> prof((size_t)grid * 8 * 8);
+    X.up(hx);
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int kchunks = nb / (int)(128 / sizeof(T));
+    for (int which = -2; which < 10; ++which) {      // two warm-up factorisations, then one per stamped update
+        HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st));
+        gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, st);
+        if (which >= 0) { prof.zero(); }
+        for (int w = 0; w < warm; ++w) {
+            gpk_update_t u{15360, 15360, 1024, WP.p, 1024, WP.p, 1024, WC.p, 15360, WC.p, 15360, 1};
+            gpk_gemm_update2(DT<T>::v, &u, 1, -1.0, wctrl.p, 0, st);
+        }
+        if (which >= 0) { gpk_tune(20, which); gpk_tune_tile_prof(prof.p); }
+        hipEventRecord(ea, st);
+        gpk_potrf_la(DT<T>::v, K.p, n, n, dinv.p, dbig.p, nb, ws.p, info.p, st);
+        hipEventRecord(eb, st);
+        HIPCHK(hipStreamSynchronize(st));
+        gpk_tune_tile_prof(nullptr);
+        float pms = 0; hipEventElapsedTime(&pms, ea, eb);
+        printf("LACLOCK potrf %.3f ms (%d updates enqueued right before it)\n", pms, warm);
+        if (which < 0) continue;
+        auto h = prof.down();
+        for (int ti = 1; ti < 8; ti += 3) {
+            double b = 0, cyc = 0; int cnt = 0;
+            for (int w = 0; w < grid; ++w) {
+                const long long* q = &h[((size_t)w * 8 + ti) * 8];
+                if (q[3] == 0) continue;
+                b += (q[2] - q[1]) * 0.01; cyc += (double)(q[5] - q[4]); ++cnt;
+            }
+            if (cnt) printf("LACLOCK %s n=%d update #%d, tile #%d of a workgroup (%d workgroups): k loop %.1f us = %.3f us per chunk = %.0f cycles per chunk at %.0f MHz\n",
+                            DT<T>::name(), n, which, ti, cnt, b / cnt, b / cnt / kchunks, cyc / cnt / kchunks, cyc / b);
+        }
+    }
+    gpk_tune(20, -1);
+}
+
 // kernel-matrix kernel alone, the shapes of the four GPU configs:  --perf-kmat
 template <typename T>
 static void perf_kmat_case(const char* nm, int nterms, const int* kinds, int64_t n, int64_t m, int d, int batch, int lower) {
@@ -1240,38 +1292,41 @@ static void dispatch_experiment() {
 
 
 // where does a tile of the persistent trailing update spend its time?   --tileprof
-static void tile_profile() {
-    const int n = 15360, k = 1024, grid = 512;
+static void tile_profile(int k = 1024, int lower = 1, int warm = 0) {
+    const int n = 15360, grid = 512;
     Dev<double> P((size_t)n * k), C((size_t)n * n);
     Dev<unsigned> ctrl(32);
-    Dev<long long> prof((size_t)grid * 8 * 4);
+    Dev<long long> prof((size_t)grid * 8 * 8);
     P.up(randv<double>((size_t)n * k, 0.01)); C.zero();
     Timer tm;
     for (int rep = 0; rep < 2; ++rep) {
         prof.zero();
+        gpk_update_t u{n, n, k, P.p, k, P.p, k, C.p, n, C.p, n, lower};
+        // `warm` launches of the same update enqueued right before the measured one: the chip is busy (and clocked up) when it starts
+        for (int w = 0; rep && w < warm; ++w) gpk_gemm_update2(GPK_F64, &u, 1, -1.0, ctrl.p, 0, nullptr);
         gpk_tune_tile_prof(rep ? prof.p : nullptr);
-        gpk_update_t u{n, n, k, P.p, k, P.p, k, C.p, n, C.p, n, 1};
         tm.start();
         gpk_gemm_update2(GPK_F64, &u, 1, -1.0, ctrl.p, 0, nullptr);
         const float ms = tm.stop();
-        printf("TILEPROF update 15360^2 lower k=1024 %s: %.3f ms\n", rep ? "with stamps" : "plain", ms);
+        printf("TILEPROF update 15360^2 %s k=%d %s, %d launches right before it: %.3f ms  %.1f TFLOP/s\n", lower ? "lower" : "full", k, rep ? "with stamps" : "plain (first launch)",
+               rep ? warm : 0, ms, (lower ? 1.0 : 2.0) * n * (double)n * k / ms * 1e-9);
     }
     gpk_tune_tile_prof(nullptr);
     auto h = prof.down();
     for (int ti = 0; ti < 8; ++ti) {
-        double a = 0, b = 0, c = 0, gap = 0; int cnt = 0, cg = 0;
+        double a = 0, b = 0, c = 0, gap = 0, cyc = 0; int cnt = 0, cg = 0;
         for (int w = 0; w < grid; ++w) {
-            const long long* q = &h[((size_t)w * 8 + ti) * 4];
+            const long long* q = &h[((size_t)w * 8 + ti) * 8];
             if (q[3] == 0) continue;
-            a += (q[1] - q[0]) * 0.01; b += (q[2] - q[1]) * 0.01; c += (q[3] - q[2]) * 0.01; ++cnt;
-            if (ti > 0) { const long long* pq = &h[((size_t)w * 8 + ti - 1) * 4]; gap += (q[0] - pq[3]) * 0.01; ++cg; }
+            a += (q[1] - q[0]) * 0.01; b += (q[2] - q[1]) * 0.01; c += (q[3] - q[2]) * 0.01; cyc += (double)(q[5] - q[4]); ++cnt;
+            if (ti > 0) { const long long* pq = &h[((size_t)w * 8 + ti - 1) * 8]; gap += (q[0] - pq[3]) * 0.01; ++cg; }
         }
-        if (cnt) printf("TILEPROF tile #%d of a workgroup (%d workgroups): request C %.1f us | k loop (incl. C arrival, first chunk) %.1f us | stores retired %.1f us | gap to previous tile %.1f us\n",
-                        ti, cnt, a / cnt, b / cnt, c / cnt, cg ? gap / cg : 0.0);
+        if (cnt) printf("TILEPROF tile #%d of a workgroup (%d workgroups): request C %.1f us | k loop (incl. C arrival, first chunk) %.1f us = %.3f us per chunk at %.0f MHz shader clock | stores retired %.1f us | gap to previous tile %.1f us\n",
+                        ti, cnt, a / cnt, b / cnt, b / cnt / (k / 16), cyc / b, c / cnt, cg ? gap / cg : 0.0);
     }
     // start-time spread of the first tiles and of the last stamps
     long long t0 = LLONG_MAX, t1 = 0, e0 = LLONG_MAX, e1 = 0;
-    for (int w = 0; w < grid; ++w) { const long long* q = &h[(size_t)w * 8 * 4]; if (q[3]) { t0 = std::min(t0, q[0]); t1 = std::max(t1, q[0]); } }
+    for (int w = 0; w < grid; ++w) { const long long* q = &h[(size_t)w * 8 * 8]; if (q[3]) { t0 = std::min(t0, q[0]); t1 = std::max(t1, q[0]); } }
     printf("TILEPROF first tiles start within %.1f us of each other\n", (t1 - t0) * 0.01);
 }
 
@@ -1442,7 +1497,11 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--cumask")) { cumask_experiment(); return 0; }
         if (!strcmp(argv[i], "--dispatch")) { dispatch_experiment(); return 0; }
-        if (!strcmp(argv[i], "--tileprof")) { tile_profile(); return 0; }
+        if (!strcmp(argv[i], "--tileprof")) {                  // --tileprof [K [LOWER [WARM]]]
+            const int k = (i + 1 < argc && atoi(argv[i + 1]) > 0) ? atoi(argv[i + 1]) : 1024;
+            tile_profile(k, (i + 2 < argc) ? atoi(argv[i + 2]) : 1, (i + 3 < argc) ? atoi(argv[i + 3]) : 0);
+            return 0;
+        }
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
             rsq_precision();
@@ -1480,6 +1539,11 @@ int main(int argc, char** argv) {
             const int reps = (i + 6 < argc) ? atoi(argv[i + 6]) : 3;
             const int ldpad = (i + 7 < argc) ? atoi(argv[i + 7]) : 0;
             if (!strcmp(argv[i + 1], "f64")) la_one<double>(n, nb, mode, mr, reps, ldpad); else la_one<float>(n, nb, mode, mr, reps, ldpad);
+            return 0;
+        }
+        if (!strcmp(argv[i], "--la-clock") && i + 3 < argc) {
+            const int warm = (i + 4 < argc) ? atoi(argv[i + 4]) : 0;
+            if (!strcmp(argv[i + 1], "f64")) la_clock<double>(atoi(argv[i + 2]), atoi(argv[i + 3]), warm); else la_clock<float>(atoi(argv[i + 2]), atoi(argv[i + 3]), warm);
             return 0;
         }
         if (!strcmp(argv[i], "--perf-la")) {                   // --perf-la [NMAX]
