@@ -21,39 +21,46 @@ import torch
 from . import ops
 from .matrix import LOG_2_PI, Chol, config
 
-__all__ = ["gp_logpdf", "sparse_elbo"]
+__all__ = ["gp_logpdf", "joint_logpdf", "sparse_elbo"]
 
 
-def _grad_inputs(be, terms, x, kinv_lower, alpha, g):
-    """``d logpdf / dx`` (n, D) from the lower triangle of ``K^{-1}`` (consumed: its buffer becomes the cotangent),
-    ``alpha = K^{-1} r`` (n, C) and the C output cotangents ``g``:  G = 1/2 (alpha diag(g) alpha^T - sum(g) K^{-1}),
-    ``dx_i = 2 sum_j G_ij dk(x_i, x_j)/dx_i``."""
-    if x.shape[-1] > 8:
-        raise NotImplementedError("gradients with respect to the inputs are implemented for at most 8 input dimensions")
+def _cotangent(be, kinv_lower, alpha, g):
+    """``G = d logpdf / dK = 1/2 (alpha diag(g) alpha^T - sum(g) K^{-1})`` as an explicit symmetric (n, n) matrix, formed in the
+    buffer of the lower triangle of ``K^{-1}`` (consumed): ``alpha = K^{-1} r`` (n, C), ``g`` the C output cotangents."""
     gt = torch.as_tensor(g, dtype=alpha.dtype, device=alpha.device)
     G = be.symmetrize_(kinv_lower)
-    be.gemm(alpha * gt[None, :], alpha, a_kmajor=True, b_kmajor=True, alpha=0.5, beta=-0.5 * float(sum(g)), out=G)
+    return be.gemm(alpha * gt[None, :], alpha, a_kmajor=True, b_kmajor=True, alpha=0.5, beta=-0.5 * float(sum(g)), out=G)
+
+
+def _grad_inputs(be, terms, x, G):
+    """``d logpdf / dx`` (n, D) from the explicit cotangent: ``dx_i = 2 sum_j G_ij dk(x_i, x_j)/dx_i`` (both arguments of
+    ``k(x, x)`` move with ``x``)."""
+    if x.shape[-1] > 8:
+        raise NotImplementedError("gradients with respect to the inputs are implemented for at most 8 input dimensions")
     _, _, gx = be.kmat_vjp_dense(terms, x, x, G, want_gradx=True)
     return 2.0 * gx
 
 
 class _GPLogpdf(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, noise_vec, kinds, *params):
+    def forward(ctx, x, r, noise_vec, noise_mat, kinds, *params):
         """``params`` = variances then scales (scalar tensors, any device); ``noise_vec`` (n,)
-        or None; ``r = y - mean`` (n, C).  Returns (C,)."""
+        or None; ``noise_mat`` (n, n) dense noise covariance or None; ``r = y - mean`` (n, C).  Returns (C,)."""
         be = ops.get_backend()
         nt = len(kinds)
         variances, scales = params[:nt], params[nt:]
         terms = ops.KTerms([(k, float(v), float(s)) for k, v, s in zip(kinds, variances, scales)])
         n, C = r.shape
         k = be.kmat(terms, x, None, lower=True, diag_add=config.epsilon, diag_vec=noise_vec)
+        if noise_mat is not None:
+            k += noise_mat                                       # (only the lower triangle is read from here on)
         chol = Chol.factor_(k)
         w = chol.solve(r)                                        # L^{-1} r
         _, ss = be.colreduce(w, want_ss=True)
         out = -(chol.logdet() + n * LOG_2_PI + ss) / 2
         ctx.chol, ctx.w, ctx.x, ctx.terms = chol, w, x, terms
         ctx.nt, ctx.has_noise = nt, noise_vec is not None
+        ctx.has_noise_mat = noise_mat is not None
         ctx.param_meta = [(p.device, p.dtype) for p in params]
         ctx.values = ([float(v) for v in variances], [float(s) for s in scales])
         return out
@@ -81,8 +88,14 @@ class _GPLogpdf(torch.autograd.Function):
             grads.append((-2.0 * variances[t] / scales[t] * S[t, 1]).to(device=dev, dtype=dt))
         grad_r = -(alpha * grad_out.reshape(1, -1).to(alpha.dtype))
         grad_noise = diag_g if ctx.has_noise else None
-        grad_x = _grad_inputs(be, terms, x, kinv, alpha, g) if ctx.needs_input_grad[0] else None
-        return (grad_x, grad_r, grad_noise, None, *grads)
+        grad_x = grad_nm = None
+        if ctx.needs_input_grad[0] or (ctx.has_noise_mat and ctx.needs_input_grad[3]):
+            G = _cotangent(be, kinv, alpha, g)                   # explicit, in the buffer of K^{-1}
+            if ctx.needs_input_grad[0]:
+                grad_x = _grad_inputs(be, terms, x, G)
+            if ctx.has_noise_mat and ctx.needs_input_grad[3]:
+                grad_nm = G                                      # d/d noise matrix: the cotangent of K itself
+        return (grad_x, grad_r, grad_noise, grad_nm, None, *grads)
 
 
 class _GPLogpdfBatched(torch.autograd.Function):
@@ -131,7 +144,7 @@ class _GPLogpdfBatched(torch.autograd.Function):
             if grad_noise is not None:
                 grad_noise[b] = diag_g
             if grad_x is not None:
-                grad_x[b] = _grad_inputs(be, terms, x[b], kinv, alpha, [g_host[b]])
+                grad_x[b] = _grad_inputs(be, terms, x[b], _cotangent(be, kinv, alpha, [g_host[b]]))
         variances, scales = ctx.values
         grads = []
         for t in range(nt):
@@ -143,10 +156,98 @@ class _GPLogpdfBatched(torch.autograd.Function):
         return (grad_x, grad_r, grad_noise, None, *grads)
 
 
-def needs_grad(tensor_terms, noise_vec, r, x=None):
+class _JointLogpdf(torch.autograd.Function):
+    """Log-density of SEVERAL processes of one measure observed jointly (``measure.logpdf((f1(x1), y1), (f2(x2), y2))``,
+    ``f(x).logpdf(y)`` of a product process): the variance is the block matrix of ``MultiOutputKernel``, block (i, j) =
+    ``kernels[p_i, p_j](x_i, x_j)``, every block a sum of primitives.  Forward = the plain HIP path (blocks written into one
+    buffer, factorised in place).  Backward: the explicit cotangent ``G = 1/2 (alpha diag(g) alpha^T - sum(g) K^{-1})`` once, then one
+    ``gpk_kmat_vjp_dense`` pass per block of the lower block triangle over its view of ``G`` (off-diagonal blocks count twice: ``G`` and
+    the block matrix are symmetric).  ``layout`` = [(i, j, number of terms)], ``params`` = the variances then scales of block
+    after block: autograd carries them back to the user's leaves through whatever kernel algebra produced them."""
+
+    @staticmethod
+    def forward(ctx, r, noise_vec, build, parts, layout, kinds, *params):
+        be = ops.get_backend()
+        n = r.shape[0]
+        k = build()                                              # lower block triangle + eps + noise on the diagonal
+        chol = Chol.factor_(k)
+        w = chol.solve(r)
+        _, ss = be.colreduce(w, want_ss=True)
+        out = -(chol.logdet() + n * LOG_2_PI + ss) / 2
+        ctx.chol, ctx.w, ctx.parts, ctx.layout, ctx.kinds = chol, w, parts, layout, kinds
+        ctx.has_noise = noise_vec is not None
+        ctx.param_meta = [(p.device, p.dtype) for p in params]
+        ctx.values = [float(p) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        be = ops.get_backend()
+        chol, w = ctx.chol, ctx.w
+        g = [float(v) for v in grad_out.reshape(-1).tolist()]    # host sync: C scalars
+        W = chol.inverse_lower()
+        G = be.gemm(W, W, a_kmajor=False, b_kmajor=False, lower_only=True, tri_k=True)      # K^{-1}, lower triangle
+        alpha = torch.stack([be.colreduce(W, w[:, c], want_dot=True, want_ss=False)[0] for c in range(w.shape[1])], dim=1)
+        G = _cotangent(be, G, alpha, g)
+        offs = [0]
+        for _, xi in ctx.parts:
+            offs.append(offs[-1] + xi.shape[0])
+        grads, pos, kpos = [None] * len(ctx.values), 0, 0
+        for (i, j, nt) in ctx.layout:
+            vals = ctx.values[pos: pos + 2 * nt]
+            variances, scales = vals[:nt], vals[nt:]
+            terms = ops.KTerms([(kd, v, sc) for kd, v, sc in zip(ctx.kinds[kpos: kpos + nt], variances, scales)])
+            gb = G[offs[i]: offs[i + 1], offs[j]: offs[j + 1]]
+            S, _, _ = be.kmat_vjp_dense(terms, ctx.parts[i][1], ctx.parts[j][1], gb)
+            wgt = 1.0 if i == j else 2.0
+            for t in range(nt):
+                dev, dt = ctx.param_meta[pos + t]
+                grads[pos + t] = (wgt * S[t, 0]).to(device=dev, dtype=dt)
+                dev, dt = ctx.param_meta[pos + nt + t]
+                grads[pos + nt + t] = (wgt * -2.0 * variances[t] / scales[t] * S[t, 1]).to(device=dev, dtype=dt)
+            pos += 2 * nt
+            kpos += nt
+        grad_r = -(alpha * grad_out.reshape(1, -1).to(alpha.dtype)) if ctx.needs_input_grad[0] else None
+        grad_noise = torch.diagonal(G).clone() if ctx.has_noise else None
+        return (grad_r, grad_noise, None, None, None, None, *grads)
+
+
+def joint_logpdf(mok, x, noise_vec, r, eps):
+    """Differentiable joint log-density under ``MultiOutputKernel`` ``mok`` at the multi-input ``x``; None when a block of the
+    lower block triangle is not a sum of primitives with scalar hyper-parameters (the caller then refuses)."""
+    kernels = mok.kernels
+    parts = [(pid, xi) for pid, xi in mok._split(x)]
+    if any((not torch.is_tensor(xi)) or xi.dim() != 2 or kernels[pid].num_outputs(xi) != xi.shape[0] for pid, xi in parts):
+        return None                                   # batched inputs / nested product processes: not covered
+    if any(xi.requires_grad for _, xi in parts):
+        return None                                   # d/dx through the block matrix: not covered (the caller refuses)
+    layout, kinds, variances_scales = [], [], []
+    as_t = lambda v: v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64)  # noqa: E731
+    for i, (pi, _) in enumerate(parts):
+        for j in range(i + 1):
+            kern = kernels[pi] if i == j else kernels[pi, parts[j][0]]
+            tt = kern.tensor_terms() if hasattr(kern, "tensor_terms") else None
+            if tt is None:
+                return None
+            layout.append((i, j, len(tt)))
+            kinds.extend(k for k, _, _ in tt)
+            variances_scales.extend([as_t(v) for _, v, _ in tt] + [as_t(sc) for _, _, sc in tt])
+    if not torch.is_grad_enabled() or not (any(p.requires_grad for p in variances_scales) or r.requires_grad
+                                            or (noise_vec is not None and noise_vec.requires_grad)):
+        return None
+
+    def build():
+        return mok.pairwise(x, None, lower=True, diag_add=eps, diag_vec=noise_vec)
+
+    return _JointLogpdf.apply(r, noise_vec, build, parts, tuple(layout), tuple(kinds), *variances_scales)
+
+
+def needs_grad(tensor_terms, noise_vec, r, x=None, noise_mat=None):
     if not torch.is_grad_enabled():
         return False
     if x is not None and torch.is_tensor(x) and x.requires_grad:
+        return True
+    if noise_mat is not None and noise_mat.requires_grad:
         return True
     for _, v, s in tensor_terms:
         if (torch.is_tensor(v) and v.requires_grad) or (torch.is_tensor(s) and s.requires_grad):
@@ -175,15 +276,15 @@ def kernel_requires_grad(kernel, _depth=0):
     return False
 
 
-def gp_logpdf(kernel, x, noise_vec, r):
-    """Differentiable log-density of ``r = y - m(x)`` under ``N(0, k(x) + diag(noise_vec) + eps I)``."""
+def gp_logpdf(kernel, x, noise_vec, r, noise_mat=None):
+    """Differentiable log-density of ``r = y - m(x)`` under ``N(0, k(x) + diag(noise_vec) + noise_mat + eps I)``."""
     tt = kernel.tensor_terms()
     kinds = tuple(k for k, _, _ in tt)
     as_t = lambda v: v if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64)  # noqa: E731
     params = [as_t(v) for _, v, _ in tt] + [as_t(s) for _, _, s in tt]
     if x.dim() == 3:
         return _GPLogpdfBatched.apply(x, r, noise_vec, kinds, *params)
-    return _GPLogpdf.apply(x, r, noise_vec, kinds, *params)
+    return _GPLogpdf.apply(x, r, noise_vec, noise_mat, kinds, *params)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -81,21 +81,49 @@ class FDD(Normal):
         """``Normal.logpdf`` plus a guard: a value that came out cut off from the autograd graph although the process
         has learnable quantities (a posterior / multi-process / dense-noise case outside the differentiable paths)
         is refused, never returned silently detached."""
-        lp = Normal.logpdf(self, x)
-        if torch.is_grad_enabled() and not isinstance(self.p, int) and torch.is_tensor(lp) and not lp.requires_grad:
+        lp, differentiable = Normal._logpdf(self, x)
+        if torch.is_grad_enabled() and not isinstance(self.p, int) and not differentiable:
             from .. import autograd as _ag
             from ..random import _x_requires_grad
 
             nz = self.noise
             noisy = ((isinstance(nz, Diagonal) and nz.diag().requires_grad)
                      or (isinstance(nz, Dense) and nz.mat is not None and nz.mat.requires_grad))
-            if noisy or _x_requires_grad(self._xr) or _ag.kernel_requires_grad(self.p.kernel):
+            if noisy or _x_requires_grad(self._xr) or _ag.kernel_requires_grad(self.p.kernel) or (torch.is_tensor(x) and x.requires_grad):
+                via_prior = self._posterior_logpdf_via_prior(x)
+                if via_prior is not None:
+                    return via_prior
                 raise NotImplementedError(
                     "this log-density is outside the differentiable paths (one process -- or one batch of independent "
                     "data sets -- whose kernel is a sum of primitives, scalar / per-point noise): its value would be "
                     "cut off from the autograd graph.  Wrap the call in torch.no_grad() if that is intended"
                 )
         return lp
+
+    def _posterior_logpdf_via_prior(self, y):
+        """A posterior log-density under learnable quantities, by the chain rule: with the process conditioned on exact
+        observations ``(fdd_obs, y_obs)`` of its prior measure,
+        ``log p(y | y_obs) = log p(y_obs, y) - log p(y_obs)`` -- two PRIOR log-densities, both on the differentiable paths
+        (one process: the fused one; several: the block one).  None when that form does not apply (pseudo-point posteriors,
+        processes built under the posterior measure, several columns of ``y``)."""
+        from .observations import Observations
+
+        link = getattr(self.p.measure, "_conditioned_on", None)
+        parents = getattr(self.p, "_parents", None)
+        if link is None or not parents or len(parents) != 1 or not torch.is_tensor(y):
+            return None
+        prior, obs = link
+        if not isinstance(obs, Observations) or parents[0].measure is not prior:
+            return None
+        y2 = y if y.dim() >= 2 else y[:, None]
+        if y2.dim() != 2 or y2.shape[-1] != 1 or bool(torch.isnan(y2).any()):
+            return None
+        here = FDD(parents[0], self.x, self.noise)
+        joint = prior.logpdf((obs.fdd, obs.y), (here, y2))
+        marginal = prior.logpdf(obs.fdd, obs.y)
+        if not (torch.is_tensor(joint) and joint.requires_grad):
+            return None
+        return joint - marginal
 
     @property
     def dtype(self):

@@ -170,6 +170,7 @@ class Measure:
         posterior.kernels.add_rule(posterior._pids, lambda i, j: obs.posterior_kernel(self, i, j))
         for p in live:
             posterior._register(p)          # (weak) back-reference, measure.py:381-383
+        posterior._conditioned_on = (self, obs)      # for the chain-rule form of differentiable posterior log-densities (fdd.py)
         return posterior
 
     def __or__(self, args):

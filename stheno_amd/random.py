@@ -12,7 +12,7 @@ import types
 import torch
 
 from . import ops
-from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, to_matrix
+from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, config, to_matrix
 
 __all__ = ["Random", "RandomProcess", "RandomVector", "Normal"]
 
@@ -204,6 +204,11 @@ class Normal(RandomVector):
     def logpdf(self, x):
         """Log-density at ``x``: ``(N,)``/``(N, 1)`` -> scalar tensor, ``(N, C)`` -> ``(C,)``,
         batched ``(B, N, 1)`` -> ``(B,)``."""
+        return self._logpdf(x)[0]
+
+    def _logpdf(self, x):
+        """``(value, differentiable)``: whether the value came from one of the autograd paths (``stheno_amd/autograd.py``) --
+        everything else is computed by ``libgpk.so`` on detached buffers, whatever ``value.requires_grad`` says."""
         if not torch.is_tensor(x):
             x = torch.as_tensor(x, dtype=self.dtype, device=self.var.device)
         if x.dim() <= 1:
@@ -228,7 +233,7 @@ class Normal(RandomVector):
                     sub = KernelDense(var.kernel, var.x[idx], noise)
                 else:
                     sub = var.dense()[idx][:, idx]
-                return Normal(mean, sub).logpdf(x[idx])
+                return Normal(mean, sub)._logpdf(x[idx])
 
         var = self.var
         n = self.dim
@@ -239,7 +244,10 @@ class Normal(RandomVector):
         if isinstance(var, KernelDense) and (r.dim() == 2 or batched_ok):
             from . import autograd as _ag
 
-            noise_vec = var.differentiable_noise()
+            noise_vec, noise_mat = var.differentiable_noise(), None
+            if noise_vec is NotImplemented and r.dim() == 2 and isinstance(var.noise, Dense) and var.noise.mat is not None \
+                    and var.noise.mat.dim() == 2:
+                noise_vec, noise_mat = None, var.noise.mat       # a dense noise covariance: its cotangent is that of K
             if noise_vec is not None and noise_vec is not NotImplemented and noise_vec.dim() != r.dim() - 1:
                 noise_vec = NotImplemented
             # k(x) = k0(x / l) with k0 a sum of primitives (l: per-dimension length scales, or none): the fused path runs
@@ -249,14 +257,24 @@ class Normal(RandomVector):
                 kern, scales = view
                 xin = var.x if scales is None else var.x / scales.to(dtype=var.x.dtype, device=var.x.device)
                 tt = kern.tensor_terms()
-                if tt is not None and _ag.needs_grad(tt, noise_vec, r, xin):
+                if tt is not None and _ag.needs_grad(tt, noise_vec, r, xin, noise_mat):
                     if xin.requires_grad and torch.is_grad_enabled() and xin.shape[-1] > 8:
                         raise NotImplementedError("gradients with respect to the inputs (or per-dimension length scales) "
                                                   "are implemented for at most 8 input dimensions")
-                    lp = _ag.gp_logpdf(kern, xin, noise_vec, r)
+                    lp = _ag.gp_logpdf(kern, xin, noise_vec, r, noise_mat)
                     if r.dim() == 3:
-                        return lp
-                    return lp[0] if lp.shape[0] == 1 else lp
+                        return lp, True
+                    return (lp[0] if lp.shape[0] == 1 else lp), True
+        if torch.is_grad_enabled() and isinstance(var, KernelDense) and r.dim() == 2:
+            from . import autograd as _ag
+            from . import kernels as _kk
+
+            if isinstance(var.kernel, _kk.MultiOutputKernel):      # several processes observed jointly
+                noise_vec = var.differentiable_noise()
+                if noise_vec is None or (noise_vec is not NotImplemented and noise_vec.dim() == 1):
+                    lp = _ag.joint_logpdf(var.kernel, var.x, noise_vec, r, config.epsilon)
+                    if lp is not None:
+                        return (lp[0] if lp.shape[0] == 1 else lp), True
         if torch.is_grad_enabled() and isinstance(var, KernelDense):
             from . import autograd as _ag
 
@@ -275,7 +293,7 @@ class Normal(RandomVector):
         logdet = var.logdet()
         iqf = var.iqf_diag(r)
         logpdfs = -(logdet[..., None] + n * LOG_2_PI + iqf) / 2
-        return logpdfs[..., 0] if logpdfs.shape[-1] == 1 else logpdfs
+        return (logpdfs[..., 0] if logpdfs.shape[-1] == 1 else logpdfs), False
 
     def entropy(self):
         return (self.var.logdet() + self.dim * (LOG_2_PI + 1)) / 2

@@ -245,10 +245,17 @@ def test_elbo_gradients_unsupported_cases_are_loud(oracle_backend):
     with pytest.raises(NotImplementedError):        # batched with several columns of y is not
         f(torch.randn(3, 20, 2, dtype=torch.float64), 0.1).logpdf(torch.randn(3, 20, 2, dtype=torch.float64))
     g = st.GP(st.Matern32(), measure=f.measure)
-    with pytest.raises(NotImplementedError):        # several processes observed jointly
-        f.measure.logpdf((f(x[:7], 0.1), y[:7]), (g(x[7:12], 0.1), y[7:12]))
+    # several processes observed jointly: differentiable since round 2 (tests/test_autograd_inputs.py) ...
+    assert f.measure.logpdf((f(x[:7], 0.1), y[:7]), (g(x[7:12], 0.1), y[7:12])).requires_grad
+    dense_noise = torch.eye(7, dtype=torch.float64) * 0.1
+    assert f(x[:7], dense_noise).logpdf(y[:7]).requires_grad       # ... and so is a dense noise covariance
+    post = f | (f(x[:7], 0.1), y[:7])
+    assert post(x[7:12], 0.1).logpdf(y[7:12]).requires_grad          # ... and a posterior log-density (chain rule over two prior ones)
+    sparse_post = f | st.PseudoObs(f(x[:4]), f(x[:9], 0.1), y[:9])
+    with pytest.raises(NotImplementedError):        # a log-density under a PSEUDO-POINT posterior is not
+        sparse_post(x[9:14], 0.1).logpdf(y[9:14])
     with torch.no_grad():                           # ... unless gradients are off
-        assert torch.isfinite(f.measure.logpdf((f(x[:7], 0.1), y[:7]), (g(x[7:12], 0.1), y[7:12])))
+        assert torch.isfinite(sparse_post(x[9:14], 0.1).logpdf(y[9:14]))
     with pytest.raises(NotImplementedError):        # noisy inducing points
         st.PseudoObs(f(x[:5], 0.01), f(x, 0.1), y).elbo(f.measure)
 

@@ -196,12 +196,12 @@ def test_elbo_input_gradients_gpu(hip_backend, kinds, n, m, d, method, ard):
 
 
 def test_learnable_length_scale_vector_outside_the_differentiable_paths_is_loud(oracle_backend):
-    """A posterior log-density under learnable per-dimension length scales is not covered: it refuses (no detached value)."""
+    """A log-density under a pseudo-point posterior with learnable per-dimension length scales is not covered: it refuses."""
     x = torch.randn(20, 2, dtype=torch.float64)
     y = torch.randn(20, 1, dtype=torch.float64)
     ls = torch.tensor([0.9, 1.3], dtype=torch.float64, requires_grad=True)
     f = st.GP(st.EQ().stretch(ls))
-    post = f | (f(x[:10], 0.1), y[:10])
+    post = f | st.PseudoObs(f(x[:4]), f(x[:10], 0.1), y[:10])
     with pytest.raises(NotImplementedError):
         post(x[10:], 0.1).logpdf(y[10:])
     with torch.no_grad():
@@ -210,3 +210,148 @@ def test_learnable_length_scale_vector_outside_the_differentiable_paths_is_loud(
     x9 = torch.randn(12, 9, dtype=torch.float64, requires_grad=True)
     with pytest.raises(NotImplementedError):
         st.GP(st.EQ())(x9, 0.1).logpdf(torch.randn(12, 1, dtype=torch.float64))
+
+
+# ---------------------------------------------------------------------------------------------
+# Several processes of one measure observed jointly: gradients of the joint log-density w.r.t. the hyper-parameters of the
+# component kernels, the noises and y, against finite differences of the joint Gaussian built block by block in NumPy.
+# ---------------------------------------------------------------------------------------------
+def run_joint_logpdf(dev, dtype, tol):
+    rng = np.random.default_rng(17)
+    n1, n2, d = 25, 35, 2
+    x1, x2 = rng.standard_normal((n1, d)), rng.standard_normal((n2, d))
+    y1, y2 = rng.standard_normal((n1, 1)), rng.standard_normal((n2, 1))
+    p0 = np.array([1.3, 0.9, 0.7, 1.4, 0.2, 0.3])          # v1, s1, v2, s2, noise1, noise2
+
+    def kmat(kind, v, s_, a, b):
+        d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        return v * O._kappa(kind, d2 / s_**2, (a @ b.T) / s_**2)
+
+    def value(p):
+        v1, s1, v2, s2, nz1, nz2 = p
+        # f1 ~ GP(v1 EQ / s1), f2 ~ GP(v2 Matern32 / s2) independent, f = f1 + f2; observed: f1 at x1, f at x2
+        k11 = kmat("eq", v1, s1, x1, x1) + nz1 * np.eye(n1)
+        k22 = kmat("eq", v1, s1, x2, x2) + kmat("matern32", v2, s2, x2, x2) + nz2 * np.eye(n2)
+        k21 = kmat("eq", v1, s1, x2, x1)
+        joint = np.block([[k11, k21.T], [k21, k22]])
+        return float(O.normal_logpdf(None, joint, np.concatenate([y1, y2])))
+
+    ref = fd_grad(value, p0.copy())
+    ts = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in p0]
+    m = st.Measure()
+    f1 = st.GP(ts[0] * st.EQ().stretch(ts[1]), measure=m)
+    f2 = st.GP(ts[2] * st.Matern32().stretch(ts[3]), measure=m)
+    f = f1 + f2
+    T_ = lambda a: torch.tensor(a, dtype=dtype, device=dev)  # noqa: E731
+    ty2 = T_(y2).requires_grad_(True)
+    lp = m.logpdf((f1(T_(x1), ts[4].to(dtype=dtype, device=dev)), T_(y1)), (f(T_(x2), ts[5].to(dtype=dtype, device=dev)), ty2))
+    assert lp.requires_grad and abs(float(lp) - value(p0)) <= tol * abs(value(p0))
+    lp.backward()
+    got = np.array([float(t.grad) for t in ts])
+    assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1.0), (got, ref)
+
+    def value_y(yy):
+        nonlocal y2
+        keep, y2 = y2, yy.reshape(n2, 1)
+        try:
+            return value(p0)
+        finally:
+            y2 = keep
+
+    ref_y = fd_grad(value_y, y2.copy().ravel(), h=1e-5)
+    assert np.max(np.abs(ty2.grad.double().cpu().numpy().ravel() - ref_y)) <= tol * max(np.max(np.abs(ref_y)), 1.0)
+
+
+def test_joint_logpdf_gradients_host_logic(oracle_backend):
+    run_joint_logpdf("cpu", torch.float64, 2e-6)
+
+
+@pytest.mark.gpu
+def test_joint_logpdf_gradients_gpu(hip_backend):
+    run_joint_logpdf("cuda", torch.float64, 5e-6)
+
+
+def run_dense_noise(dev, dtype, tol):
+    """``f(x, N).logpdf(y)`` with a dense noise covariance ``N = c B B^T + 0.1 I``: d/dc (through the matrix), d/d kernel, d/dx."""
+    rng = np.random.default_rng(23)
+    n, d = 40, 2
+    x, y = rng.standard_normal((n, d)), rng.standard_normal((n, 1))
+    Bm = rng.standard_normal((n, 3))
+    p0 = np.array([1.2, 0.8, 0.5])                          # variance, scale, c
+
+    def value(p, xx=None):
+        xx = x if xx is None else xx
+        d2 = ((xx[:, None, :] - xx[None, :, :]) ** 2).sum(-1)
+        k = p[0] * np.exp(-0.5 * d2 / p[1] ** 2) + p[2] * Bm @ Bm.T + 0.1 * np.eye(n)
+        return float(O.normal_logpdf(None, k, y))
+
+    ref = fd_grad(value, p0.copy())
+    ts = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in p0]
+    tx = torch.tensor(x, dtype=dtype, device=dev, requires_grad=True)
+    tb = torch.tensor(Bm, dtype=dtype, device=dev)
+    noise = ts[2].to(dtype=dtype, device=dev) * (tb @ tb.T) + 0.1 * torch.eye(n, dtype=dtype, device=dev)
+    lp = st.GP(ts[0] * st.EQ().stretch(ts[1]))(tx, noise).logpdf(torch.tensor(y, dtype=dtype, device=dev))
+    assert lp.requires_grad and abs(float(lp) - value(p0)) <= tol * abs(value(p0))
+    lp.backward()
+    got = np.array([float(t.grad) for t in ts])
+    assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1.0), (got, ref)
+    i, cd = n // 3, 1
+    xp, xm = x.copy(), x.copy()
+    xp[i, cd] += 1e-6; xm[i, cd] -= 1e-6
+    fdx = (value(p0, xp) - value(p0, xm)) / 2e-6
+    assert abs(float(tx.grad[i, cd]) - fdx) <= tol * max(abs(fdx), 1.0)
+
+
+def test_dense_noise_gradients_host_logic(oracle_backend):
+    run_dense_noise("cpu", torch.float64, 2e-6)
+
+
+@pytest.mark.gpu
+def test_dense_noise_gradients_gpu(hip_backend):
+    run_dense_noise("cuda", torch.float64, 5e-6)
+
+
+def run_posterior_logpdf(dev, dtype, tol):
+    """Predictive log-density ``(f | (f(x1, n1), y1))(x2, n2).logpdf(y2)`` under learnable hyper-parameters (the held-out
+    log-likelihood objective): chain rule over two prior log-densities; values against the non-differentiable posterior path,
+    gradients against finite differences of the conditional Gaussian."""
+    rng = np.random.default_rng(29)
+    n1, n2, d = 30, 12, 2
+    x1, x2 = rng.standard_normal((n1, d)), rng.standard_normal((n2, d))
+    y1, y2 = rng.standard_normal((n1, 1)), rng.standard_normal((n2, 1))
+    p0 = np.array([1.1, 0.9, 0.25])                          # variance, scale, noise
+
+    def value(p):
+        def km(a, b):
+            d2 = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+            return p[0] * np.exp(-0.5 * d2 / p[1] ** 2)
+        k11 = km(x1, x1) + p[2] * np.eye(n1)
+        k21 = km(x2, x1)
+        sol = np.linalg.solve(k11, np.concatenate([y1, k21.T], axis=1))
+        mean = k21 @ sol[:, :1]
+        cov = km(x2, x2) + p[2] * np.eye(n2) - k21 @ sol[:, 1:]
+        return float(O.normal_logpdf(mean, cov, y2))
+
+    ref = fd_grad(value, p0.copy())
+    ts = [torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in p0]
+    T_ = lambda a: torch.tensor(a, dtype=dtype, device=dev)  # noqa: E731
+    f = st.GP(ts[0] * st.EQ().stretch(ts[1]))
+    nz = ts[2].to(dtype=dtype, device=dev)
+    post = f | (f(T_(x1), nz), T_(y1))
+    lp = post(T_(x2), nz).logpdf(T_(y2))
+    assert lp.requires_grad and abs(float(lp) - value(p0)) <= tol * abs(value(p0))
+    with torch.no_grad():
+        plain = post(T_(x2), nz).logpdf(T_(y2))
+    assert abs(float(plain) - float(lp)) <= 1e-8 * abs(float(lp))
+    lp.backward()
+    got = np.array([float(t.grad) for t in ts])
+    assert np.max(np.abs(got - ref)) <= tol * max(np.max(np.abs(ref)), 1.0), (got, ref)
+
+
+def test_posterior_logpdf_gradients_host_logic(oracle_backend):
+    run_posterior_logpdf("cpu", torch.float64, 5e-6)
+
+
+@pytest.mark.gpu
+def test_posterior_logpdf_gradients_gpu(hip_backend):
+    run_posterior_logpdf("cuda", torch.float64, 1e-5)
