@@ -258,12 +258,14 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
  * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 13: column-major GEMM tile order from this ratio of
  * tile columns to tile rows (off by default); 17: 1 = one-workgroup-per-matrix TRSV for batches of small factors;
- * 18: 1 = the CUs reserved for the look-ahead chain rejoin the trailing update once the chain is done (default).
+ * 18: 1 = the CUs reserved for the look-ahead chain rejoin the trailing update once the chain is done (default);
+ * 20: gpk_tune_tile_prof stamps only the v-th persistent launch since this knob was set (-1 = every launch).
  * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);
-/* device buffer (grid x 8 tiles x 4 int64, or NULL): wall-clock stamps (10 ns ticks) of the persistent update's tiles:
- * entry / C tile requested / k loop done / stores retired. */
+/* device buffer (grid x 8 tiles x 8 int64, or NULL): stamps of the persistent update's first 8 tiles per workgroup:
+ * [0..3] wall clock (10 ns ticks) at entry / C tile requested / k loop done / stores retired, [4], [5] shader-cycle
+ * counter at the start and the end of the k loop (so the clock the loop ran at can be read off), [6], [7] unused. */
 void gpk_tune_tile_prof(long long* dev_buf);
 
 /* Strided 2-D copy (rows x cols). */
