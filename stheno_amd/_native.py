@@ -125,4 +125,8 @@ def load():
         import atexit
 
         atexit.register(lib.gpk_shutdown)      # helper streams must not outlive the HIP runtime's own teardown
+        # development aid for A/B runs of the library's tuning knobs (gpk_tune in include/gpk.h): GPK_TUNE="21=0,9=4096"
+        for item in filter(None, os.environ.get("GPK_TUNE", "").split(",")):
+            key, _, value = item.partition("=")
+            lib.gpk_tune(int(key), int(value))
     return _LIB
