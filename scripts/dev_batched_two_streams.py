@@ -1,0 +1,45 @@
+"""Experiment: cfg4 (512 x N=2048 fp32 logpdf) as ONE batch on one stream vs 2 / 4 sub-batches on separate streams
+(low-efficiency phases of one sub-batch -- diagonal blocks, K=128 panel work -- under the trailing GEMMs of another)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import stheno_amd as st  # noqa: E402
+
+st.B.epsilon = 1e-6
+B, n, d = 512, 2048, 3
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, n, d, generator=g, dtype=torch.float32).cuda()
+y = torch.randn(B, n, 1, generator=g, dtype=torch.float32).cuda()
+f = st.GP(st.EQ())
+
+
+def run(parts):
+    streams = [torch.cuda.Stream() for _ in range(parts)]
+    step = B // parts
+    outs = [None] * parts
+    cur = torch.cuda.current_stream()
+    for i, s in enumerate(streams):
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            outs[i] = f(x[i * step:(i + 1) * step], 0.1).logpdf(y[i * step:(i + 1) * step])
+    for s in streams:
+        cur.wait_stream(s)
+    return torch.cat(outs)
+
+
+ref = None
+for parts in (1, 2, 4, 1, 2, 4):
+    for _ in range(2):
+        out = run(parts) if parts > 1 else f(x, 0.1).logpdf(y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out = run(parts) if parts > 1 else f(x, 0.1).logpdf(y)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    if ref is None:
+        ref = out
+    print(f"parts={parts}: {ms:.2f} ms per 512 GPs, max |diff| vs one batch {float((out - ref).abs().max()):.3e}")
