@@ -574,10 +574,8 @@ LaDevice* la_device() {
     LaDevice& d = g_la_dev[dev];
     if (d.aux == nullptr) {
         unsigned keys[8];
-        if (gpk_helper_stream(&d.aux, keys) != GPK_OK) {
-            d.aux = nullptr;
-            return nullptr;
-        }
+        // no CU-masked stream on this device (refused by the runtime): the same algorithm runs on one stream, without the overlap
+        if (gpk_helper_stream(&d.aux, keys) != GPK_OK) d.aux = nullptr;
     }
     return &d;
 }
@@ -727,7 +725,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, nb, T(-1), P1, ld, 0, P1, ld, 0, T(1),
                                 A + k1 * ld + k1, ld, 0, 1, 1, stream);
         if (st) return st;
-        const bool overlap = g_la_mode == 1 && (n - k2) >= g_la_min_rows;
+        const bool overlap = g_la_mode == 1 && dev->aux != nullptr && (n - k2) >= g_la_min_rows;
         hipEvent_t e_fork = nullptr, e_join = nullptr;
         if (overlap) {
             e_fork = la_event(*dev, ev++);
