@@ -22,6 +22,10 @@ class _Config:
     #: raise ``torch.linalg.LinAlgError`` for non-positive-definite matrices (costs one
     #: 4-byte device->host read per factorisation)
     check_info = True
+    #: scan `y` for NaN (missing observations, ``random.py:262-264`` / ``observations.py:73-74``) before a log-density / conditioning;
+    #: the scan is a device reduction plus ONE host read of its flag -- set False when `y` is known to be complete and the host should
+    #: not wait for the device there
+    check_nan = True
     #: outer block of the blocked Cholesky (0 = library default)
     potrf_nbo = 0
     #: single matrices of at least this order take the look-ahead factorisation (``gpk_potrf_la``); 0 disables it

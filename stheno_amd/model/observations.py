@@ -103,8 +103,8 @@ class AbstractObservations:
             y = y.reshape(-1, 1)
         if y.shape[-1] != 1:
             raise ValueError(f"Invalid shape of observed values {y_shape}.")
-        # Missing data (host sync, as in the reference: observations.py:73-76).
-        if y.dim() == 2:
+        # Missing data (host sync, as in the reference: observations.py:73-76; opt out with `config.check_nan = False`).
+        if config.check_nan and y.dim() == 2:
             available = ~torch.isnan(y[:, 0])
             if not bool(available.all()):
                 fdd = take(fdd, available)

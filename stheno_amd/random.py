@@ -215,7 +215,7 @@ class Normal(RandomVector):
             x = x.reshape(-1, 1)
 
         # Missing data (not for batched computation): random.py:261-270.
-        if x.dim() == 2 and x.shape[1] == 1:
+        if config.check_nan and x.dim() == 2 and x.shape[1] == 1:
             available = ~torch.isnan(x[:, 0])
             if not bool(available.all()):
                 idx = torch.nonzero(available)[:, 0]

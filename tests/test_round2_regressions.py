@@ -284,3 +284,20 @@ def test_per_dimension_length_scales(dtype):
     assert lp.requires_grad
     lp.backward()
     assert ls.grad.shape == (3,) and bool(torch.isfinite(ls.grad).all())
+
+
+def test_nan_scan_can_be_switched_off():
+    """``config.check_nan = False``: no device->host read of the NaN flag; values for complete data are unchanged."""
+    from stheno_amd.matrix import config
+
+    rng = np.random.default_rng(31)
+    x, y = rng.standard_normal((40, 2)), rng.standard_normal((40, 1))
+    f = st.GP(st.EQ())
+    want = float(f(T(x), 0.2).logpdf(T(y)))
+    post_want = (f | (f(T(x), 0.2), T(y)))(T(x[:5])).mean
+    config.check_nan = False
+    try:
+        assert abs(float(f(T(x), 0.2).logpdf(T(y))) - want) <= 1e-12 * abs(want)
+        assert rel((f | (f(T(x), 0.2), T(y)))(T(x[:5])).mean, post_want.cpu().numpy()) < 1e-12
+    finally:
+        config.check_nan = True
