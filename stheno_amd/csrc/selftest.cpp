@@ -1071,9 +1071,10 @@ static void gemm_one(int M, int N, int K, int flags, int reps, int64_t lda = -1)
     Timer tm;
     for (int rep = 0; rep < reps; ++rep) {
         tm.start();
-        gpk_gemm(DT<T>::v, 1, 1, M, N, K, -1.0, A.p, lda, 0, B.p, K, 0, (flags & 32) ? 0.0 : 1.0, C.p, N, 0, 1, flags & 15, nullptr);
+        // flags: 1/2/4/8 as in gpk.h, 32: beta = 0, 64: B stored K x N (n contiguous)
+        gpk_gemm(DT<T>::v, 1, (flags & 64) ? 0 : 1, M, N, K, -1.0, A.p, lda, 0, B.p, (flags & 64) ? N : K, 0, (flags & 32) ? 0.0 : 1.0, C.p, N, 0, 1, flags & 15, nullptr);
         const float ms = tm.stop();
-        const double fl = ((flags & 9) ? 1.0 : 2.0) * M * (double)N * K;
+        const double fl = ((flags & 13) ? 1.0 : 2.0) * M * (double)N * K;
         printf("GEMM %s M=%d N=%d K=%d flags=%d lda=%lld  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), M, N, K, flags, (long long)lda, ms, fl / ms * 1e-9);
     }
 }
