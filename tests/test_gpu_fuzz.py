@@ -80,3 +80,23 @@ def test_pseudo_point_ragged_shapes(seed, dtype):
         ref = O.pseudo_obs(terms, x, noise, y, z, method=method, eps=e)
         assert abs(float(obs.elbo(f.measure)) - ref["elbo"]) <= tol * abs(ref["elbo"]), (method, n, m, d)
         assert rel(obs.mu(f.measure), ref["mu"]) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("seed", range(8))
+def test_batched_ragged_shapes(seed, dtype):
+    """Leading batch axis (``tests/model/test_cases.py:134-155``) with ragged B, N, D: one launch sequence for all data sets."""
+    rng = np.random.default_rng(9000 + seed)
+    bsz = int(rng.choice([1, 3, 8, 17, 70]))
+    n = int(rng.choice([5, 64, 129, 200, 333]))
+    d = int(rng.integers(1, 9))
+    kinds = [str(k) for k in rng.choice(ALL_KINDS, size=int(rng.integers(1, 4)), replace=True)]
+    terms = [(k, float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.6, 2.5)) * np.sqrt(d)) for k in kinds]
+    x, y = rng.standard_normal((bsz, n, d)), rng.standard_normal((bsz, n, 1))
+    noise = float(rng.uniform(0.05, 0.5))
+    tol, e = TOL[dtype], EPS[dtype]
+    with eps(e):
+        f = st.GP(sum(v * KINDS[k]().stretch(s) for k, v, s in terms))
+        lp = f(dev(x, dtype), noise).logpdf(dev(y, dtype))
+        assert lp.shape == (bsz,)
+        assert rel(lp, O.gp_logpdf_batched(terms, x, noise, y, eps=e)) < tol, (terms, x.shape)
