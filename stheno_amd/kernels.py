@@ -76,7 +76,11 @@ def uprank(x):
     if isinstance(x, MultiInput):
         return x
     if not torch.is_tensor(x):
+        # host data (NumPy arrays, lists, Python numbers -- what the reference's default backend is fed): one copy to the
+        # device the HIP backend computes on; tensors stay where the caller put them (a CPU tensor is refused by the backend)
         x = torch.as_tensor(x)
+        if ops.get_backend().name == "hip":
+            x = x.to(torch.device("cuda", torch.cuda.current_device()))
     if x.dim() == 0:
         return x.reshape(1, 1)
     if x.dim() == 1:

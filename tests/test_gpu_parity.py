@@ -347,3 +347,20 @@ def test_lookahead_factorisation_through_the_api(dtype, n):
     finally:
         matrix.config.potrf_lookahead_from = old
     assert nb not in c2._dinv_sb and rel(torch.tril(c.l), torch.tril(c2.l).double().cpu().numpy()) < tol
+
+
+def test_numpy_inputs_are_moved_to_the_device():
+    """The reference's default backend is fed NumPy arrays (``README.md:43-86``): host data given to the HIP path is copied
+    to the device once; results are device tensors (``B.to_numpy`` brings them back)."""
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "readme_kats.json")))
+    x = np.linspace(0, 2, 10)
+    y = x ** 2
+    f = st.GP(st.EQ())
+    post = f | (f(x), y)
+    pred = post(np.array([1.0, 2.0, 3.0]))
+    assert pred.mean.device.type == "cuda"
+    assert rel(pred.mean[:, 0], [1.00000068, 3.99999999, 8.4825932]) < 1e-6       # README.md:58-61
+    lp = f(x, 0.1).logpdf(y)
+    assert lp.device.type == "cuda" and abs(float(lp) - O.gp_logpdf([("eq", 1.0, 1.0)], x, 0.1, y[:, None])) < 1e-9
+    assert isinstance(B.to_numpy(pred.mean), np.ndarray)
+    assert kat is not None
