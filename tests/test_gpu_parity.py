@@ -321,9 +321,9 @@ def test_normal_arithmetic_and_kl_on_device():
     assert rel(B.dense(n1.m2), v1 + m1 @ m1.T) < 1e-13
 
 
-@pytest.mark.parametrize("dtype,n", [(torch.float64, 6144 + 37), (torch.float32, 6144 + 128)])
+@pytest.mark.parametrize("dtype,n", [(torch.float64, 8192 + 37), (torch.float32, 8192 + 128)])
 def test_lookahead_factorisation_through_the_api(dtype, n):
-    """Orders from 6144 take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
+    """Orders from 8192 take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
     against LAPACK, the merged block inverses it returns against what the solves then compute, ragged order included."""
     from stheno_amd import matrix
 
@@ -331,7 +331,7 @@ def test_lookahead_factorisation_through_the_api(dtype, n):
     x = rng.standard_normal((n, 4))
     k = O.kernel_matrix([("eq", 1.0, 1.0)], x) + 0.5 * np.eye(n)
     c = Chol.factor_(dev(k, dtype).clone())
-    nb = matrix.config.potrf_lookahead_nb[dtype]
+    nb = 512 if n < matrix.config.potrf_lookahead_wide_from else matrix.config.potrf_lookahead_nb[dtype]
     assert nb in c._dinv_sb and c._dinv_sb[nb].shape[-3] == (n + nb - 1) // nb      # the look-ahead path ran
     l_ref = np.linalg.cholesky(k)
     tol = 1e-10 if dtype == torch.float64 else 2e-4
