@@ -254,7 +254,7 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * measured optima, the product path never calls these.  key 1: use 64x64 GEMM tiles below this many 128-tiles;
  * 2: XCD super-tile order from this many tiles; 4: row-pair tile order from this many tiles; 6: look-ahead overlaps while the trailing matrix has at least this many
  * rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the persistent update takes 64x64 tiles
- * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm;
+ * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm (0 = 4096 with blocks up to 512, 6144 above);
  * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
  * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 13: column-major GEMM tile order from this ratio of
  * tile columns to tile rows (off by default); 17: 1 = one-workgroup-per-matrix TRSV for batches of small factors;

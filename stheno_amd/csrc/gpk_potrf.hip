@@ -562,7 +562,8 @@ struct LaDevice {
 std::mutex g_la_mutex;
 LaDevice g_la_dev[64];
 int64_t g_la_min_rows = 2048;     // tuning knob (gpk_tune(6, v)): overlap while the trailing matrix has >= this many rows
-int64_t g_la_tail_rows = 6144;    // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path
+int64_t g_la_tail_rows = 0;       // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path;
+                                  // 0 = by block width: 4096 with nb <= 512, 6144 above (N = 8192, nb = 512: 6.69 vs 7.04 ms)
 int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
 int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
 int g_la_rejoin = 1;              // tuning knob (gpk_tune(18, v)): reserved CUs rejoin the trailing update after the chain
@@ -693,7 +694,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         return gpk_trtri_merge_launch<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB),
                                          nb, dinv_big + (k / nb) * per, Tp, stream);   // the panel workspace is free by now
     };
-    if (n <= g_la_tail_rows) return finish_plain(0);
+    const int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : (nb <= 512 ? 4096 : 6144);
+    if (n <= tail_rows) return finish_plain(0);
 
     int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, 0, stream);
     if (st) return st;
@@ -714,7 +716,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         }
         if (st) return st;
         const T* P1 = A + k1 * ld + k0;
-        if (n - k1 <= g_la_tail_rows) {
+        if (n - k1 <= tail_rows) {
             // last look-ahead step: the whole trailing matrix is updated in place, the rest is factorised the plain way
             GpkSeg<T> sg{n - k1, n - k1, nb, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0};
             st = gpk_gemm_persist_launch<T>(&sg, 1, T(-1), ctrl, 0, stream);

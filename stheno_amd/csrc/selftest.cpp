@@ -486,7 +486,7 @@ static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_
     dA.up(A); dRef.up(A); info.zero(); info2.zero();
     gpk_tune(7, mode); gpk_tune(6, min_rows); gpk_tune(9, tail_rows);
     const int st = gpk_potrf_la(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
-    gpk_tune(7, 1); gpk_tune(6, 2048); gpk_tune(9, 6144);
+    gpk_tune(7, 1); gpk_tune(6, 2048); gpk_tune(9, 0);
     const int st2 = gpk_potrf(DT<T>::v, dRef.p, n, ld, 0, 1, dinv2.p, info2.p, 0, nullptr);
     HIPCHK(hipDeviceSynchronize());
     auto L = dA.down(), R = dRef.down();
@@ -568,7 +568,7 @@ static void test_lookahead() {
             dA.up(A); info.zero();
             gpk_tune(6, 0); gpk_tune(9, tail);
             const int st = gpk_potrf_la(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
-            gpk_tune(6, 2048); gpk_tune(9, 6144);
+            gpk_tune(6, 2048); gpk_tune(9, 0);
             HIPCHK(hipDeviceSynchronize());
             char nm[160];
             snprintf(nm, sizeof nm, "potrf_la_%s not PD (tail %lld): info %d (expect %d) st%d", DT<T>::name(), (long long)tail, info.down()[0], bad + 1, st);
