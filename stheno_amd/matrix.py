@@ -29,7 +29,7 @@ class _Config:
     #: outer block of the blocked Cholesky (0 = library default)
     potrf_nbo = 0
     #: single matrices of at least this order take the look-ahead factorisation (``gpk_potrf_la``); 0 disables it
-    potrf_lookahead_from = 8192
+    potrf_lookahead_from = 7168
     #: its outer block = the order of the explicitly inverted diagonal blocks: 512 below `potrf_lookahead_wide_from`, else the
     #: per-dtype value (measured on MI355X, fp64 / fp32 alike: N = 8192: 6.95 ms at 512, 7.42 at 1024, 7.33 plain;
     #: N = 12288: 15.1 / 15.6 / 16.8; N = 14336: 21.5 / 21.2 / 23.7; N = 16384: 29.8 / 28.7 / 32.6)

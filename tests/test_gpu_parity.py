@@ -323,7 +323,7 @@ def test_normal_arithmetic_and_kl_on_device():
 
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 8192 + 37), (torch.float32, 8192 + 128)])
 def test_lookahead_factorisation_through_the_api(dtype, n):
-    """Orders from 8192 take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
+    """Orders from 7168 take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
     against LAPACK, the merged block inverses it returns against what the solves then compute, ragged order included."""
     from stheno_amd import matrix
 
