@@ -125,8 +125,11 @@ def load():
         import atexit
 
         atexit.register(lib.gpk_shutdown)      # helper streams must not outlive the HIP runtime's own teardown
-        # development aid for A/B runs of the library's tuning knobs (gpk_tune in include/gpk.h): GPK_TUNE="21=0,9=4096"
-        for item in filter(None, os.environ.get("GPK_TUNE", "").split(",")):
-            key, _, value = item.partition("=")
-            lib.gpk_tune(int(key), int(value))
+        # Development aid for A/B runs of the library's tuning knobs (gpk_tune in include/gpk.h), e.g.
+        # GPK_DEV=1 GPK_TUNE="21=0,9=4096".  Ignored unless GPK_DEV=1 is set as well: a stray GPK_TUNE in a user's
+        # environment must not change what the product path runs.
+        if os.environ.get("GPK_DEV") == "1":
+            for item in filter(None, os.environ.get("GPK_TUNE", "").split(",")):
+                key, _, value = item.partition("=")
+                lib.gpk_tune(int(key), int(value))
     return _LIB

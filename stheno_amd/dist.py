@@ -30,6 +30,12 @@ def _world(group):
     return 1, 0
 
 
+def _collective(group):
+    """The exchange step runs whenever a process group exists -- also a one-rank group (RCCL then copies in place): the
+    single-GPU run of a sharded job exercises the same calls as the 8-GPU one.  Without a process group there is nothing to call."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def sharded_logpdf(process, x_local, noise, y_local, total, group=None):
     """Log-densities of ``total`` independent GPs, of which this rank holds the shard
     ``x_local`` (b_local, N, D) / ``y_local`` (b_local, N, 1) given by :func:`shard_bounds`.
@@ -39,7 +45,7 @@ def sharded_logpdf(process, x_local, noise, y_local, total, group=None):
     if x_local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} should hold {hi - lo} GPs, got {x_local.shape[0]}")
     local = process(x_local, noise).logpdf(y_local).reshape(-1)
-    if world == 1:
+    if not _collective(group):
         return local
     sizes = [h - l for l, h in (shard_bounds(total, world, r) for r in range(world))]
     width = max(sizes)
@@ -57,9 +63,8 @@ def sharded_logpdf(process, x_local, noise, y_local, total, group=None):
 
 def sharded_logpdf_sum(process, x_local, noise, y_local, group=None):
     """Sum of the log-densities over all ranks' GPs (one-scalar all-reduce)."""
-    world, _ = _world(group)
     s = process(x_local, noise).logpdf(y_local).sum().reshape(1)
-    if world > 1:
+    if _collective(group):
         dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     return s[0]
 
@@ -76,10 +81,8 @@ def sharded_elbo(obs, measure, group=None):
     2 * (7/8) * 67 MB / 153 GB/s = 0.8 ms, per-link bound on xGMI -- then every rank finishes the
     M x M solve and holds the same ELBO (``stheno/model/observations.py:279-336`` with the
     sums over observations distributed)."""
-    world, _ = _world(group)
-
     def reduce(stats):
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
 
     if torch.is_grad_enabled() and obs._differentiable_requested(measure):

@@ -14,6 +14,7 @@ dependency that ``stheno/model/*.py`` uses:
 Inputs follow the reference's conventions: ``(N,)`` -> ``(N, 1)``; ``(N, D)``;
 ``(B, N, D)`` batched.
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -100,6 +101,18 @@ def _as_float(v):
             raise ValueError("kernel hyper-parameters must be scalars")
         return float(v.detach())
     return float(v)
+
+
+_UNSET = object()
+
+
+def _is_vector_scale(scale):
+    """One length scale per input dimension (torch tensor, NumPy array, list or tuple with more than one entry)?"""
+    if torch.is_tensor(scale):
+        return scale.numel() > 1
+    if isinstance(scale, (list, tuple)):
+        return True
+    return np.ndim(scale) > 0 and np.size(scale) > 1
 
 
 def _as_param(v):
@@ -197,7 +210,7 @@ class Kernel:
 
     def stretch(self, scale):
         """``k.stretch(l)``: ``k(x / l, y / l)``.  ``l``: a scalar, or one length scale per input dimension."""
-        if (torch.is_tensor(scale) and scale.numel() > 1) or isinstance(scale, (list, tuple)):
+        if _is_vector_scale(scale):
             return InputScaled(self, scale)
         return Stretched(self, _as_param(scale))
 
@@ -379,7 +392,7 @@ class InputScaled(Kernel):
         return self.k.elwise(self._scaled(x), **kw)
 
     def stretch(self, scale):
-        if (torch.is_tensor(scale) and scale.numel() > 1) or isinstance(scale, (list, tuple)):
+        if _is_vector_scale(scale):
             return InputScaled(self.k, self.scales * torch.as_tensor(scale).to(self.scales))
         return InputScaled(self.k, self.scales * _as_float(scale))
 
@@ -409,6 +422,7 @@ class Sum(Kernel):
     def __init__(self, a, b):
         self.a, self.b = a, b
         self.stationary = a.stationary and b.stationary
+        self._view = _UNSET
 
     def num_outputs(self, x):
         return self.a.num_outputs(x)
@@ -426,12 +440,21 @@ class Sum(Kernel):
         return _merge_terms(ta + tb)
 
     def input_scaled_view(self):
+        # asked several times per FDD / log-density: the comparison of the two length-scale vectors (a device-to-host
+        # synchronisation when they live on the GPU) is made once per kernel object
+        if self._view is _UNSET:
+            self._view = self._input_scaled_view()
+        return self._view
+
+    def _input_scaled_view(self):
         va, vb = self.a.input_scaled_view(), self.b.input_scaled_view()
         if va is None or vb is None:
             return None
         sa, sb = va[1], vb[1]
         same = (sa is sb) or (sa is not None and sb is not None and sa.shape == sb.shape and not sa.requires_grad
-                              and not sb.requires_grad and bool(torch.equal(sa, sb.to(sa))))
+                              and not sb.requires_grad
+                              and (sa.data_ptr() == sb.data_ptr() and sa.device == sb.device and sa.dtype == sb.dtype
+                                   or bool(torch.equal(sa, sb.to(sa)))))
         return (Sum(va[0], vb[0]), sa) if same else None      # different length-scale vectors: no common division
 
     def pairwise(self, x, y=None, **kw):

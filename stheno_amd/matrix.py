@@ -75,6 +75,7 @@ class Chol:
         self._checked = False
         self._dinv_sb = {128: dinv}
         self._clean = False
+        self.lookahead_nb = 0
 
     @classmethod
     def factor_(cls, a):
@@ -89,7 +90,11 @@ class Chol:
         if nb:
             dinv, info, dnb = be.potrf_(a, config.potrf_nbo, lookahead_nb=nb)
             c = cls(a, dinv, info)
-            c._dinv_sb[nb] = dnb          # the merged inverses the solves want come for free
+            c.lookahead_nb = nb           # (which path ran; the tests ask)
+            if nb == _solve_block(n, 1, a.dtype == torch.float64):
+                c._dinv_sb[nb] = dnb      # the merged inverses the solves want come for free
+            # (otherwise -- fp32, whose solves stay at 512-blocks for accuracy, or a 512-block look-ahead under 1024-block
+            # solves -- nobody would ever read them: n * nb elements, 134 MB at N = 32768 fp32, are released here)
         else:
             dinv, info = be.potrf_(a, config.potrf_nbo)
             c = cls(a, dinv, info)

@@ -81,24 +81,35 @@ class FDD(Normal):
         """``Normal.logpdf`` plus a guard: a value that came out cut off from the autograd graph although the process
         has learnable quantities (a posterior / multi-process / dense-noise case outside the differentiable paths)
         is refused, never returned silently detached."""
+        posterior = not isinstance(self.p, int) and getattr(self.p.measure, "_conditioned_on", None) is not None
+        if posterior and torch.is_grad_enabled() and self._learnable(x):
+            # a posterior density under learnable quantities: the plain path would factorise the posterior covariance,
+            # only for its value to be discarded -- go to the chain-rule form (two prior densities) at once
+            via_prior = self._posterior_logpdf_via_prior(x)
+            if via_prior is not None:
+                return via_prior
         lp, differentiable = Normal._logpdf(self, x)
-        if torch.is_grad_enabled() and not isinstance(self.p, int) and not differentiable:
-            from .. import autograd as _ag
-            from ..random import _x_requires_grad
-
-            nz = self.noise
-            noisy = ((isinstance(nz, Diagonal) and nz.diag().requires_grad)
-                     or (isinstance(nz, Dense) and nz.mat is not None and nz.mat.requires_grad))
-            if noisy or _x_requires_grad(self._xr) or _ag.kernel_requires_grad(self.p.kernel) or (torch.is_tensor(x) and x.requires_grad):
-                via_prior = self._posterior_logpdf_via_prior(x)
-                if via_prior is not None:
-                    return via_prior
-                raise NotImplementedError(
-                    "this log-density is outside the differentiable paths (one process -- or one batch of independent "
-                    "data sets -- whose kernel is a sum of primitives, scalar / per-point noise): its value would be "
-                    "cut off from the autograd graph.  Wrap the call in torch.no_grad() if that is intended"
-                )
+        if torch.is_grad_enabled() and not isinstance(self.p, int) and not differentiable and self._learnable(x):
+            via_prior = None if posterior else self._posterior_logpdf_via_prior(x)
+            if via_prior is not None:
+                return via_prior
+            raise NotImplementedError(
+                "this log-density is outside the differentiable paths (one process -- or one batch of independent "
+                "data sets -- whose kernel is a sum of primitives, scalar / per-point noise): its value would be "
+                "cut off from the autograd graph.  Wrap the call in torch.no_grad() if that is intended"
+            )
         return lp
+
+    def _learnable(self, x):
+        """Does anything behind this log-density require a gradient (kernel hyper-parameters, inputs, noise, the data)?"""
+        from .. import autograd as _ag
+        from ..random import _x_requires_grad
+
+        nz = self.noise
+        noisy = ((isinstance(nz, Diagonal) and nz.diag().requires_grad)
+                 or (isinstance(nz, Dense) and nz.mat is not None and nz.mat.requires_grad))
+        return bool(noisy or _x_requires_grad(self._xr) or _ag.kernel_requires_grad(self.p.kernel)
+                    or (torch.is_tensor(x) and x.requires_grad))
 
     def _posterior_logpdf_via_prior(self, y):
         """A posterior log-density under learnable quantities, by the chain rule: with the process conditioned on exact

@@ -332,7 +332,16 @@ def test_lookahead_factorisation_through_the_api(dtype, n):
     k = O.kernel_matrix([("eq", 1.0, 1.0)], x) + 0.5 * np.eye(n)
     c = Chol.factor_(dev(k, dtype).clone())
     nb = 512 if n < matrix.config.potrf_lookahead_wide_from else matrix.config.potrf_lookahead_nb[dtype]
-    assert nb in c._dinv_sb and c._dinv_sb[nb].shape[-3] == (n + nb - 1) // nb      # the look-ahead path ran
+    assert c.lookahead_nb == nb                                       # the look-ahead path ran
+    # the block inverses it leaves behind are what the merge of the 128-block inverses computes (they are kept with the factor
+    # only when the solves use that block size: matrix.Chol.factor_)
+    be = ops.get_backend()
+    a2 = dev(k, dtype).clone()
+    dinv2, info2, dnb = be.potrf_(a2, 0, lookahead_nb=nb)
+    assert int(info2.max()) == 0 and dnb.shape[-3] == (n + nb - 1) // nb
+    merged = be.trtri_merge(a2, dinv2, nb)
+    assert rel(dnb, merged.double().cpu().numpy()) < (1e-11 if dtype == torch.float64 else 1e-4)
+    del a2, dinv2, dnb, merged
     l_ref = np.linalg.cholesky(k)
     tol = 1e-10 if dtype == torch.float64 else 2e-4
     assert rel(torch.tril(c.l), l_ref) < tol
@@ -346,7 +355,7 @@ def test_lookahead_factorisation_through_the_api(dtype, n):
         c2 = Chol.factor_(dev(k, dtype).clone())
     finally:
         matrix.config.potrf_lookahead_from = old
-    assert nb not in c2._dinv_sb and rel(torch.tril(c.l), torch.tril(c2.l).double().cpu().numpy()) < tol
+    assert c2.lookahead_nb == 0 and rel(torch.tril(c.l), torch.tril(c2.l).double().cpu().numpy()) < tol
 
 
 def test_numpy_inputs_are_moved_to_the_device():

@@ -1,0 +1,200 @@
+"""Round-3 evidence under the driver's eye (``pytest -m gpu`` on the MI355X):
+
+ * north_star's own parity clause at its own size: HIP vs the oracle at N = 16384, D = 8, fp64, 1e-6 relative
+   (``tests/golden/cfg2_n16384.json``, generated on the build container by ``tests/golden/make_golden_fullsize.py``;
+   reference semantics ``stheno/random.py:248-280``, ``tests/test_random.py:185-192``);
+ * configs[2] at its full N = 32768: factor / solve residuals and fp64-on-device at full N against fp32 (1e-3);
+ * the look-ahead factorisation with 1024-blocks (what the headline bench runs) against LAPACK on the host;
+ * the native self-test binary (``stheno_amd/csrc/gpk_selftest``) must report ``fail=0``;
+ * RCCL on the hardware: the sharded paths of ``stheno_amd/dist.py`` through a one-rank ``nccl`` process group
+   (``scripts/rccl_1rank.py``, run with ``NCCL_DEBUG=INFO``; reference semantics ``tests/model/test_cases.py:134-155``);
+ * ``gpk_potrf_la`` inside a stream capture (the claim in ``include/gpk.h``).
+"""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import stheno_amd as st
+from bench import NOISE, make_inputs, make_step
+from stheno_amd import B, matrix, ops
+
+from .conftest import ROOT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hip_backend")]
+DEV = torch.device("cuda")
+OUT_DIR = os.path.join(ROOT, "gpurun_out", "r03")
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def test_config2_n16384_against_the_full_size_oracle_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "cfg2_n16384.json")) as fh:
+        g = json.load(fh)
+    w, t = make_inputs("dense_f64", DEV)
+    # the same numbers went into the oracle on the build container (CPU generator streams are deterministic)
+    for key, arr in (("x", t["x"]), ("y", t["y"]), ("xs_first", t["xs"][: g["n_test"]])):
+        host = np.ascontiguousarray(arr.cpu().numpy(), dtype="<f8")
+        assert hashlib.sha256(host.tobytes()).hexdigest() == g["inputs"][key]["sha256"], key
+    assert t["x"].shape == (16384, 8) and t["x"].dtype == torch.float64
+    f = st.GP(st.EQ())
+    fdd = f(t["x"], NOISE)
+    lp = float(fdd.logpdf(t["y"]))
+    assert abs(lp - g["logpdf"]) <= 1e-6 * abs(g["logpdf"]), (lp, g["logpdf"])
+    post = f | (fdd, t["y"])
+    mean, var = post(t["xs"][: g["n_test"]]).marginals()
+    ref_m, ref_v = np.array(g["posterior_mean"]), np.array(g["posterior_var"])
+    assert np.max(np.abs(mean.cpu().numpy() - ref_m)) <= 1e-6 * np.max(np.abs(ref_m))
+    assert np.max(np.abs(var.cpu().numpy() - ref_v)) <= 1e-6 * np.max(np.abs(ref_v))
+    # ... and the bench step itself (all 2048 test points) agrees with that on the shared points
+    lp_b, mean_b, var_b = make_step("dense_f64", w, t)()
+    assert abs(float(lp_b) - g["logpdf"]) <= 1e-6 * abs(g["logpdf"])
+    assert np.max(np.abs(mean_b[: g["n_test"]].cpu().numpy() - ref_m)) <= 1e-6 * np.max(np.abs(ref_m))
+    assert np.max(np.abs(var_b[: g["n_test"]].cpu().numpy() - ref_v)) <= 1e-6 * np.max(np.abs(ref_v))
+    # logdet and the quadratic form separately (a cancellation between the two would hide in the sum)
+    chol = fdd.var.chol()
+    assert abs(float(chol.logdet()) - g["logdet"]) <= 1e-9 * abs(g["logdet"])
+    assert abs(float(chol.iqf_diag(t["y"])[0]) - g["quadratic_form"]) <= 1e-8 * abs(g["quadratic_form"])
+
+
+def test_config3_full_size_residuals_and_fp64_on_device():
+    B.epsilon = 1e-6
+    try:
+        w, t = make_inputs("sum_f32", DEV)
+        n = t["x"].shape[0]
+        assert n == 32768 and t["x"].dtype == torch.float32
+        k = st.EQ() + st.Linear()
+        f = st.GP(k)
+        fdd = f(t["x"], NOISE)
+        lp32 = fdd.logpdf(t["y"])
+        m32, v32 = (f | (fdd, t["y"]))(t["xs"]).marginals()
+        chol = fdd.var.chol()
+        assert chol.l.shape == (n, n)
+        L = chol.lower()
+        rows = torch.tensor([0, 1, 127, 128, 1023, 1024, 1025, 8191, 16384, 20000, 31743, 32767], device=DEV)
+        k_rows = k.pairwise(t["x"][rows], t["x"])
+        k_rows[torch.arange(len(rows), device=DEV), rows] += NOISE + B.epsilon
+        # rows of L L^T reproduce rows of K + sigma^2 I to fp32 round-off (accumulated in fp64 so that the check itself adds none)
+        for i, r in enumerate(rows.tolist()):
+            got = (L[r:r + 1, : r + 1].double() @ L[: r + 1, : r + 1].double().T)[0]
+            assert rel(got, k_rows[i, : r + 1]) < 2e-5, r
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        b = torch.randn(n, 3, dtype=torch.float32, device=DEV, generator=gen)
+        assert rel(L @ chol.solve(b), b) < 2e-3          # fp32 forward error grows with cond(L); residual stays small
+        b2 = torch.randn(n, 64, dtype=torch.float32, device=DEV, generator=gen)
+        assert rel(L @ chol.solve(b2), b2) < 2e-3
+        del L, chol, fdd, k_rows
+        # the same computation in fp64 on the device at the FULL size (the 1e-3 bar of north_star for fp32)
+        B.epsilon = 1e-12
+        x64, y64, xs64 = t["x"].double(), t["y"].double(), t["xs"].double()
+        f64 = st.GP(st.EQ() + st.Linear())
+        fd64 = f64(x64, NOISE)
+        lp64 = fd64.logpdf(y64)
+        m64, v64 = (f64 | (fd64, y64))(xs64).marginals()
+        assert abs(float(lp32) - float(lp64)) <= 1e-3 * abs(float(lp64)), (float(lp32), float(lp64))
+        assert rel(m32, m64) < 1e-3 and rel(v32, v64) < 1e-3
+        # fp64 residual at full size
+        c64 = fd64.var.chol()
+        L64 = c64.lower()
+        for r in (0, 1025, 20000, 32767):
+            kr = (st.EQ() + st.Linear()).pairwise(x64[r:r + 1], x64[: r + 1])[0]
+            kr[r] += NOISE + 1e-12
+            got = (L64[r:r + 1, : r + 1] @ L64[: r + 1, : r + 1].T)[0]
+            assert rel(got, kr) < 1e-12, r
+    finally:
+        B.epsilon = 1e-12
+
+
+@pytest.mark.parametrize("dtype,n", [(torch.float64, 14336), (torch.float32, 14464)])
+def test_lookahead_1024_blocks_against_lapack(dtype, n):
+    """``Chol.factor_`` at an order that takes the 1024-block look-ahead path, against ``np.linalg.cholesky`` (LAPACK on the host)."""
+    assert n >= matrix.config.potrf_lookahead_wide_from
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 8, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+    k = st.EQ()
+    a = k.pairwise(x, None)
+    a.diagonal().add_(NOISE)
+    ref = np.linalg.cholesky(a.double().cpu().numpy())
+    chol = matrix.Chol.factor_(a.clone())
+    assert chol.lookahead_nb == 1024            # the 1024-block look-ahead path ran
+    L = chol.lower().double().cpu().numpy()
+    err = np.max(np.abs(L - ref)) / np.max(np.abs(ref))
+    assert err < (1e-11 if dtype == torch.float64 else 2e-4), err
+    # the 1024-block inverses the look-ahead leaves behind are the inverses of L's diagonal blocks
+    be = ops.get_backend()
+    _, info, dnb = be.potrf_(a.clone(), 0, lookahead_nb=1024)
+    assert int(info.max()) == 0
+    w1 = dnb[0, 1].double().cpu().numpy()
+    blk = ref[1024:2048, 1024:2048]
+    assert np.max(np.abs(w1 @ blk - np.eye(1024))) < (1e-9 if dtype == torch.float64 else 5e-3)
+
+
+def test_native_selftest_binary_reports_no_failure():
+    exe = os.path.join(ROOT, "stheno_amd", "csrc", "gpk_selftest")
+    assert os.path.exists(exe), "gpk_selftest was not built (make -C stheno_amd/csrc)"
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, "selftest_pytest.log"), "w") as fh:
+        fh.write(res.stdout + res.stderr)
+    m = re.search(r"SUMMARY pass=(\d+) fail=(\d+)", res.stdout)
+    assert m, res.stdout[-2000:] + res.stderr[-2000:]
+    assert int(m.group(2)) == 0 and int(m.group(1)) >= 500, m.group(0)
+    assert res.returncode == 0
+
+
+def test_rccl_one_rank_process_group_on_the_device():
+    env = dict(os.environ, NCCL_DEBUG="INFO", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29600 + os.getpid() % 300))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_1rank.py")], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, "rccl_1rank.log"), "w") as fh:
+        fh.write(res.stdout + "\n--- stderr ---\n" + res.stderr)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    both = res.stdout + res.stderr
+    assert "NCCL INFO" in both, "no RCCL init banner: the nccl backend did not come up"
+    m = re.search(r"RCCL1RANK (\{.*\})", res.stdout)
+    assert m, res.stdout[-2000:]
+    out = json.loads(m.group(1))
+    assert out["backend"] == "nccl" and out["world_size"] == 1
+    assert out["logpdf_max_rel_err"] < 1e-6 and out["logpdf_sum_rel_err"] < 1e-6
+    for tag in ("vfe", "fitc", "dtc"):
+        assert out["elbo_%s_rel_err" % tag] < 1e-6, (tag, out)
+    assert out["allgather_512_logpdfs_us"] > 0
+
+
+def test_potrf_lookahead_inside_a_stream_capture():
+    """``include/gpk.h``: "under stream capture it joins the capture".  Capture one look-ahead factorisation into a graph,
+    replay it on fresh data, compare with the eager result."""
+    n = 8192
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, 8, generator=g, dtype=torch.float64).to(DEV)
+    a0 = st.EQ().pairwise(x, None)
+    a0.diagonal().add_(NOISE)
+    be = ops.get_backend()
+    eager = a0.clone()
+    be.potrf_(eager, 0, lookahead_nb=512)       # also creates the helper stream outside the capture (gpk_init's job)
+    torch.cuda.synchronize()
+    buf = a0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            outs = be.potrf_(buf, 0, lookahead_nb=512)
+    torch.cuda.current_stream().wait_stream(side)
+    buf.copy_(a0)
+    outs[1].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(outs[1].max()) == 0
+    assert rel(torch.tril(buf), torch.tril(eager)) < 1e-13
