@@ -42,6 +42,9 @@ struct Traits<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) + 4 * i; }
+    // row j of a 16x16 C/D tile lives in accumulator register rowi(j) of the 16 lanes of lane group rowq(j)
+    static __host__ __device__ constexpr int rowq(int j) { return j & 3; }
+    static __host__ __device__ constexpr int rowi(int j) { return j >> 2; }
 };
 
 // f32: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain, f32 vector rate).  A/B as
@@ -56,6 +59,8 @@ struct Traits<float> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int crow(int lane, int i) { return (lane >> 4) * 4 + i; }
+    static __host__ __device__ constexpr int rowq(int j) { return j >> 2; }
+    static __host__ __device__ constexpr int rowi(int j) { return j & 3; }
 };
 
 static inline int64_t gpk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -20,6 +20,7 @@
 // inv(L_cc) blocks are kept: gpk_solve.hip turns every triangular solve of the
 // path into GEMM/GEMV work with them.
 #include "gpk_common.hpp"
+#include "gpk_diag_sched.hpp"
 #include <vector>
 
 namespace {
@@ -446,7 +447,431 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
     PROF_MARK(5);
 }
 
+// ---------------------------------------------------------------------------
+// potrf_diag2_kernel -- the same job (factor the 128x128 diagonal block in LDS, write L, invert in LDS, write inv(L)) with the
+// serial chain stripped to what is serial.  See gpk_diag_sched.hpp for the structure (phases, who does what); here are the two
+// engines the schedule drives:
+//
+//  * chol16 (the chain wave): Cholesky AND inverse of one 16x16 tile held in the MFMA accumulator layout.  The tile is kept as a
+//    full symmetric matrix C; column j of the elimination is ONE v_mfma 16x16x4 rank-1 update  C -= v v^T / d  whose A and B
+//    operands are the SAME accumulator register -- row j of C sits in register rowi(j) of the 16 lanes of lane group rowq(j),
+//    which is exactly the lane group that supplies k-slice rowq(j) of both operands, and by symmetry row j is column j -- so no
+//    cross-lane traffic at all besides v_readlanes of the pivot.  A second MFMA per column applies the same elimination to a
+//    tile E that starts as the identity: E ends as the unit-lower inverse, inv(L) = diag(1/sqrt(d)) E.  The pivot recurrence
+//    d_{j+1} = C[j+1][j+1] - C[j][j+1]^2 / d_j runs one column AHEAD on the scalar side (two v_readlanes + FMA + v_rcp + Newton),
+//    in the shadow of the two MFMAs of column j; square roots are taken once, for all 16 pivots, after the loop.  The chain per
+//    column is then about the matrix pipe (2 x 64 cycles in fp64), against readlane -> rsq -> Goldschmidt -> 15 readlane / FMA
+//    pairs (~250 cycles) in potrf_diag_kernel above;
+//  * run_tasks: an interpreter of 16x16 tile products (solves against an inverted diagonal tile, rank-16 updates, merge passes of
+//    the inverse).  A wave is alone on its SIMD and issues in order, so everything that is not an MFMA has to sit BETWEEN the
+//    (dependent) MFMAs of a product: the operands of the next k-block are requested between the four MFMAs of the current one,
+//    the result of the previous product is written after the first MFMA of the next.  The task words (LDS element offsets
+//    precomputed on the host side of the table) travel in VGPR lanes and are fetched with v_readlane: no scalar memory load in
+//    the loop (those share the LDS wait counter).
+// ---------------------------------------------------------------------------
+constexpr int LDD = 17;    // row pitch of the kept diagonal tiles of L
+
+__constant__ gpk_diag::DevSched g_diag_sched = gpk_diag::make_dev_sched(LDP);
+static_assert(gpk_diag::sched_has_end_slot(), "diagonal-block schedule: every task list needs an empty slot at its end");
+static_assert(GPK_DB * LDP < 65536, "tile offsets are packed into 16 bits");
+
+#define GPK_SB() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ double recip_nr(double d) {      // 1 / d: v_rcp_f64 (2^-26) + two Newton steps
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ float recip_nr(float d) {
+    float y = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, y, 1.0f);
+    y = fmaf(y, e, y);
+    return y;
+}
+
+template <typename T>
+__device__ __forceinline__ void chol16(T* __restrict__ S, T* __restrict__ Ld, int s, int lane, int* info, int info_off) {
+    typedef typename Traits<T>::acc_t acc_t;
+    const int lr = lane & 15, g = lane >> 4;
+    const int c0 = 16 * s;
+    acc_t c, e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // only the lower triangle of the tile is meaningful in LDS: mirror it on the way in
+        const int r = Traits<T>::crow(lane, i);
+        const int hi = r > lr ? r : lr, lo = r > lr ? lr : r;
+        c[i] = S[(c0 + hi) * LDP + c0 + lo];
+        e[i] = (r == lr) ? T(1) : T(0);
+    }
+    T vsave[16];                                  // row j of C at step j (lane group rowq(j)): column j of L before scaling
+    T dvec = T(1);                                // lane with (lane & 15) == j keeps pivot j
+    T d = lane_bcast(c[Traits<T>::rowi(0)], 16 * Traits<T>::rowq(0));
+    T rho = -recip_nr(d);
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = Traits<T>::rowq(j), i = Traits<T>::rowi(j);
+        const bool inq = (g == q);
+        const T v = inq ? c[i] : T(0);            // row j of C = column j (symmetry), in k-slice q of both operands
+        const T w = v * rho;                      // -v / d
+        T vj1 = T(0), cj1 = T(1);
+        if (j < 15) {                             // what the next pivot needs, taken BEFORE this column's update
+            vj1 = lane_bcast(c[i], 16 * q + j + 1);                                                     // C[j][j+1]
+            cj1 = lane_bcast(c[Traits<T>::rowi(j + 1)], 16 * Traits<T>::rowq(j + 1) + j + 1);          // C[j+1][j+1]
+        }
+        GPK_SB();
+        c = Traits<T>::mfma(v, w, c);             // C -= v v^T / d
+        GPK_SB();
+        // in the shadow of that MFMA: the next pivot (first half), the operands of the E update
+        const T d_next = fma(vj1 * rho, vj1, cj1);
+        T y = (sizeof(T) == 8) ? (T)__builtin_amdgcn_rcp((double)d_next) : (T)__builtin_amdgcn_rcpf((float)d_next);
+        const T we = (inq && lr > j) ? w : T(0);
+        const T eb = inq ? e[i] : T(0);
+        bad = (!(d > T(0)) && bad == 0) ? j + 1 : bad;
+        dvec = (lr == j) ? d : dvec;
+        vsave[j] = v;
+        GPK_SB();
+        e = Traits<T>::mfma(we, eb, e);           // E[r][:] -= (v_r / d) E[j][:],  r > j
+        GPK_SB();
+        // Newton steps of the reciprocal of the next pivot
+        T en = fma(-d_next, y, T(1));
+        y = fma(y, en, y);
+        if (sizeof(T) == 8) {
+            en = fma(-d_next, y, T(1));
+            y = fma(y, en, y);
+        }
+        d = d_next;
+        rho = -y;
+    }
+    // 1 / sqrt(d_j) for all 16 pivots at once (lane j), then: column j of L = vsave[j] / sqrt(d_j); row r of the inverse = E[r] / sqrt(d_r)
+    T sq, rsv;
+    sqrt_rsqrt(dvec, sq, rsv);
+    T rs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) rs[j] = lane_bcast(rsv, j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        T sel = rs[Traits<T>::crow(0, i)];
+#pragma unroll
+        for (int gg = 1; gg < 4; ++gg) sel = (g == gg) ? rs[Traits<T>::crow(16 * gg, i)] : sel;
+        S[(c0 + Traits<T>::crow(lane, i)) * LDP + c0 + lr] = e[i] * sel;                                // inv(L_ss), zeros above the diagonal
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (g == Traits<T>::rowq(j) && lr >= j) Ld[(c0 + lr) * LDD + j] = vsave[j] * rs[j];            // L[lr][j]  (lr = j: d / sqrt(d))
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, info_off + c0 + bad);
+}
+
+template <typename T>
+struct TileOps {
+    T a[4], b[4];
+};
+
+template <typename T>
+struct Diag2Out {          // what the write-back of L needs
+    T* A;
+    int64_t ld;
+    int nv;
+    bool vec_io;
+};
+
+// column panel s of L (rows 16 s .. 127, 16 columns), part `part` of `parts` (by rows), from LDS to global memory: the diagonal
+// tile comes from Ld (lower part only: nothing above the diagonal of A is ever written), the rest from S.
+template <typename T>
+__device__ __forceinline__ void store_panel(const T* __restrict__ S, const T* __restrict__ Ld, uint32_t w0, int lane, const Diag2Out<T>& o) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int LPR = 16 / VEC;                 // lanes per row
+    const int s = w0 & 0xff, part = (w0 >> 8) & 0xf, parts = (w0 >> 12) & 0xf;
+    const int r0 = 16 * s, rows = GPK_DB - r0;
+    const int len = ((rows + parts - 1) / parts + 7) / 8 * 8;
+    const int rbeg = r0 + part * len;
+    int rend = rbeg + len;
+    if (rend > GPK_DB) rend = GPK_DB;
+    if (rend > o.nv) rend = o.nv;
+    const int cv = (lane % LPR) * VEC;
+    for (int r = rbeg + lane / LPR; r < rend; r += 64 / LPR) {
+        T* dst = o.A + (int64_t)r * o.ld + r0 + cv;
+        if (r < r0 + 16) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if (cv + v <= r - r0) dst[v] = Ld[r * LDD + cv + v];
+        } else {
+            vec_t val;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) val[v] = S[r * LDP + r0 + cv + v];
+            if (o.vec_io) {
+                *reinterpret_cast<vec_t*>(dst) = val;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) dst[v] = val[v];
+            }
+        }
+    }
+}
+
+// One k-block of a tile product with compile-time roles: `cur` holds its operands, `nx` receives those of the next k-block
+// (p0 / p1 / pkb describe it; a harmless re-read of the current block when there is nothing to prefetch), `acc` accumulates,
+// `oth` is the other accumulator: it may still hold the previous product (written out after the first MFMA) and receives the
+// starting value of the next product.
+template <typename T>
+__device__ __forceinline__ void tile_step(T* __restrict__ S, TileOps<T>& cur, TileOps<T>& nx, typename Traits<T>::acc_t& acc,
+                                          typename Traits<T>::acc_t& oth, uint32_t w0, uint32_t p0, uint32_t p1, int pkb, bool last, bool pre,
+                                          bool has_next, uint32_t n0, uint32_t n1, bool pend, int pend_off, int offA, int offBn, int offC) {
+    using namespace gpk_diag;
+    constexpr int CSTEP = (sizeof(T) == 8 ? 4 : 1) * LDP;      // LDS rows between accumulator registers i and i + 1
+    acc = Traits<T>::mfma(cur.a[0], cur.b[0], acc);
+    GPK_SB();
+    if (pend) {                                                 // the previous product, finished one MFMA ago
+        T* po = S + pend_off + offC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) po[i * CSTEP] = oth[i];
+    }
+    {
+        const T* pa = S + (p0 >> 16) + 16 * pkb + offA;
+        const bool neg = dw1_neg(p1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const T a = pa[4 * kk];
+            nx.a[kk] = neg ? -a : a;
+        }
+    }
+    GPK_SB();
+    acc = Traits<T>::mfma(cur.a[1], cur.b[1], acc);
+    GPK_SB();
+    {
+        const bool bt = dw1_btrans(p1);
+        const T* pb = S + (p1 & 0xffff) + (bt ? 16 * pkb + offA : 16 * LDP * pkb + offBn);
+        const int bs = bt ? 4 : 4 * LDP;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) nx.b[kk] = pb[kk * bs];
+    }
+    GPK_SB();
+    acc = Traits<T>::mfma(cur.a[2], cur.b[2], acc);
+    GPK_SB();
+    T ini[4];
+    {
+        const T* pc = S + (p0 & 0xffff) + offC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ini[i] = pc[i * CSTEP];
+    }
+    GPK_SB();
+    acc = Traits<T>::mfma(cur.a[3], cur.b[3], acc);
+    GPK_SB();
+    if (last) {
+        if (pre) {
+            const bool init = dw1_init(p1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) oth[i] = init ? ini[i] : T(0);
+        } else {
+            // nothing was prefetched (the list ends here, or the next product reads this one's output): write out now, then fetch
+            T* po = S + (w0 & 0xffff) + offC;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) po[i * CSTEP] = acc[i];
+            if (has_next) {
+                const T* pa = S + (n0 >> 16) + offA;
+                const bool neg = dw1_neg(n1);
+                const bool bt = dw1_btrans(n1);
+                const T* pb = S + (n1 & 0xffff) + (bt ? offA : offBn);
+                const int bs = bt ? 4 : 4 * LDP;
+                const T* pc = S + (n0 & 0xffff) + offC;
+                const bool init = dw1_init(n1);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const T a = pa[4 * kk];
+                    nx.a[kk] = neg ? -a : a;
+                    nx.b[kk] = pb[kk * bs];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const T vinit = pc[i * CSTEP];
+                    oth[i] = init ? vinit : T(0);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void run_tasks(T* __restrict__ S, const T* __restrict__ Ld, unsigned tw, int lane, const Diag2Out<T>& o) {
+    using namespace gpk_diag;
+    typedef typename Traits<T>::acc_t acc_t;
+    constexpr int CSTEP = (sizeof(T) == 8 ? 4 : 1) * LDP;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int offA = lr * LDP + kq;              // A operand, and B read transposed
+    const int offBn = kq * LDP + lr;             // B read as stored
+    const int offC = Traits<T>::crow(lane, 0) * LDP + lr;
+    auto W0 = [&](int q) { return (uint32_t)__builtin_amdgcn_readlane((int)tw, q); };
+    auto W1 = [&](int q) { return (uint32_t)__builtin_amdgcn_readlane((int)tw, MAXT + q); };
+
+    int q = 0;
+    uint32_t w0 = W0(0), w1 = W1(0);
+    if (dw1_kind(w1) == (int)K_MM) {
+        TileOps<T> o0, o1;
+        acc_t a0, a1;
+        {   // prologue: operands of the first k-block, start of the first accumulator
+            const T* pa = S + (w0 >> 16) + offA;
+            const bool neg = dw1_neg(w1), bt = dw1_btrans(w1), init = dw1_init(w1);
+            const T* pb = S + (w1 & 0xffff) + (bt ? offA : offBn);
+            const int bs = bt ? 4 : 4 * LDP;
+            const T* pc = S + (w0 & 0xffff) + offC;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const T a = pa[4 * kk];
+                o0.a[kk] = neg ? -a : a;
+                o0.b[kk] = pb[kk * bs];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T vinit = pc[i * CSTEP];
+                a0[i] = init ? vinit : T(0);
+                a1[i] = T(0);
+            }
+        }
+        int kb = 0, state = 0, pend_off = 0;
+        bool pend = false;
+#pragma unroll 1
+        while (true) {
+            const bool last = (kb + 1 == dw1_nkb(w1));
+            uint32_t n0 = w0, n1 = w1;
+            bool has_next = true;
+            if (last) {
+                n0 = W0(q + 1);
+                n1 = W1(q + 1);
+                has_next = dw1_kind(n1) == (int)K_MM;
+            }
+            const bool pre = has_next && !(last && dw1_dep(n1));
+            const uint32_t p0 = pre ? n0 : w0, p1 = pre ? n1 : w1;
+            const int pkb = (pre && !last) ? kb + 1 : 0;
+            switch (state) {
+                case 0: tile_step<T>(S, o0, o1, a0, a1, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
+                case 1: tile_step<T>(S, o1, o0, a0, a1, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
+                case 2: tile_step<T>(S, o0, o1, a1, a0, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
+                default: tile_step<T>(S, o1, o0, a1, a0, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
+            }
+            pend = last && pre;
+            pend_off = w0 & 0xffff;
+            state ^= 1;
+            if (last) {
+                if (!has_next) break;
+                state ^= 2;
+                ++q;
+                w0 = n0;
+                w1 = n1;
+                kb = 0;
+            } else {
+                ++kb;
+            }
+        }
+        ++q;
+        w0 = W0(q);
+        w1 = W1(q);
+    }
+    while (dw1_kind(w1) == (int)K_STORE) {
+        store_panel<T>(S, Ld, w0, lane, o);
+        ++q;
+        w0 = W0(q);
+        w1 = W1(q);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void potrf_diag2_kernel(DiagArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) T S[GPK_DB * LDP];
+    __shared__ T Ld[GPK_DB * LDD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t b = blockIdx.x;
+    T* __restrict__ A = p.A + b * p.bstride + p.off * p.ld + p.off;
+    const int rem = p.n - (int)p.off;
+    const int nv = rem < GPK_DB ? rem : GPK_DB;
+
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int CPR = GPK_DB / VEC;              // 16-byte chunks per row
+    constexpr int PER = GPK_DB * CPR / 256;        // chunks per thread
+    const bool vec_io = (nv == GPK_DB) && ((uintptr_t)A % 16 == 0) && (p.ld % VEC == 0);
+    long long* prof = (p.prof != nullptr && blockIdx.x == 0 && tid == 0) ? p.prof + (p.off / GPK_DB) * 32 : nullptr;
+    if (prof) prof[0] = (long long)__builtin_readcyclecounter();
+
+    // this wave's task words of the first phase (lanes 0 .. 2 MAXT - 1), requested before the block itself
+    const uint32_t* __restrict__ sched = &g_diag_sched.w[0][0][0];
+    const int tlane = lane < 2 * gpk_diag::MAXT ? lane : 0;
+    unsigned tw = sched[(0 * 4 + wave) * 2 * gpk_diag::MAXT + tlane];
+
+    // ---- load the lower triangle (identity-padded past nv); nothing above the diagonal is initialised: those tiles are scratch
+    // and chol16 mirrors the diagonal tiles on the way in ----
+    if (vec_io) {
+        vec_t buf[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = (id % CPR) * VEC;
+            if (c <= r) buf[i] = *reinterpret_cast<const vec_t*>(A + (int64_t)r * p.ld + c);
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = (id % CPR) * VEC;
+            if (c <= r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) S[r * LDP + c + v] = buf[i][v];      // (the entries right of the diagonal in this chunk: never read)
+            }
+        }
+    } else {
+        for (int base = 0; base < GPK_DB * GPK_DB; base += 256 * 16) {
+            T buf[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = base + tid + 256 * i;
+                const int r = idx >> 7, c = idx & 127;
+                buf[i] = (r < nv && c <= r) ? A[(int64_t)r * p.ld + c] : ((r == c) ? T(1) : T(0));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = base + tid + 256 * i;
+                const int r = idx >> 7, c = idx & 127;
+                if (c <= r) S[r * LDP + c] = buf[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (prof) prof[1] = (long long)__builtin_readcyclecounter();
+
+    Diag2Out<T> o{A, p.ld, nv, vec_io};
+#pragma unroll 1
+    for (int ph = 0; ph < gpk_diag::NPH; ++ph) {
+        // next phase's task words: in flight under this phase
+        const int phn = ph + 1 < gpk_diag::NPH ? ph + 1 : ph;
+        const unsigned twn = sched[(phn * 4 + wave) * 2 * gpk_diag::MAXT + tlane];
+        if (wave == 0 && (ph & 1) == 0 && ph <= 14) chol16<T>(S, Ld, ph >> 1, lane, p.info + b, (int)p.off + p.info_base);
+        run_tasks<T>(S, Ld, tw, lane, o);
+        __syncthreads();
+        tw = twn;
+        if (prof) prof[2 + ph] = (long long)__builtin_readcyclecounter();
+    }
+
+    if (p.dinv == nullptr) return;
+    // ---- write inv(L): the lower triangle of S; zeros above the diagonal (those tiles held scratch) ----
+    T* __restrict__ W = p.dinv + b * p.dinv_bstride + (p.off / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int id = tid + 256 * i;
+        const int r = id / CPR, c = (id % CPR) * VEC;
+        vec_t w;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) w[v] = (c + v <= r) ? S[r * LDP + c + v] : T(0);
+        *reinterpret_cast<vec_t*>(W + (int64_t)r * GPK_DB + c) = w;
+    }
+    if (prof) prof[2 + gpk_diag::NPH] = (long long)__builtin_readcyclecounter();
+}
+
 long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
+int g_diag_v2 = 0;                  // tuning knob (gpk_tune(30, v)): 1 = potrf_diag2_kernel (pipelined; measured SLOWER, see profiles/r03_experiments.md), 0 = potrf_diag_kernel
 
 template <typename T>
 struct PanelCtx {
@@ -471,7 +896,10 @@ int potrf_panel(const PanelCtx<T>& x, int64_t c0, int64_t w) {
         d.A = x.A; d.ld = x.ld; d.bstride = x.bstride; d.off = c0; d.n = (int)x.n;
         d.dinv = x.dinv; d.dinv_bstride = x.dstride; d.info = x.info; d.info_base = x.info_base;
         d.prof = g_diag_prof;
-        hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3((unsigned)x.batch), dim3(256), 0, x.stream, d);
+        if (g_diag_v2)
+            hipLaunchKernelGGL((potrf_diag2_kernel<T>), dim3((unsigned)x.batch), dim3(256), 0, x.stream, d);
+        else
+            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3((unsigned)x.batch), dim3(256), 0, x.stream, d);
         GPK_CHECK_LAUNCH();
         const int64_t r1 = c0 + GPK_DB;   // first row below the diagonal block
         if (r1 >= x.n) return GPK_OK;
@@ -630,6 +1058,7 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 10) g_la_ps_mode = (int)value;
     if (key == 18) g_la_rejoin = (int)value;
     if (key == 11) g_la_strip_last = (int)value;
+    if (key == 30) g_diag_v2 = (int)value;
 }
 
 #define GPK_LA_PAD 16
@@ -668,7 +1097,8 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     if (e_in == nullptr || e_out == nullptr) return GPK_ERR_LAUNCH;
     if (hipEventRecord(e_in, nullptr) != hipSuccess || hipStreamWaitEvent(dev->priv, e_in, 0) != hipSuccess) return GPK_ERR_LAUNCH;
     const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, ws, info, dev->priv);
-    if (hipEventRecord(e_out, dev->priv) != hipSuccess || hipStreamWaitEvent(nullptr, e_out, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+    // joined whatever `st` is: what was enqueued on the private stream before a failure still uses the caller's buffers
+    if (hipEventRecord(e_out, dev->priv) != hipSuccess || hipStreamWaitEvent(nullptr, e_out, 0) != hipSuccess) return st ? st : GPK_ERR_LAUNCH;
     return st;
 }
 
@@ -742,28 +1172,36 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         }
         GpkPersistSaved saved;
         saved.valid = 0;
-        // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
-        // ~0.3 ms for those, which the main stream would otherwise spend idle
-        if (k2 < n) {
-            const T* P2 = A + k2 * ld + k0;
-            GpkSeg<T> seg[2];
-            const int so = g_la_strip_last ? 1 : 0;   // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
-            seg[so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
-            seg[1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
-            st = gpk_gemm_persist_launch<T>(seg, 2, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
-            if (st) return st;
-        }
-        if (overlap) {
-            if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-            st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux);
-            if (st) return st;
-            if (g_la_rejoin && saved.valid) {       // chain done: the reserved CUs take tiles of the update that is still running
-                st = gpk_gemm_persist_rejoin<T>(&saved, dev->aux);
-                if (st) return st;
+        // Everything between the fork and the join: on ANY failure in here the helper stream is still joined to `stream` below --
+        // work already enqueued on it references `ws`, `dinv128` and `A`, which the caller releases as soon as it sees the error
+        // (a caching allocator would hand that memory to later work on the caller's stream).
+        auto forked = [&]() -> int {
+            // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
+            // ~0.3 ms for those, which the main stream would otherwise spend idle
+            if (k2 < n) {
+                const T* P2 = A + k2 * ld + k0;
+                GpkSeg<T> seg[2];
+                const int so = g_la_strip_last ? 1 : 0;   // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
+                seg[so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
+                seg[1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
+                const int s2 = gpk_gemm_persist_launch<T>(seg, 2, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
+                if (s2) return s2;
             }
-            if (hipEventRecord(e_join, dev->aux) != hipSuccess) return GPK_ERR_LAUNCH;
-            if (hipStreamWaitEvent(stream, e_join, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+            if (overlap) {
+                if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+                const int s2 = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux);
+                if (s2) return s2;
+                if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
+                    return gpk_gemm_persist_rejoin<T>(&saved, dev->aux);
+            }
+            return GPK_OK;
+        };
+        st = forked();
+        if (overlap) {
+            const bool joined = hipEventRecord(e_join, dev->aux) == hipSuccess && hipStreamWaitEvent(stream, e_join, 0) == hipSuccess;
+            if (!joined && st == GPK_OK) st = GPK_ERR_LAUNCH;
         }
+        if (st) return st;
     }
     return GPK_OK;
 }

@@ -1457,18 +1457,26 @@ static void cumask_experiment() {
 }
 
 template <typename T>
-static void diag_phase_profile(int n) {
+static void diag_phase_profile(int n, bool v2) {
     const int nblk = (n + 127) / 128;
-    Dev<long long> prof((size_t)nblk * 16);
+    Dev<long long> prof((size_t)nblk * 32);
     prof.zero();
+    gpk_tune(30, v2 ? 1 : 0);
     gpk_tune_diag_prof(prof.p);
     profile_one<T>(n, 0, 1);
     gpk_tune_diag_prof(nullptr);
     auto h = prof.down();
     for (int blk : {0, nblk / 2, nblk - 1}) {
-        const long long* q = &h[(size_t)blk * 16];
-        printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld [trsm %lld  c1 %lld  chol(wave0) %lld]  storeL %lld  invert %lld [16x16 %lld]  storeW %lld  total %lld\n",
-               DT<T>::name(), blk, q[1] - q[0], q[2] - q[1], q[8], q[9], q[10], q[3] - q[2], q[4] - q[3], q[6] - q[3], q[5] - q[4], q[5] - q[0]);
+        if (!v2) {
+            const long long* q = &h[(size_t)blk * 16];
+            printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld [trsm %lld  c1 %lld  chol(wave0) %lld]  storeL %lld  invert %lld [16x16 %lld]  storeW %lld  total %lld\n",
+                   DT<T>::name(), blk, q[1] - q[0], q[2] - q[1], q[8], q[9], q[10], q[3] - q[2], q[4] - q[3], q[6] - q[3], q[5] - q[4], q[5] - q[0]);
+        } else {
+            const long long* q = &h[(size_t)blk * 32];
+            printf("DIAGPROF2 %s blk %d cycles: load %lld | phases", DT<T>::name(), blk, q[1] - q[0]);
+            for (int ph = 0; ph < 18; ++ph) printf(" %lld", q[2 + ph] - q[1 + ph]);
+            printf(" | storeW %lld | total %lld\n", q[20] - q[19], q[20] - q[0]);
+        }
     }
 }
 
@@ -1506,8 +1514,10 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
             rsq_precision();
-            diag_phase_profile<double>(atoi(argv[i + 1]));
-            diag_phase_profile<float>(atoi(argv[i + 1]));
+            for (int v2 = 0; v2 < 2; ++v2) {
+                diag_phase_profile<double>(atoi(argv[i + 1]), v2 != 0);
+                diag_phase_profile<float>(atoi(argv[i + 1]), v2 != 0);
+            }
             return 0;
         }
         if (!strcmp(argv[i], "--profile") && i + 3 < argc) {   // --profile f64|f32 N NBO
@@ -1526,6 +1536,12 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--perf-kmat")) { perf_kmat(); return 0; }
         if (!strcmp(argv[i], "--kmat")) {                      // only the kernel-matrix checks, both kernels
             for (int band = 1; band >= 0; --band) { gpk_tune(12, band); test_kmat<double>(); test_kmat<float>(); }
+            printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
+            return g_fail ? 1 : 0;
+        }
+        if (!strcmp(argv[i], "--potrf")) {                     // only the factorisation checks (plain + look-ahead)
+            test_potrf<double>(); test_potrf<float>();
+            test_lookahead<double>(); test_lookahead<float>();
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
             return g_fail ? 1 : 0;
         }
