@@ -118,13 +118,21 @@ int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* di
 int gpk_trtri_merge(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
                     const void* dinv128, int sb, void* dinv_sb, void* tmp, void* stream);
 
-/* B <- L^{-1} B, many right-hand sides (MFMA GEMM sweep).  tmp: batch * sb * nrhs elements.
+/* B <- L^{-1} B, many right-hand sides: recursive blocked solve on the MFMA GEMM (half of the flops in ONE GEMM with K = n/2, a
+ * quarter in two with K = n/4, ...; the sb x sb diagonal blocks by their merged inverses).  tmp: batch * sb * nrhs elements.
  * Replaces `B.solve(L, .)` / the solves inside `B.iqf` (LAPACK trsm):
  * stheno/model/observations.py:301,322,327,329; mlkernels.PosteriorMean/PosteriorKernel
  * constructed at observations.py:148-168. */
 int gpk_trsm_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
                    int sb, void* b, int64_t nrhs, int64_t ldb, int64_t sb_stride, void* tmp,
                    int64_t batch, void* stream);
+
+/* The same solve OUT OF PLACE: x = L^{-1} b into a second n x nrhs buffer (ldx >= nrhs), `b` is used up as workspace.  Saves the
+ * copy of every solved block (the in-place form builds it in `tmp` first): the form the posterior path uses for its
+ * 2048-column solve.  Replaces the same reference call sites as gpk_trsm_lower. */
+int gpk_trsm_lower_to(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
+                      int sb, void* b, int64_t nrhs, int64_t ldb, int64_t sb_stride, void* x, int64_t ldx,
+                      int64_t sx_stride, int64_t batch, void* stream);
 
 /* B <- L^{-1} B, nrhs <= 8 (GEMV sweep, HBM-bound).  tmp: batch * sb * nrhs elements.
  * Replaces the solve inside `B.iqf_diag(var, y - mean)`: stheno/random.py:276,

@@ -41,6 +41,24 @@ __global__ __launch_bounds__(256, 1) void k64(double* out, long long* cyc, int n
     out[threadIdx.x] = c[0] + c[1] + e[0] + a;
     if (threadIdx.x == 0) cyc[MODE] = t1 - t0;
 }
+template <int NACC, bool ONEWAVE>
+__global__ __launch_bounds__(256, 1) void kacc(double* out, long long* cyc, int n, int slot) {
+    const int lane = threadIdx.x & 63;
+    if (ONEWAVE && threadIdx.x >= 64) return;
+    f64x4 c[NACC];
+    for (int q = 0; q < NACC; ++q) c[q] = f64x4{1.0 + q, 0.5, 0.25, 0.125};
+    const double a = 1e-3 * lane, b = 1e-3;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[q], 0, 0, 0);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    double s = 0;
+    for (int q = 0; q < NACC; ++q) s += c[q][0] + c[q][3];
+    out[threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[slot] = t1 - t0;
+}
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k32(float* out, long long* cyc, int n) {
     const int lane = threadIdx.x & 63;
@@ -58,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void k32(float* out, long long* cyc, int n)
 }
 int main() {
     double* o; float* of; long long* c;
-    hipMalloc(&o, 4096); hipMalloc(&of, 4096); hipMalloc(&c, 16 * 8); hipMemset(c, 0, 128);
+    hipMalloc(&o, 4096); hipMalloc(&of, 4096); hipMalloc(&c, 32 * 8); hipMemset(c, 0, 256);
     const int n = 2000;
     for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL(k64<0>, dim3(1), dim3(256), 0, 0, o, c, n);
@@ -71,10 +89,21 @@ int main() {
         hipLaunchKernelGGL(k32<0>, dim3(1), dim3(256), 0, 0, of, c, n);
         hipLaunchKernelGGL(k32<2>, dim3(1), dim3(256), 0, 0, of, c, n);
         hipLaunchKernelGGL(k32<3>, dim3(1), dim3(256), 0, 0, of, c, n);
+        hipLaunchKernelGGL((kacc<1, false>), dim3(1), dim3(256), 0, 0, o, c, n, 16);
+        hipLaunchKernelGGL((kacc<2, false>), dim3(1), dim3(256), 0, 0, o, c, n, 17);
+        hipLaunchKernelGGL((kacc<3, false>), dim3(1), dim3(256), 0, 0, o, c, n, 18);
+        hipLaunchKernelGGL((kacc<4, false>), dim3(1), dim3(256), 0, 0, o, c, n, 19);
+        hipLaunchKernelGGL((kacc<8, false>), dim3(1), dim3(256), 0, 0, o, c, n, 20);
+        hipLaunchKernelGGL((kacc<16, false>), dim3(1), dim3(256), 0, 0, o, c, n, 21);
+        hipLaunchKernelGGL((kacc<4, true>), dim3(1), dim3(256), 0, 0, o, c, n, 22);
+        hipLaunchKernelGGL((kacc<16, true>), dim3(1), dim3(256), 0, 0, o, c, n, 23);
         hipDeviceSynchronize();
     }
-    long long h[16];
-    hipMemcpy(h, c, 128, hipMemcpyDeviceToHost);
+    long long h[32];
+    hipMemcpy(h, c, 256, hipMemcpyDeviceToHost);
+    const int nacc[] = {1, 2, 3, 4, 8, 16, 4, 16};
+    for (int i = 0; i < 8; ++i)
+        printf("LAT f64 %2d independent accumulators, %s: %7.1f cycles per MFMA\n", nacc[i], i < 6 ? "4 waves (one per SIMD)" : "ONE wave on the CU     ", (double)h[16 + i] / n / nacc[i]);
     const char* nm[] = {"f64 dependent MFMA chain", "f64 two independent chains (per pair)", "f64 MFMA -> read acc -> mul -> MFMA", "f64 same + independent MFMA",
                         "f64 8 dependent v_fma", "f64 rcp + 2 Newton", "f64 readlane pair -> fma", "", "f32 dependent MFMA chain", "", "f32 MFMA -> read -> mul -> MFMA", "f32 same + independent MFMA"};
     for (int i = 0; i < 12; ++i)

@@ -1,7 +1,7 @@
 """List the kernels of the LAST repetition in a rocprofv3 --kernel-trace CSV, in start order:
 start offset, duration, gap to the previous kernel's end, grid size, name.
 
-usage: python scripts/dev_trace_sequence.py <kernel_trace.csv> [marker-kernel-substring (default: kmat)]
+usage: python scripts/dev_trace_sequence.py <kernel_trace.csv> [marker-kernel-substring (default: kmat)] [k: start at the k-th last marker kernel (default 1)]
 """
 import csv
 import re
@@ -23,7 +23,9 @@ for r in rows:
         grid *= max(1, int(r[g]) // max(1, int(r[w])))
     ev.append((int(r[ks]), int(r[ke]), grid, name[:60]))
 ev.sort()
-last = max((i for i, e in enumerate(ev) if marker in e[3]), default=0)
+kth = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+marks = [i for i, e in enumerate(ev) if marker in e[3]]
+last = marks[-kth] if len(marks) >= kth else 0
 ev = ev[last:]
 t0 = ev[0][0]
 prev = t0

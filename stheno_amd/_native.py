@@ -53,6 +53,11 @@ SIGNATURES = {
         [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr,
          _c_i64, _c_ptr],
     ),
+    "gpk_trsm_lower_to": (
+        _c_int,
+        [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64,
+         _c_i64, _c_i64, _c_ptr],
+    ),
     "gpk_trsv_lower": (
         _c_int,
         [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_ptr, _c_int, _c_i64, _c_i64, _c_ptr,

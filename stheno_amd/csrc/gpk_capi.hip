@@ -104,6 +104,14 @@ int gpk_trsm_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, 
                                  (T*)tmp, batch, (hipStream_t)stream));
 }
 
+int gpk_trsm_lower_to(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
+                      int sb, void* b, int64_t nrhs, int64_t ldb, int64_t sb_stride, void* x, int64_t ldx, int64_t sx_stride,
+                      int64_t batch, void* stream) {
+    if (x == nullptr) return GPK_ERR_ARG(12);
+    D1(dtype, gpk_trsm_launch<T>((const T*)l, n, ld, sl, (const T*)dinv_sb, sb, (T*)b, nrhs, ldb, sb_stride,
+                                 (T*)nullptr, batch, (hipStream_t)stream, (T*)x, ldx, sx_stride));
+}
+
 int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
                    int sb, void* b, int nrhs, int64_t ldb, int64_t sb_stride, void* tmp, int64_t batch,
                    void* stream) {

@@ -133,6 +133,11 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
 template <typename T>
 int gpk_gemm_persist_rejoin(const GpkPersistSaved* saved, hipStream_t helper_stream);
 
+// One 128-column step below a factorised diagonal block: panel solve + rank-128 update of the rest of the outer panel, one launch
+// (panel_step_kernel in gpk_gemm.hip).  flags: ceil((n - c - 128) / 32) zeroed words of device scratch.
+template <typename T>
+int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, int64_t ke, unsigned* flags, hipStream_t stream);
+
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
                      int* info, int nbo, hipStream_t stream);
@@ -164,7 +169,8 @@ int gpk_trtri_merge_launch(const T* L, int64_t n, int64_t ld, int64_t batch, int
                            const T* dinv128, int sb, T* dinv_sb, T* tmp, hipStream_t stream);
 template <typename T>
 int gpk_trsm_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
-                    int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream);
+                    int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream,
+                    T* X = nullptr, int64_t ldx = 0, int64_t sX = 0);
 template <typename T>
 int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
                     int nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream);

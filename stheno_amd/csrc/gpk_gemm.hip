@@ -68,6 +68,8 @@ struct GemmArgs {
     int tri_pairs;    // triangular enumeration by row pairs / 8-column chunks (see decode_tile)
     int n_super;
     int SN;
+    int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
+                      // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };
 
 __device__ __forceinline__ void tri_decode(int s, int& I, int& J) {
@@ -285,7 +287,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // Register staging.  Small tiles (TS = 64) serve the narrow, latency-bound GEMMs of the path
     // (panel / merge / solve), where a workgroup is often alone on its CU: they keep TWO k-chunks of
     // global loads in flight (PF2); the 128-tile kernel hides the latency with its second workgroup.
-    constexpr bool PF2 = (TS == 64);
+    constexpr bool PF2 = (TS <= 64);
     vec_t ra[PF2 ? 2 : 1][FR], rb[PF2 ? 2 : 1][NCT][FR];
 
     const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS * NCT <= p.N);
@@ -430,6 +432,17 @@ template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT = 1>
 __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (1 + NCT) * op_bytes(TS)];
     int ti, tj;
+    if constexpr (TS == 128 && NCT == 1) {
+        const int bid = (int)blockIdx.x;
+        if (bid >= p.split_from) {
+            const int qd = bid - p.split_from;
+            if (!decode_tile(p, p.split_from + (qd >> 2), ti, tj)) return;
+            const int ti2 = 2 * ti + ((qd >> 1) & 1), tj2 = 2 * tj + (qd & 1);
+            if ((p.lower_only && tj2 > ti2) || ti2 * 64 >= p.M || tj2 * 64 >= p.N) return;
+            gemm_tile<T, 64, A_KMAJ, B_KMAJ, EDGE, 1>(p, ti2, tj2, blockIdx.y, blockIdx.z, smem);
+            return;
+        }
+    }
     if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
     gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
@@ -454,6 +467,7 @@ template <typename T>
 struct PersistArgs {
     GemmArgs<T> seg[2];
     int ntiles0, ntiles;      // tiles of segment 0, of both
+    int ntasks, split_from;   // tasks = tiles, except that the tiles from split_from on are handed out as four quarter tiles each
     unsigned* ctrl;
     int reserve;
     int max_leave;
@@ -490,14 +504,17 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
     __syncthreads();
     t = __builtin_amdgcn_readfirstlane(s_tile);     // uniform by construction; tell the compiler (scalar loads of the segment)
     __syncthreads();
-    while (t < p.ntiles) {
+    while (t < p.ntasks) {
         // the next tile index is requested now and read after this tile: its latency hides under the k-loop
         int nxt = 0;
         if (tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);
-        const int sgi = (t >= p.ntiles0) ? 1 : 0;
+        const bool quarter = (TS == 128) && t >= p.split_from;
+        const int quad = quarter ? ((t - p.split_from) & 3) : 0;
+        const int tt = quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
+        const int sgi = (tt >= p.ntiles0) ? 1 : 0;
         const GemmArgs<T>& g = p.seg[sgi];
         int ti, tj;
-        const int tl = t - (sgi ? p.ntiles0 : 0);
+        const int tl = tt - (sgi ? p.ntiles0 : 0);
         int reps = 1;
         bool ok = true;
         if (g.tri_k_lo_b && g.pair_cols) {
@@ -509,6 +526,14 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             reps = 2;
         } else {
             ok = decode_tile(g, tl, ti, tj);
+        }
+        if constexpr (TS == 128) {
+            if (ok && quarter) {              // the last, partial round of the launch: 64 x 64 quarters of a 128-tile
+                const int ti2 = 2 * ti + (quad >> 1), tj2 = 2 * tj + (quad & 1);
+                if (!((g.lower_only && tj2 > ti2) || ti2 * 64 >= g.M || tj2 * 64 >= g.N))
+                    gemm_tile<T, 64, true, true, EDGE, 1>(g, ti2, tj2, 0, 0, smem, nullptr);
+                ok = false;
+            }
         }
         if (ok) {
             long long* pr = (p.prof != nullptr && nlocal < 8) ? p.prof + ((int64_t)blockIdx.x * 8 + nlocal) * 8 : nullptr;
@@ -580,6 +605,7 @@ Prof g_prof;
 
 int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
 int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
+int g_split_tail = 1;               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
                                     // unbalance the XCDs), so it is off unless asked for
@@ -615,6 +641,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 4) g_tri_pairs_from = (int)value;
     if (key == 8) g_persist_small_below = value;
     if (key == 13) g_colmajor_ratio = (int)value;
+    if (key == 31) g_split_tail = (int)value;
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -724,6 +751,21 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool edge = !aligned || (M % ts) || (N % (ts * nct)) || (K % BK);
     g.vec_ok = aligned ? 1 : 0;
 
+    // The last, partial round.  The hardware hands out workgroups in index order as slots free up, so with equal tiles the last
+    // `total mod slots` of them run alone at the end while the other slots idle -- up to a whole tile time per launch (measured:
+    // 1664 tiles = 3.25 rounds of 512 slots cost the time of 4).  When that remainder is at most half a round, its tiles are
+    // launched as four 64 x 64 quarter tiles each: they fit one or two rounds of ~0.35 tile times.  Same results (a tile's entries are
+    // computed by the same k order whichever kernel body does it).
+    g.split_from = INT32_MAX;
+    if (g_split_tail && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && !g.swizzle && !g.tri_pairs && !g.colmajor && (flags & (2 | 4 | 8)) == 0 &&
+        (const void*)A != (const void*)C && (const void*)B != (const void*)C) {      // (in-place: one workgroup must own all columns of its rows)
+        const int64_t slots = (int64_t)device_cus() * 2;
+        const int64_t rem = total % slots;
+        if (total > slots && rem > 0 && 2 * rem <= slots) {
+            g.split_from = (int)(total - rem);
+            gridx = total + 3 * rem;
+        }
+    }
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
     ProfSlot* slot = nullptr;
     if (g_prof.on) {
@@ -908,6 +950,8 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     if (live == 1) { pa.seg[1] = pa.seg[0]; }
     if (total > INT32_MAX / 2) return GPK_ERR_ARG(1);
     pa.ntiles = (int)total;
+    pa.ntasks = (int)total;
+    pa.split_from = INT32_MAX;
     pa.ctrl = ctrl;
     pa.prof = nullptr;
     if (g_tile_prof != nullptr) {
@@ -931,6 +975,16 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
             for (int x = 0; x < 8; ++x) { pa.rkeys[x] = keys[x]; nk += keys[x] != 0; }
             pa.reserve = nk > 0 ? 1 : 0;
             pa.max_leave = per_cu * nk;
+        }
+    }
+    if (g_split_tail && ts == 128 && total > gridx) {        // the last, partial round as quarter tiles (see gpk_gemm_launch2)
+        bool plain = true;
+        for (int i = 0; i < live; ++i) plain = plain && !pa.seg[i].pair_cols && !pa.seg[i].tri_k_lo_b;
+        const int64_t workers = gridx - pa.max_leave;
+        const int64_t rem = total % workers;
+        if (plain && workers > 0 && rem > 0 && 2 * rem <= workers) {
+            pa.split_from = (int)(total - rem);
+            pa.ntasks = (int)(total + 3 * rem);
         }
     }
     ProfSlot* slot = nullptr;
@@ -977,6 +1031,127 @@ int gpk_gemm_persist_rejoin(const GpkPersistSaved* saved, hipStream_t helper_str
     GPK_CHECK_LAUNCH();
     return GPK_OK;
 }
+
+// ---------------------------------------------------------------------------
+// One step of the blocked Cholesky below a factorised 128x128 diagonal block, in ONE launch (gpk_potrf.hip, single matrices):
+//   phase A   L[r, c:c+128] = P[r, :] inv(L_cc)^T          the panel solve, strips of TS rows (one workgroup per strip)
+//   phase B   A[r, cb] -= L[r, c:c+128] L[cb rows, c:c+128]^T   the rank-128 update of the columns of the outer panel still to come,
+//                                                          one workgroup per (strip, 128-column block) on or below the diagonal
+// Phase B of a workgroup needs phase A of its own strip and of the (up to 128 / TS) strips that hold the rows of its column block:
+// one flag word per strip, published by the strip's phase-A workgroup (stores -> barrier -> agent-scope release -> flag) and
+// polled by one lane of the consumers (relaxed agent loads -> agent-scope acquire -> barrier).  Phase-A workgroups have the lowest
+// block indices and never wait before they publish, so the launch makes progress whatever part of the grid is resident.  Against
+// two launches (panel solve, then update) the chain of a 128-column step loses a kernel boundary and a ramp, and with TS = 32 the
+// strips are twice as fine as the 64-row tiles of the plain kernel (a lone wave per SIMD issues its MFMAs at a fraction of the
+// pipe rate: the step is latency-bound, not throughput-bound).
+// ---------------------------------------------------------------------------
+namespace {
+template <typename T>
+struct PanelStepArgs {
+    GemmArgs<T> trsm;     // A = P (rows below the diagonal block; M x 128), B = inv(L_cc) (128 x 128), C = P (in place)
+    GemmArgs<T> upd;      // A = B = the panel after phase A (M x 128 / N x 128), C = the trailing columns (M x N)
+    unsigned* flags;      // one word per strip, zero before the launch
+    int nstrips, ncb;     // strips of TS rows; 128-column blocks to update (0: panel solve only)
+};
+
+template <typename T, int TS, bool EDGE>
+__global__ __launch_bounds__(256, 2) void panel_step_kernel(PanelStepArgs<T> p) {
+    constexpr int NCT = 128 / TS;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (1 + NCT) * op_bytes(TS)];
+    const int tid = threadIdx.x;
+    int strip = (int)blockIdx.x, cb = 0;
+    if (strip >= p.nstrips) {                  // an update-only workgroup: (strip, cb >= 1), strips from the first one that reaches block cb
+        int r = strip - p.nstrips;
+        for (cb = 1; cb < p.ncb; ++cb) {
+            const int cnt = p.nstrips - cb * NCT;
+            if (r < cnt) break;
+            r -= cnt;
+        }
+        if (cb >= p.ncb) return;
+        strip = cb * NCT + r;
+    }
+    if (cb == 0) {
+        gemm_tile<T, TS, true, true, EDGE, NCT>(p.trsm, strip, 0, 0, 0, smem);
+        __syncthreads();                        // every wave's stores of the strip are out (vmcnt drained before the barrier)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&p.flags[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (p.ncb == 0) return;
+    }
+    if (tid == 0) {
+        // the rows of column block cb are strips cb NCT .. cb NCT + NCT - 1; plus this workgroup's own strip when another one solved it
+        int lo = cb * NCT, hi = lo + NCT;
+        if (hi > p.nstrips) hi = p.nstrips;
+        for (int s = lo; s < hi + 1; ++s) {
+            const int f = (s < hi) ? s : strip;
+            while (__hip_atomic_load(&p.flags[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    gemm_tile<T, TS, true, true, EDGE, NCT>(p.upd, strip, cb, 0, 0, smem);
+}
+}  // namespace
+
+// A: n x n matrix (ld), c: first column of the factorised diagonal block, W = inv(L_cc) (128 x 128, row-major), ke: end of the outer
+// panel (columns [c + 128, ke) are updated; ke <= c + 128: panel solve only).  flags: >= ceil((n - c - 128) / 32) zeroed words.
+template <typename T>
+int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, int64_t ke, unsigned* flags, hipStream_t stream) {
+    const int64_t r1 = c + GPK_DB;
+    const int64_t m = n - r1;
+    if (m <= 0) return GPK_OK;
+    if (ke > n) ke = n;
+    const int64_t ncols = ke > r1 ? ke - r1 : 0;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int BK = Traits<T>::BK;
+    const int ts = (m <= 4096) ? 32 : 64;       // latency-bound steps take the finer strips
+    PanelStepArgs<T> pa;
+    GemmArgs<T>& g = pa.trsm;
+    T* P = A + r1 * ld + c;
+    g.A = P; g.B = W; g.C = P; g.Cin = P;
+    g.lda = ld; g.ldb = GPK_DB; g.ldc = ld; g.ldcin = ld;
+    g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
+    g.M = (int)m; g.N = GPK_DB; g.K = GPK_DB;
+    g.alpha = T(1); g.beta_over_alpha = T(0); g.has_beta = 0;
+    g.tiles_m = (int)gpk_cdiv(m, ts); g.tiles_n = 1;
+    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
+    g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
+    const bool aligned = ((uintptr_t)P % 16 == 0) && ((uintptr_t)W % 16 == 0) && (ld % VEC == 0);
+    g.vec_ok = aligned ? 1 : 0;
+    GemmArgs<T>& u = pa.upd;
+    u = g;
+    u.A = P; u.B = P; u.C = A + r1 * ld + r1; u.Cin = u.C;
+    u.ldb = ld;
+    u.N = (int)ncols;
+    u.alpha = T(-1); u.beta_over_alpha = T(-1); u.has_beta = 1;
+    u.tiles_n = (int)gpk_cdiv(ncols > 0 ? ncols : 1, GPK_DB);
+    const bool edge = !aligned || (m % ts) || (ncols % GPK_DB) || (GPK_DB % BK);
+    pa.flags = flags;
+    pa.nstrips = (int)gpk_cdiv(m, ts);
+    pa.ncb = (int)gpk_cdiv(ncols, GPK_DB);
+    const int nct = GPK_DB / ts;
+    int64_t grid = pa.nstrips;
+    for (int cb = 1; cb < pa.ncb; ++cb) {
+        const int64_t cnt = pa.nstrips - (int64_t)cb * nct;
+        if (cnt > 0) grid += cnt;
+    }
+    ProfSlot* slot = nullptr;
+    if (g_prof.on) slot = g_prof.begin(64 + (sizeof(T) == 8 ? 8 : 0) + (edge ? 1 : 0), (double)m * GPK_DB * GPK_DB + 2.0 * (double)m * (double)ncols * GPK_DB, stream);
+    if (ts == 32) {
+        if (edge) hipLaunchKernelGGL((panel_step_kernel<T, 32, true>), dim3((unsigned)grid), dim3(256), 0, stream, pa);
+        else hipLaunchKernelGGL((panel_step_kernel<T, 32, false>), dim3((unsigned)grid), dim3(256), 0, stream, pa);
+    } else {
+        if (edge) hipLaunchKernelGGL((panel_step_kernel<T, 64, true>), dim3((unsigned)grid), dim3(256), 0, stream, pa);
+        else hipLaunchKernelGGL((panel_step_kernel<T, 64, false>), dim3((unsigned)grid), dim3(256), 0, stream, pa);
+    }
+    if (slot) g_prof.end(slot, stream);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+template int gpk_panel_step_launch<double>(double*, int64_t, int64_t, int64_t, const double*, int64_t, unsigned*, hipStream_t);
+template int gpk_panel_step_launch<float>(float*, int64_t, int64_t, int64_t, const float*, int64_t, unsigned*, hipStream_t);
 
 #define GPK_INST(T)                                                                                  \
     template int gpk_gemm_launch2<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,    \

@@ -20,7 +20,6 @@
 // inv(L_cc) blocks are kept: gpk_solve.hip turns every triangular solve of the
 // path into GEMM/GEMV work with them.
 #include "gpk_common.hpp"
-#include "gpk_diag_sched.hpp"
 #include <vector>
 
 namespace {
@@ -37,6 +36,7 @@ struct DiagArgs {
     int* info;
     int info_base;     // added to the reported pivot order (the matrix may be a diagonal block of a larger one)
     long long* prof;   // debug: per-phase cycle stamps of workgroup 0 (nullable)
+    int zero_next;     // clear the first 4 KiB of the NEXT block's slot in `dinv`: the flag words of the panel step that follows (gpk_panel_step_launch)
 };
 
 #define PROF_MARK(i)                                                            \
@@ -444,347 +444,143 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
         for (int v = 0; v < VEC; ++v) w[v] = S[r * LDP + c + v];
         *reinterpret_cast<vec_t*>(W + (int64_t)r * GPK_DB + c) = w;
     }
+    if (p.zero_next) {
+        uint4* z = reinterpret_cast<uint4*>(W + (int64_t)GPK_DB * GPK_DB);
+        z[tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
     PROF_MARK(5);
 }
 
 // ---------------------------------------------------------------------------
-// potrf_diag2_kernel -- the same job (factor the 128x128 diagonal block in LDS, write L, invert in LDS, write inv(L)) with the
-// serial chain stripped to what is serial.  See gpk_diag_sched.hpp for the structure (phases, who does what); here are the two
-// engines the schedule drives:
-//
-//  * chol16 (the chain wave): Cholesky AND inverse of one 16x16 tile held in the MFMA accumulator layout.  The tile is kept as a
-//    full symmetric matrix C; column j of the elimination is ONE v_mfma 16x16x4 rank-1 update  C -= v v^T / d  whose A and B
-//    operands are the SAME accumulator register -- row j of C sits in register rowi(j) of the 16 lanes of lane group rowq(j),
-//    which is exactly the lane group that supplies k-slice rowq(j) of both operands, and by symmetry row j is column j -- so no
-//    cross-lane traffic at all besides v_readlanes of the pivot.  A second MFMA per column applies the same elimination to a
-//    tile E that starts as the identity: E ends as the unit-lower inverse, inv(L) = diag(1/sqrt(d)) E.  The pivot recurrence
-//    d_{j+1} = C[j+1][j+1] - C[j][j+1]^2 / d_j runs one column AHEAD on the scalar side (two v_readlanes + FMA + v_rcp + Newton),
-//    in the shadow of the two MFMAs of column j; square roots are taken once, for all 16 pivots, after the loop.  The chain per
-//    column is then about the matrix pipe (2 x 64 cycles in fp64), against readlane -> rsq -> Goldschmidt -> 15 readlane / FMA
-//    pairs (~250 cycles) in potrf_diag_kernel above;
-//  * run_tasks: an interpreter of 16x16 tile products (solves against an inverted diagonal tile, rank-16 updates, merge passes of
-//    the inverse).  A wave is alone on its SIMD and issues in order, so everything that is not an MFMA has to sit BETWEEN the
-//    (dependent) MFMAs of a product: the operands of the next k-block are requested between the four MFMAs of the current one,
-//    the result of the previous product is written after the first MFMA of the next.  The task words (LDS element offsets
-//    precomputed on the host side of the table) travel in VGPR lanes and are fetched with v_readlane: no scalar memory load in
-//    the loop (those share the LDS wait counter).
+// potrf_diag3_kernel -- potrf_diag_kernel restructured around what a lone wave per SIMD costs on gfx950 (scripts/dev/mfma_latency.hip:
+// one wave issues an fp64 v_mfma 16x16x4 every ~140 cycles at best -- 46 % of the pipe -- and ~180 on a dependent chain; two waves per
+// SIMD reach the pipe rate between them):
+//  * 512 threads = two waves per SIMD: every MFMA phase (rank-16 updates, the three merge levels of the inverse) gets twice the
+//    matrix throughput of the 256-thread kernel;
+//  * no separate micro-TRSM: the 16-column micro-panel is factorised as a PANEL.  In micro_chol only lanes 0..15 of the wave held rows
+//    (the other three 16-lane groups computed the same thing redundantly); here those lane groups hold the rows of the tiles BELOW the
+//    diagonal tile, and the scaling + rank-1 updates of the very same loop are their triangular solve -- for free, in the shadow of
+//    the broadcast chain.  One wave covers the diagonal tile + 3 tiles; up to three waves (each repeating the diagonal tile's
+//    arithmetic, so that they need no communication) cover the whole micro-panel;
+//  * per micro-step: (U1) all eight waves update micro-column s+1 by column s (one tile each), then the panel waves factorise
+//    micro-panel s+1 WHILE the other waves apply column s to the rest of the trailing tiles (U2).
+// Everything else (load, write-back, in-LDS inversion by recursive doubling) as in potrf_diag_kernel, on eight waves.
 // ---------------------------------------------------------------------------
-constexpr int LDD = 17;    // row pitch of the kept diagonal tiles of L
+constexpr int D3_THREADS = 512;
+constexpr int D3_WAVES = D3_THREADS / 64;
 
-__constant__ gpk_diag::DevSched g_diag_sched = gpk_diag::make_dev_sched(LDP);
-static_assert(gpk_diag::sched_has_end_slot(), "diagonal-block schedule: every task list needs an empty slot at its end");
-static_assert(GPK_DB * LDP < 65536, "tile offsets are packed into 16 bits");
+// waves that factorise micro-panel s (tiles s .. 7: the diagonal tile + 7 - s tiles below it, three per wave)
+__device__ __forceinline__ int panel_waves(int s) { return s == 0 ? 3 : (s <= 3 ? 2 : 1); }
 
-#define GPK_SB() __builtin_amdgcn_sched_barrier(0)
-
-__device__ __forceinline__ double recip_nr(double d) {      // 1 / d: v_rcp_f64 (2^-26) + two Newton steps
-    double y = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-d, y, 1.0);
-    y = fma(y, e, y);
-    return y;
-}
-__device__ __forceinline__ float recip_nr(float d) {
-    float y = __builtin_amdgcn_rcpf(d);
-    const float e = fmaf(-d, y, 1.0f);
-    y = fmaf(y, e, y);
-    return y;
-}
-
+// micro-panel s by wave `pw` (0 .. panel_waves(s) - 1): lanes 0..15 = rows of the diagonal tile, lane group g = 1..3 = rows of tile
+// s + 3 pw + g (idle past tile 7).  Wave 0 writes the diagonal tile, the reciprocal pivots and reports a non-positive pivot.
 template <typename T>
-__device__ __forceinline__ void chol16(T* __restrict__ S, T* __restrict__ Ld, int s, int lane, int* info, int info_off) {
-    typedef typename Traits<T>::acc_t acc_t;
+__device__ __forceinline__ void panel_chol(T* __restrict__ S, T* __restrict__ rdiag, int s, int pw, int lane, int* info, int off) {
     const int lr = lane & 15, g = lane >> 4;
     const int c0 = 16 * s;
-    acc_t c, e;
+    const int tile = (g == 0) ? s : s + 3 * pw + g;
+    const bool live = tile < 8;
+    const int row = 16 * (live ? tile : s) + lr;
+    T a[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                 // only the lower triangle of the tile is meaningful in LDS: mirror it on the way in
-        const int r = Traits<T>::crow(lane, i);
-        const int hi = r > lr ? r : lr, lo = r > lr ? lr : r;
-        c[i] = S[(c0 + hi) * LDP + c0 + lo];
-        e[i] = (r == lr) ? T(1) : T(0);
-    }
-    T vsave[16];                                  // row j of C at step j (lane group rowq(j)): column j of L before scaling
-    T dvec = T(1);                                // lane with (lane & 15) == j keeps pivot j
-    T d = lane_bcast(c[Traits<T>::rowi(0)], 16 * Traits<T>::rowq(0));
-    T rho = -recip_nr(d);
+    for (int c = 0; c < 16; ++c) a[c] = S[row * LDP + c0 + c];
     int bad = 0;
+    T myr = T(0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int q = Traits<T>::rowq(j), i = Traits<T>::rowi(j);
-        const bool inq = (g == q);
-        const T v = inq ? c[i] : T(0);            // row j of C = column j (symmetry), in k-slice q of both operands
-        const T w = v * rho;                      // -v / d
-        T vj1 = T(0), cj1 = T(1);
-        if (j < 15) {                             // what the next pivot needs, taken BEFORE this column's update
-            vj1 = lane_bcast(c[i], 16 * q + j + 1);                                                     // C[j][j+1]
-            cj1 = lane_bcast(c[Traits<T>::rowi(j + 1)], 16 * Traits<T>::rowq(j + 1) + j + 1);          // C[j+1][j+1]
-        }
-        GPK_SB();
-        c = Traits<T>::mfma(v, w, c);             // C -= v v^T / d
-        GPK_SB();
-        // in the shadow of that MFMA: the next pivot (first half), the operands of the E update
-        const T d_next = fma(vj1 * rho, vj1, cj1);
-        T y = (sizeof(T) == 8) ? (T)__builtin_amdgcn_rcp((double)d_next) : (T)__builtin_amdgcn_rcpf((float)d_next);
-        const T we = (inq && lr > j) ? w : T(0);
-        const T eb = inq ? e[i] : T(0);
+        const T d = lane_bcast(a[j], j);
         bad = (!(d > T(0)) && bad == 0) ? j + 1 : bad;
-        dvec = (lr == j) ? d : dvec;
-        vsave[j] = v;
-        GPK_SB();
-        e = Traits<T>::mfma(we, eb, e);           // E[r][:] -= (v_r / d) E[j][:],  r > j
-        GPK_SB();
-        // Newton steps of the reciprocal of the next pivot
-        T en = fma(-d_next, y, T(1));
-        y = fma(y, en, y);
-        if (sizeof(T) == 8) {
-            en = fma(-d_next, y, T(1));
-            y = fma(y, en, y);
+        T ljj, rinv;
+        sqrt_rsqrt(d, ljj, rinv);
+        a[j] = (lane == j) ? ljj : a[j] * rinv;       // rows below the diagonal tile: this IS their solve
+        myr = (lane == j) ? rinv : myr;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+            const T lcj = lane_bcast(a[j], c);
+            a[c] -= a[j] * lcj;
         }
-        d = d_next;
-        rho = -y;
     }
-    // 1 / sqrt(d_j) for all 16 pivots at once (lane j), then: column j of L = vsave[j] / sqrt(d_j); row r of the inverse = E[r] / sqrt(d_r)
-    T sq, rsv;
-    sqrt_rsqrt(dvec, sq, rsv);
-    T rs[16];
+    if (live && (g != 0 || pw == 0)) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) rs[j] = lane_bcast(rsv, j);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        T sel = rs[Traits<T>::crow(0, i)];
-#pragma unroll
-        for (int gg = 1; gg < 4; ++gg) sel = (g == gg) ? rs[Traits<T>::crow(16 * gg, i)] : sel;
-        S[(c0 + Traits<T>::crow(lane, i)) * LDP + c0 + lr] = e[i] * sel;                                // inv(L_ss), zeros above the diagonal
+        for (int c = 0; c < 16; ++c) S[row * LDP + c0 + c] = a[c];
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (g == Traits<T>::rowq(j) && lr >= j) Ld[(c0 + lr) * LDD + j] = vsave[j] * rs[j];            // L[lr][j]  (lr = j: d / sqrt(d))
-    if (bad != 0 && lane == 0) atomicCAS(info, 0, info_off + c0 + bad);
-}
-
-template <typename T>
-struct TileOps {
-    T a[4], b[4];
-};
-
-template <typename T>
-struct Diag2Out {          // what the write-back of L needs
-    T* A;
-    int64_t ld;
-    int nv;
-    bool vec_io;
-};
-
-// column panel s of L (rows 16 s .. 127, 16 columns), part `part` of `parts` (by rows), from LDS to global memory: the diagonal
-// tile comes from Ld (lower part only: nothing above the diagonal of A is ever written), the rest from S.
-template <typename T>
-__device__ __forceinline__ void store_panel(const T* __restrict__ S, const T* __restrict__ Ld, uint32_t w0, int lane, const Diag2Out<T>& o) {
-    typedef typename Traits<T>::vec_t vec_t;
-    constexpr int VEC = Traits<T>::VEC;
-    constexpr int LPR = 16 / VEC;                 // lanes per row
-    const int s = w0 & 0xff, part = (w0 >> 8) & 0xf, parts = (w0 >> 12) & 0xf;
-    const int r0 = 16 * s, rows = GPK_DB - r0;
-    const int len = ((rows + parts - 1) / parts + 7) / 8 * 8;
-    const int rbeg = r0 + part * len;
-    int rend = rbeg + len;
-    if (rend > GPK_DB) rend = GPK_DB;
-    if (rend > o.nv) rend = o.nv;
-    const int cv = (lane % LPR) * VEC;
-    for (int r = rbeg + lane / LPR; r < rend; r += 64 / LPR) {
-        T* dst = o.A + (int64_t)r * o.ld + r0 + cv;
-        if (r < r0 + 16) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                if (cv + v <= r - r0) dst[v] = Ld[r * LDD + cv + v];
-        } else {
-            vec_t val;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) val[v] = S[r * LDP + r0 + cv + v];
-            if (o.vec_io) {
-                *reinterpret_cast<vec_t*>(dst) = val;
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) dst[v] = val[v];
-            }
-        }
+    if (pw == 0) {
+        if (lane < 16) rdiag[c0 + lr] = myr;
+        if (bad != 0 && lane == 0) atomicCAS(info, 0, off + c0 + bad);
     }
 }
 
-// One k-block of a tile product with compile-time roles: `cur` holds its operands, `nx` receives those of the next k-block
-// (p0 / p1 / pkb describe it; a harmless re-read of the current block when there is nothing to prefetch), `acc` accumulates,
-// `oth` is the other accumulator: it may still hold the previous product (written out after the first MFMA) and receives the
-// starting value of the next product.
-template <typename T>
-__device__ __forceinline__ void tile_step(T* __restrict__ S, TileOps<T>& cur, TileOps<T>& nx, typename Traits<T>::acc_t& acc,
-                                          typename Traits<T>::acc_t& oth, uint32_t w0, uint32_t p0, uint32_t p1, int pkb, bool last, bool pre,
-                                          bool has_next, uint32_t n0, uint32_t n1, bool pend, int pend_off, int offA, int offBn, int offC) {
-    using namespace gpk_diag;
-    constexpr int CSTEP = (sizeof(T) == 8 ? 4 : 1) * LDP;      // LDS rows between accumulator registers i and i + 1
-    acc = Traits<T>::mfma(cur.a[0], cur.b[0], acc);
-    GPK_SB();
-    if (pend) {                                                 // the previous product, finished one MFMA ago
-        T* po = S + pend_off + offC;
+// One level of the recursive-doubling inversion on NW waves (see invert_level): the NPAIR * TPP output tiles are dealt round-robin
+// to the waves, each wave advances its (at most PER) tiles together, and every tile accumulates into TWO accumulators (even / odd
+// k-steps, summed at the end): a dependent fp64 MFMA costs ~180 cycles, so the levels with one tile per wave are chain-bound, not
+// pipe-bound.  (Skipping the k-blocks in which the triangular operand vanishes -- 3/8 of the last level -- was tried with
+// wave-uniform predicates around the loads and MFMAs: 17.3k -> 20.2k cycles for the three levels, the branches cost more than
+// the MFMAs they save.)
+template <typename T, int H, int NW>
+__device__ __forceinline__ void invert_level_w(T* S, int wave, int lane, int lr, int kq) {
+    typedef typename Traits<T>::acc_t acc_t;
+    constexpr int HB = H / 16, TPP = HB * HB, NPAIR = GPK_DB / (2 * H), NTILE = NPAIR * TPP, PER = (NTILE + NW - 1) / NW;
+    int ti[PER], tj[PER], o[PER];
+    bool on[PER];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) po[i * CSTEP] = oth[i];
+    for (int q = 0; q < PER; ++q) {
+        const int item = wave + NW * q;
+        on[q] = item < NTILE;
+        const int it = on[q] ? item : 0;
+        const int t = it % TPP;
+        ti[q] = t / HB;
+        tj[q] = t % HB;
+        o[q] = (it / TPP) * 2 * H;
     }
-    {
-        const T* pa = S + (p0 >> 16) + 16 * pkb + offA;
-        const bool neg = dw1_neg(p1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const T a = pa[4 * kk];
-            nx.a[kk] = neg ? -a : a;
-        }
-    }
-    GPK_SB();
-    acc = Traits<T>::mfma(cur.a[1], cur.b[1], acc);
-    GPK_SB();
-    {
-        const bool bt = dw1_btrans(p1);
-        const T* pb = S + (p1 & 0xffff) + (bt ? 16 * pkb + offA : 16 * LDP * pkb + offBn);
-        const int bs = bt ? 4 : 4 * LDP;
+    for (int pass = 0; pass < 2; ++pass) {
+        acc_t acc[PER][2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) nx.b[kk] = pb[kk * bs];
-    }
-    GPK_SB();
-    acc = Traits<T>::mfma(cur.a[2], cur.b[2], acc);
-    GPK_SB();
-    T ini[4];
-    {
-        const T* pc = S + (p0 & 0xffff) + offC;
+        for (int q = 0; q < PER; ++q)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ini[i] = pc[i * CSTEP];
-    }
-    GPK_SB();
-    acc = Traits<T>::mfma(cur.a[3], cur.b[3], acc);
-    GPK_SB();
-    if (last) {
-        if (pre) {
-            const bool init = dw1_init(p1);
+            for (int e = 0; e < 2; ++e) acc[q][e][0] = acc[q][e][1] = acc[q][e][2] = acc[q][e][3] = T(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) oth[i] = init ? ini[i] : T(0);
-        } else {
-            // nothing was prefetched (the list ends here, or the next product reads this one's output): write out now, then fetch
-            T* po = S + (w0 & 0xffff) + offC;
+        for (int kb = 0; kb < HB; ++kb) {
+            T av[PER][4], bv[PER][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) po[i * CSTEP] = acc[i];
-            if (has_next) {
-                const T* pa = S + (n0 >> 16) + offA;
-                const bool neg = dw1_neg(n1);
-                const bool bt = dw1_btrans(n1);
-                const T* pb = S + (n1 & 0xffff) + (bt ? offA : offBn);
-                const int bs = bt ? 4 : 4 * LDP;
-                const T* pc = S + (n0 & 0xffff) + offC;
-                const bool init = dw1_init(n1);
+            for (int q = 0; q < PER; ++q)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const T a = pa[4 * kk];
-                    nx.a[kk] = neg ? -a : a;
-                    nx.b[kk] = pb[kk * bs];
+                    const int k = 16 * kb + 4 * kk + kq;
+                    if (pass == 0) {   // T = C * Ainv
+                        av[q][kk] = S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + k];
+                        bv[q][kk] = S[(o[q] + k) * LDP + o[q] + 16 * tj[q] + lr];
+                    } else {           // C' = -Dinv * T
+                        av[q][kk] = -S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + H + k];
+                        bv[q][kk] = S[(o[q] + H + k) * LDP + o[q] + 16 * tj[q] + lr];
+                    }
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const T vinit = pc[i * CSTEP];
-                    oth[i] = init ? vinit : T(0);
-                }
-            }
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int q = 0; q < PER; ++q) acc[q][kk & 1] = Traits<T>::mfma(av[q][kk], bv[q][kk], acc[q][kk & 1]);
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+            if (on[q]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    S[(o[q] + H + 16 * ti[q] + Traits<T>::crow(lane, i)) * LDP + o[q] + 16 * tj[q] + lr] = acc[q][0][i] + acc[q][1][i];
+            }
+        __syncthreads();
     }
 }
 
 template <typename T>
-__device__ __forceinline__ void run_tasks(T* __restrict__ S, const T* __restrict__ Ld, unsigned tw, int lane, const Diag2Out<T>& o) {
-    using namespace gpk_diag;
-    typedef typename Traits<T>::acc_t acc_t;
-    constexpr int CSTEP = (sizeof(T) == 8 ? 4 : 1) * LDP;
-    const int lr = lane & 15, kq = lane >> 4;
-    const int offA = lr * LDP + kq;              // A operand, and B read transposed
-    const int offBn = kq * LDP + lr;             // B read as stored
-    const int offC = Traits<T>::crow(lane, 0) * LDP + lr;
-    auto W0 = [&](int q) { return (uint32_t)__builtin_amdgcn_readlane((int)tw, q); };
-    auto W1 = [&](int q) { return (uint32_t)__builtin_amdgcn_readlane((int)tw, MAXT + q); };
-
-    int q = 0;
-    uint32_t w0 = W0(0), w1 = W1(0);
-    if (dw1_kind(w1) == (int)K_MM) {
-        TileOps<T> o0, o1;
-        acc_t a0, a1;
-        {   // prologue: operands of the first k-block, start of the first accumulator
-            const T* pa = S + (w0 >> 16) + offA;
-            const bool neg = dw1_neg(w1), bt = dw1_btrans(w1), init = dw1_init(w1);
-            const T* pb = S + (w1 & 0xffff) + (bt ? offA : offBn);
-            const int bs = bt ? 4 : 4 * LDP;
-            const T* pc = S + (w0 & 0xffff) + offC;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const T a = pa[4 * kk];
-                o0.a[kk] = neg ? -a : a;
-                o0.b[kk] = pb[kk * bs];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const T vinit = pc[i * CSTEP];
-                a0[i] = init ? vinit : T(0);
-                a1[i] = T(0);
-            }
-        }
-        int kb = 0, state = 0, pend_off = 0;
-        bool pend = false;
-#pragma unroll 1
-        while (true) {
-            const bool last = (kb + 1 == dw1_nkb(w1));
-            uint32_t n0 = w0, n1 = w1;
-            bool has_next = true;
-            if (last) {
-                n0 = W0(q + 1);
-                n1 = W1(q + 1);
-                has_next = dw1_kind(n1) == (int)K_MM;
-            }
-            const bool pre = has_next && !(last && dw1_dep(n1));
-            const uint32_t p0 = pre ? n0 : w0, p1 = pre ? n1 : w1;
-            const int pkb = (pre && !last) ? kb + 1 : 0;
-            switch (state) {
-                case 0: tile_step<T>(S, o0, o1, a0, a1, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
-                case 1: tile_step<T>(S, o1, o0, a0, a1, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
-                case 2: tile_step<T>(S, o0, o1, a1, a0, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
-                default: tile_step<T>(S, o1, o0, a1, a0, w0, p0, p1, pkb, last, pre, has_next, n0, n1, pend, pend_off, offA, offBn, offC); break;
-            }
-            pend = last && pre;
-            pend_off = w0 & 0xffff;
-            state ^= 1;
-            if (last) {
-                if (!has_next) break;
-                state ^= 2;
-                ++q;
-                w0 = n0;
-                w1 = n1;
-                kb = 0;
-            } else {
-                ++kb;
-            }
-        }
-        ++q;
-        w0 = W0(q);
-        w1 = W1(q);
-    }
-    while (dw1_kind(w1) == (int)K_STORE) {
-        store_panel<T>(S, Ld, w0, lane, o);
-        ++q;
-        w0 = W0(q);
-        w1 = W1(q);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, 1) void potrf_diag2_kernel(DiagArgs<T> p) {
-    __shared__ __attribute__((aligned(16))) T S[GPK_DB * LDP];
-    __shared__ T Ld[GPK_DB * LDD];
+__global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) T S[GPK_DB * LDP + GPK_DB];
+    T* rdiag = S + GPK_DB * LDP;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
     const int64_t b = blockIdx.x;
     T* __restrict__ A = p.A + b * p.bstride + p.off * p.ld + p.off;
     const int rem = p.n - (int)p.off;
@@ -792,86 +588,171 @@ __global__ __launch_bounds__(256, 1) void potrf_diag2_kernel(DiagArgs<T> p) {
 
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
-    constexpr int CPR = GPK_DB / VEC;              // 16-byte chunks per row
-    constexpr int PER = GPK_DB * CPR / 256;        // chunks per thread
+    constexpr int CPR = GPK_DB / VEC;                    // 16-byte chunks per row
+    constexpr int PER = GPK_DB * CPR / D3_THREADS;       // chunks per thread
     const bool vec_io = (nv == GPK_DB) && ((uintptr_t)A % 16 == 0) && (p.ld % VEC == 0);
     long long* prof = (p.prof != nullptr && blockIdx.x == 0 && tid == 0) ? p.prof + (p.off / GPK_DB) * 32 : nullptr;
     if (prof) prof[0] = (long long)__builtin_readcyclecounter();
 
-    // this wave's task words of the first phase (lanes 0 .. 2 MAXT - 1), requested before the block itself
-    const uint32_t* __restrict__ sched = &g_diag_sched.w[0][0][0];
-    const int tlane = lane < 2 * gpk_diag::MAXT ? lane : 0;
-    unsigned tw = sched[(0 * 4 + wave) * 2 * gpk_diag::MAXT + tlane];
-
-    // ---- load the lower triangle (identity-padded past nv); nothing above the diagonal is initialised: those tiles are scratch
-    // and chol16 mirrors the diagonal tiles on the way in ----
+    // ---- phase 0: load the lower triangle; pad with identity; zeros above the diagonal ----
     if (vec_io) {
+        // all global loads of a thread are in flight before its first LDS store (one latency, not one per chunk)
         vec_t buf[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
+            const int id = tid + D3_THREADS * i;
             const int r = id / CPR, c = (id % CPR) * VEC;
-            if (c <= r) buf[i] = *reinterpret_cast<const vec_t*>(A + (int64_t)r * p.ld + c);
+            const int cc = (c <= r) ? c : 0;             // (above the diagonal: a harmless in-bounds address, the value is dropped below)
+            buf[i] = *reinterpret_cast<const vec_t*>(A + (int64_t)r * p.ld + cc);
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
+            const int id = tid + D3_THREADS * i;
             const int r = id / CPR, c = (id % CPR) * VEC;
-            if (c <= r) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) S[r * LDP + c + v] = buf[i][v];      // (the entries right of the diagonal in this chunk: never read)
-            }
+            for (int v = 0; v < VEC; ++v) S[r * LDP + c + v] = (c + v <= r) ? buf[i][v] : T(0);
         }
     } else {
-        for (int base = 0; base < GPK_DB * GPK_DB; base += 256 * 16) {
-            T buf[16];
+#pragma unroll 1
+        for (int base = 0; base < GPK_DB * GPK_DB; base += D3_THREADS * 8) {
+            T buf[8];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = base + tid + 256 * i;
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + tid + D3_THREADS * i;
                 const int r = idx >> 7, c = idx & 127;
                 buf[i] = (r < nv && c <= r) ? A[(int64_t)r * p.ld + c] : ((r == c) ? T(1) : T(0));
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = base + tid + 256 * i;
-                const int r = idx >> 7, c = idx & 127;
-                if (c <= r) S[r * LDP + c] = buf[i];
+            for (int i = 0; i < 8; ++i) {
+                const int idx = base + tid + D3_THREADS * i;
+                S[(idx >> 7) * LDP + (idx & 127)] = buf[i];
             }
         }
     }
     __syncthreads();
     if (prof) prof[1] = (long long)__builtin_readcyclecounter();
 
-    Diag2Out<T> o{A, p.ld, nv, vec_io};
-#pragma unroll 1
-    for (int ph = 0; ph < gpk_diag::NPH; ++ph) {
-        // next phase's task words: in flight under this phase
-        const int phn = ph + 1 < gpk_diag::NPH ? ph + 1 : ph;
-        const unsigned twn = sched[(phn * 4 + wave) * 2 * gpk_diag::MAXT + tlane];
-        if (wave == 0 && (ph & 1) == 0 && ph <= 14) chol16<T>(S, Ld, ph >> 1, lane, p.info + b, (int)p.off + p.info_base);
-        run_tasks<T>(S, Ld, tw, lane, o);
+    // ---- phase 1: factorise ----
+    {
+        const int np = panel_waves(0);
+        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane, p.info + b, (int)p.off + p.info_base);
+    }
+    __syncthreads();
+    if (prof) prof[2] = (long long)__builtin_readcyclecounter();
+    for (int s = 0; s < 7; ++s) {
+        const int c0 = 16 * s;
+        // (U1) micro-column s+1 by column s: 7 - s tiles, one per wave
+        rank16_update<T>(S, c0, 0, s, 7 - s, wave, D3_WAVES, lane, lr, kq);
         __syncthreads();
-        tw = twn;
-        if (prof) prof[2 + ph] = (long long)__builtin_readcyclecounter();
+        // panel s+1 on its waves  ||  (U2) column s applied to the remaining tiles on the others
+        const int np = panel_waves(s + 1);
+        if (wave < np)
+            panel_chol<T>(S, rdiag, s + 1, wave, lane, p.info + b, (int)p.off + p.info_base);
+        else
+            rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - np, D3_WAVES - np, lane, lr, kq);
+        __syncthreads();
+        if (prof) prof[3 + s] = (long long)__builtin_readcyclecounter();
     }
 
+    // ---- phase 2: write L (lower triangle only; the upper triangle is never touched) ----
+    if (vec_io) {
+        vec_t wbuf[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + D3_THREADS * i;
+            const int r = id / CPR, c = (id % CPR) * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) wbuf[i][v] = S[r * LDP + c + v];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = tid + D3_THREADS * i;
+            const int r = id / CPR, c = (id % CPR) * VEC;
+            if (c + VEC - 1 <= r) {
+                *reinterpret_cast<vec_t*>(A + (int64_t)r * p.ld + c) = wbuf[i];
+            } else if (c <= r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (c + v <= r) A[(int64_t)r * p.ld + c + v] = wbuf[i][v];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
+            const int r = idx >> 7, c = idx & 127;
+            if (r < nv && c <= r) A[(int64_t)r * p.ld + c] = S[r * LDP + c];
+        }
+    }
     if (p.dinv == nullptr) return;
-    // ---- write inv(L): the lower triangle of S; zeros above the diagonal (those tiles held scratch) ----
+    // phase 2's reads of S are complete before the in-place inversion -- a barrier that waits for the LDS only: __syncthreads()
+    // would also wait for the write-back of L to RETIRE (s_waitcnt vmcnt(0)), ~5k cycles of nothing (measured: "storeL 6.2k")
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (prof) prof[10] = (long long)__builtin_readcyclecounter();
+
+    // ---- phase 3: invert L in place ----
+    // I. the eight 16x16 diagonal tiles: 16-lane group g of waves 0 / 1 owns tile 4 * wave + g, lane lr solves for column lr of
+    //    the inverse.  Right-looking: x_i is final once the columns before it have been applied, then column i of L updates the rows
+    //    below (independent FMAs: the dependent chain is one multiply + one FMA per step); column i + 1 is requested while column i
+    //    is applied (two waves per SIMD leave 256 registers per lane: the 120 multipliers of the fp64 tile would not fit)
+    if (wave < 2) {
+        const int c0 = 16 * (4 * wave + kq);
+        T x[16], v[16], rd[16], col[2][16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] = (i == lr) ? T(1) : T(0);
+            rd[i] = rdiag[c0 + i];
+        }
+#pragma unroll
+        for (int r = 1; r < 16; ++r) col[0][r] = S[(c0 + r) * LDP + c0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i + 1 < 16) {
+#pragma unroll
+                for (int r = i + 2; r < 16; ++r) col[(i + 1) & 1][r] = S[(c0 + r) * LDP + c0 + i + 1];
+            }
+            x[i] = v[i] * rd[i];
+#pragma unroll
+            for (int r = i + 1; r < 16; ++r) v[r] -= col[i & 1][r] * x[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // every multiplier has been read before the tile is overwritten (one lane group owns it)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[(c0 + i) * LDP + c0 + lr] = x[i];   // zeros above the diagonal
+    }
+    __syncthreads();
+    if (prof) prof[11] = (long long)__builtin_readcyclecounter();
+    // II. recursive doubling: [A 0; C D]^-1 = [Ai 0; -Di C Ai, Di].
+    invert_level_w<T, 16, D3_WAVES>(S, wave, lane, lr, kq);
+    invert_level_w<T, 32, D3_WAVES>(S, wave, lane, lr, kq);
+    invert_level_w<T, 64, D3_WAVES>(S, wave, lane, lr, kq);
+    if (prof) prof[12] = (long long)__builtin_readcyclecounter();
+
+    // ---- phase 4: write inv(L) (identity-padded, zeros above the diagonal) ----
     T* __restrict__ W = p.dinv + b * p.dinv_bstride + (p.off / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + D3_THREADS * i;
         const int r = id / CPR, c = (id % CPR) * VEC;
         vec_t w;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) w[v] = (c + v <= r) ? S[r * LDP + c + v] : T(0);
+        for (int v = 0; v < VEC; ++v) w[v] = S[r * LDP + c + v];
         *reinterpret_cast<vec_t*>(W + (int64_t)r * GPK_DB + c) = w;
     }
-    if (prof) prof[2 + gpk_diag::NPH] = (long long)__builtin_readcyclecounter();
+    if (p.zero_next && tid < 256) {
+        uint4* z = reinterpret_cast<uint4*>(W + (int64_t)GPK_DB * GPK_DB);
+        z[tid] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (prof) prof[13] = (long long)__builtin_readcyclecounter();
 }
 
 long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
-int g_diag_v2 = 0;                  // tuning knob (gpk_tune(30, v)): 1 = potrf_diag2_kernel (pipelined; measured SLOWER, see profiles/r03_experiments.md), 0 = potrf_diag_kernel
+int g_diag_v2 = 1;                  // tuning knob (gpk_tune(30, v)): 1 = potrf_diag3_kernel (512 threads, panel factorisation), 0 = potrf_diag_kernel
+
+template <typename T>
+void launch_diag(const DiagArgs<T>& d, unsigned batch, hipStream_t stream) {
+    if (g_diag_v2)
+        hipLaunchKernelGGL((potrf_diag3_kernel<T>), dim3(batch), dim3(D3_THREADS), 0, stream, d);
+    else
+        hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(batch), dim3(256), 0, stream, d);
+}
 
 template <typename T>
 struct PanelCtx {
@@ -896,10 +777,8 @@ int potrf_panel(const PanelCtx<T>& x, int64_t c0, int64_t w) {
         d.A = x.A; d.ld = x.ld; d.bstride = x.bstride; d.off = c0; d.n = (int)x.n;
         d.dinv = x.dinv; d.dinv_bstride = x.dstride; d.info = x.info; d.info_base = x.info_base;
         d.prof = g_diag_prof;
-        if (g_diag_v2)
-            hipLaunchKernelGGL((potrf_diag2_kernel<T>), dim3((unsigned)x.batch), dim3(256), 0, x.stream, d);
-        else
-            hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3((unsigned)x.batch), dim3(256), 0, x.stream, d);
+        d.zero_next = 0;
+        launch_diag<T>(d, (unsigned)x.batch, x.stream);
         GPK_CHECK_LAUNCH();
         const int64_t r1 = c0 + GPK_DB;   // first row below the diagonal block
         if (r1 >= x.n) return GPK_OK;
@@ -921,6 +800,40 @@ int potrf_panel(const PanelCtx<T>& x, int64_t c0, int64_t w) {
                             T(1), x.A + cm * x.ld + cm, x.ld, x.bstride, x.batch, true, x.stream);
     if (st) return st;
     return potrf_panel<T>(x, cm, h);
+}
+
+// The same panel, columns [c0, c0 + w), for ONE matrix with the fused step kernel: per 128 columns the diagonal-block kernel and
+// ONE launch that solves the rows below it and applies the rank-128 update to the rest of the panel (gpk_panel_step_launch) --
+// two dependent launches per step instead of three, finer strips, no recursion (the rank-128 updates stay inside the panel: at
+// most w - 128 columns wide; everything right of the panel waits for the caller's rank-w update as before).  The flag words of
+// step c live in the slot of diagonal block c / 128 + 1 of `dinv`, which nothing else touches until that block is factorised;
+// the diagonal-block kernel of step c clears them.
+template <typename T>
+int potrf_panel_fused(const PanelCtx<T>& x, int64_t c0, int64_t w) {
+    const int64_t ke = (c0 + w < x.n) ? c0 + w : x.n;
+    for (int64_t c = c0; c < ke; c += GPK_DB) {
+        const bool below = c + GPK_DB < x.n;
+        DiagArgs<T> d;
+        d.A = x.A; d.ld = x.ld; d.bstride = x.bstride; d.off = c; d.n = (int)x.n;
+        d.dinv = x.dinv; d.dinv_bstride = x.dstride; d.info = x.info; d.info_base = x.info_base;
+        d.prof = g_diag_prof;
+        d.zero_next = below ? 1 : 0;
+        launch_diag<T>(d, 1u, x.stream);
+        GPK_CHECK_LAUNCH();
+        if (!below) break;
+        T* Wc = x.dinv + (c / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
+        const int st = gpk_panel_step_launch<T>(x.A, x.n, x.ld, c, Wc, ke, reinterpret_cast<unsigned*>(Wc + (int64_t)GPK_DB * GPK_DB), x.stream);
+        if (st) return st;
+    }
+    return GPK_OK;
+}
+int g_fused_step = 1;              // tuning knob (gpk_tune(32, v)): single matrices take potrf_panel_fused
+
+template <typename T>
+int potrf_panel_any(const PanelCtx<T>& x, int64_t c0, int64_t w) {
+    // the flag words of a step (one per strip of 32 rows below it, 1024 at most) need the dinv slot of the next block: n < 32768
+    if (g_fused_step && x.batch == 1 && x.dinv != nullptr && x.n - c0 <= 32768) return potrf_panel_fused<T>(x, c0, w);
+    return potrf_panel<T>(x, c0, w);
 }
 
 }  // namespace
@@ -945,7 +858,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream, info_base};
     for (int64_t k0 = 0; k0 < n; k0 += nbo) {
         const int64_t k1 = (k0 + nbo < n) ? k0 + nbo : n;
-        int pst = potrf_panel<T>(ctx, k0, nbo);
+        int pst = potrf_panel_any<T>(ctx, k0, nbo);
         if (pst) return pst;
         if (k1 < n) {
             const T* P = A + k1 * ld + k0;
@@ -1026,7 +939,7 @@ int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tm
     T* Ab = A + k0 * ld + k0;
     T* d128 = dinv128 + (k0 / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
     PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0};
-    int st = potrf_panel<T>(sub, 0, nb);
+    int st = potrf_panel_any<T>(sub, 0, nb);
     if (st) return st;
     return gpk_trtri_merge_launch<T>(Ab, w, ld, 1, 0, d128, nb, dinv_big + j * (int64_t)nb * nb, tmp, s);
 }
@@ -1059,6 +972,7 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 18) g_la_rejoin = (int)value;
     if (key == 11) g_la_strip_last = (int)value;
     if (key == 30) g_diag_v2 = (int)value;
+    if (key == 32) g_fused_step = (int)value;
 }
 
 #define GPK_LA_PAD 16

@@ -391,33 +391,69 @@ int gpk_trtri_merge_launch(const T* L, int64_t n, int64_t ld, int64_t batch, int
 }
 
 // ---------------------------------------------------------------------------
-// B <- L^{-1} B, many right-hand sides (GEMM sweep)
-//   dinv_sb: [batch][nsb][sb][sb];  tmp: [batch][sb][nrhs]
+// X = L^{-1} B, many right-hand sides: RECURSIVE blocked solve over the sb-blocks of L.
+//   solve(q0, q1):  one block:  X_q = inv(L_qq) B_q                       (GEMM with the merged inverse, k clipped to its triangle)
+//                   else:       solve(q0, m);  B[m:q1] -= L[m:q1, q0:m] X[q0:m]  (ONE GEMM, K = all of q0..m);  solve(m, q1)
+// Against the right-looking sweep (one update of everything below per block, K = sb) the flops are the same, but half of them
+// sit in a single GEMM with K = n/2 and a quarter in two with K = n/4: every C tile is read and written log2(n/sb) times instead of
+// n/sb times, launches have exact tile counts more often (cfg2: 8192 x 2048 x 8192 = exactly two rounds of 128-tiles; the sweep's
+// 1664-tile updates paid 4 rounds for 3.25), and the long k loops run at the large-K rate of the tile kernel.
+//   dinv_sb: [batch][nsb][sb][sb].
+//   X == nullptr: in place -- B is overwritten with the solution; tmp: [batch][sb][nrhs] (a solved block is formed there, then copied).
+//   X != nullptr: out of place -- solved blocks go to X ([batch] n x nrhs, ldx, stride sX), B is used up as workspace; no copies.
 // ---------------------------------------------------------------------------
+namespace {
+template <typename T>
+struct TrsmCtx {
+    const T* L; int64_t n, ld, sL;
+    const T* dinv; int sb; int64_t per, ssb;
+    T* B; int64_t nrhs, ldb, sB;
+    T* X; int64_t ldx, sX;         // where solved blocks live (== B, ldb, sB in place)
+    T* tmp; int64_t st_tmp;
+    int64_t batch; hipStream_t stream;
+};
+template <typename T>
+int trsm_rec(const TrsmCtx<T>& c, int q0, int q1) {
+    const int64_t r0 = (int64_t)q0 * c.sb;
+    if (q1 - q0 == 1) {
+        const int64_t rq = (c.n - r0 < c.sb) ? c.n - r0 : c.sb;
+        const bool inplace = (c.X == c.B);
+        T* dst = inplace ? c.tmp : c.X + r0 * c.ldx;
+        int st = gpk_gemm_launch<T>(true, false, rq, c.nrhs, rq, T(1), c.dinv + q0 * c.per, c.sb, c.ssb, c.B + r0 * c.ldb, c.ldb, c.sB, T(0),
+                                    dst, inplace ? c.nrhs : c.ldx, inplace ? c.st_tmp : c.sX, c.batch, 4, c.stream);   // inv(L_qq) is lower triangular
+        if (st || !inplace) return st;
+        return gpk_copy2d_launch<T>(c.tmp, c.nrhs, c.st_tmp, c.B + r0 * c.ldb, c.ldb, c.sB, rq, c.nrhs, c.batch, c.stream);
+    }
+    int h = 1;                                   // split at the largest power of two below the count: the big GEMMs get power-of-two K
+    while (2 * h < q1 - q0) h *= 2;
+    const int m = q0 + h;
+    int st = trsm_rec<T>(c, q0, m);
+    if (st) return st;
+    const int64_t rm = (int64_t)m * c.sb;
+    const int64_t r1 = ((int64_t)q1 * c.sb < c.n) ? (int64_t)q1 * c.sb : c.n;
+    st = gpk_gemm_launch<T>(true, false, r1 - rm, c.nrhs, rm - r0, T(-1), c.L + rm * c.ld + r0, c.ld, c.sL, c.X + r0 * c.ldx, c.ldx, c.sX, T(1),
+                            c.B + rm * c.ldb, c.ldb, c.sB, c.batch, 0, c.stream);
+    if (st) return st;
+    return trsm_rec<T>(c, m, q1);
+}
+}  // namespace
+
 template <typename T>
 int gpk_trsm_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv_sb, int sb, T* B,
-                    int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream) {
+                    int64_t nrhs, int64_t ldb, int64_t sB, T* tmp, int64_t batch, hipStream_t stream, T* X, int64_t ldx, int64_t sX) {
     if (n <= 0 || nrhs <= 0 || batch <= 0) return GPK_OK;
     if (!gpk_valid_sb(sb)) return GPK_ERR_ARG(6);
+    if (X == nullptr && tmp == nullptr) return GPK_ERR_ARG(11);
+    if (X != nullptr && ldx < nrhs) return GPK_ERR_ARG(15);
     const int nsb = (int)gpk_cdiv(n, sb);
-    const int64_t per = (int64_t)sb * sb, ssb = (int64_t)nsb * per;
-    const int64_t st_tmp = (int64_t)sb * nrhs;
-    for (int q = 0; q < nsb; ++q) {
-        const int64_t r0 = (int64_t)q * sb;
-        const int64_t rq = (n - r0 < sb) ? n - r0 : sb;
-        int st = gpk_gemm_launch<T>(true, false, rq, nrhs, rq, T(1), dinv_sb + q * per, sb, ssb,
-                                    B + r0 * ldb, ldb, sB, T(0), tmp, nrhs, st_tmp, batch, 4, stream);   // inv(L_qq) is lower triangular
-        if (st) return st;
-        st = gpk_copy2d_launch<T>(tmp, nrhs, st_tmp, B + r0 * ldb, ldb, sB, rq, nrhs, batch, stream);
-        if (st) return st;
-        const int64_t r1 = r0 + rq;
-        if (r1 < n) {
-            st = gpk_gemm_launch<T>(true, false, n - r1, nrhs, rq, T(-1), L + r1 * ld + r0, ld, sL, tmp,
-                                    nrhs, st_tmp, T(1), B + r1 * ldb, ldb, sB, batch, false, stream);
-            if (st) return st;
-        }
-    }
-    return GPK_OK;
+    TrsmCtx<T> c;
+    c.L = L; c.n = n; c.ld = ld; c.sL = sL;
+    c.dinv = dinv_sb; c.sb = sb; c.per = (int64_t)sb * sb; c.ssb = (int64_t)nsb * c.per;
+    c.B = B; c.nrhs = nrhs; c.ldb = ldb; c.sB = sB;
+    c.X = X ? X : B; c.ldx = X ? ldx : ldb; c.sX = X ? sX : sB;
+    c.tmp = tmp; c.st_tmp = (int64_t)sb * nrhs;
+    c.batch = batch; c.stream = stream;
+    return trsm_rec<T>(c, 0, nsb);
 }
 
 // ---------------------------------------------------------------------------
@@ -506,7 +542,7 @@ int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb
     template int gpk_trtri_merge_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,  \
                                            int, T*, T*, hipStream_t);                               \
     template int gpk_trsm_launch<T>(const T*, int64_t, int64_t, int64_t, const T*, int, T*, int64_t, \
-                                    int64_t, int64_t, T*, int64_t, hipStream_t);                    \
+                                    int64_t, int64_t, T*, int64_t, hipStream_t, T*, int64_t, int64_t); \
     template int gpk_trsv_launch<T>(const T*, int64_t, int64_t, int64_t, const T*, int, T*, int,    \
                                     int64_t, int64_t, T*, int64_t, hipStream_t);
 GPK_INST(double)

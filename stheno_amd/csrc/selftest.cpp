@@ -200,6 +200,11 @@ static void test_gemm() {
     test_gemm_case<T>(true, false, 4224, 4224, 32, 1, 0, 1, false, 0);   // 33x33 tiles, rectangular super-tiles
     test_gemm_case<T>(true, false, 300, 3000, 40, 1, 1, 1, false, 1);    // many more tile columns than rows: column-major tile order
     test_gemm_case<T>(true, true, 260, 2100, 33, -1, 0, 2, false, 0);
+    // more than one round of 128-tiles with a short last round: its tiles run as 64 x 64 quarters (ragged edges, both operand layouts)
+    test_gemm_case<T>(true, true, 4100, 4100, 70, -1, 1, 1, true, 1);
+    test_gemm_case<T>(false, false, 3000, 3100, 50, 1, 1, 1, false, 1);
+    test_gemm_case<T>(true, false, 4100, 4100, 40, -1, 1, 1, true, 0);
+    test_gemm_case<T>(false, true, 3072, 3328, 48, 1, 0, 1, false, 0);
 }
 
 // ----------------------------------------------------------------------------
@@ -407,6 +412,26 @@ static void test_potrf_case(int n, int batch, int nbo, int nrhs_small, int nrhs_
         }
         snprintf(nm, sizeof nm, "%s_%s n%d nrhs%d sb%d batch%d st%d/%d", pass == 0 ? "trsv" : "trsm", DT<T>::name(), n, nrhs, sb, batch, s3, s4);
         report(nm, (s3 || s4) ? INFINITY : nu / de2, DT<T>::eps * 1000);
+        if (pass == 1) {   // the same solve out of place: the solution goes to a second buffer (its own leading dimension), b is workspace
+            const int64_t ldx = nrhs + 1;
+            Dev<T> dX((size_t)batch * n * ldx);
+            dX.up(std::vector<T>((size_t)batch * n * ldx, T(7)));
+            dB.up(Bm);
+            const int s5 = gpk_trsm_lower_to(DT<T>::v, dA.p, n, ld, sA, dsb.p, sb, dB.p, nrhs, ldb, (int64_t)n * ldb, dX.p, ldx, (int64_t)n * ldx, batch, nullptr);
+            HIPCHK(hipDeviceSynchronize());
+            auto gx = dX.down();
+            double nu2 = 0;
+            for (int b = 0; b < batch; ++b) for (int i = 0; i < n; ++i) {
+                for (int c = 0; c < nrhs; ++c) {
+                    const double g = (double)gx[((size_t)b * n + i) * ldx + c];
+                    if (!std::isfinite(g)) nu2 = INFINITY;
+                    nu2 = std::max(nu2, std::fabs(g - ref[((size_t)b * n + i) * ldb + c]));
+                }
+                if ((double)gx[((size_t)b * n + i) * ldx + nrhs] != 7.0) nu2 = INFINITY;      // the padding column of x is not touched
+            }
+            snprintf(nm, sizeof nm, "trsm_to_%s n%d nrhs%d sb%d batch%d st%d", DT<T>::name(), n, nrhs, sb, batch, s5);
+            report(nm, s5 ? INFINITY : nu2 / de2, DT<T>::eps * 1000);
+        }
     }
 }
 template <typename T>
@@ -1457,26 +1482,55 @@ static void cumask_experiment() {
 }
 
 template <typename T>
-static void diag_phase_profile(int n, bool v2) {
+static void diag_phase_profile(int n, int ver) {
     const int nblk = (n + 127) / 128;
     Dev<long long> prof((size_t)nblk * 32);
     prof.zero();
-    gpk_tune(30, v2 ? 1 : 0);
+    gpk_tune(30, ver);
     gpk_tune_diag_prof(prof.p);
     profile_one<T>(n, 0, 1);
     gpk_tune_diag_prof(nullptr);
     auto h = prof.down();
     for (int blk : {0, nblk / 2, nblk - 1}) {
-        if (!v2) {
+        if (ver == 0) {
             const long long* q = &h[(size_t)blk * 16];
             printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld [trsm %lld  c1 %lld  chol(wave0) %lld]  storeL %lld  invert %lld [16x16 %lld]  storeW %lld  total %lld\n",
                    DT<T>::name(), blk, q[1] - q[0], q[2] - q[1], q[8], q[9], q[10], q[3] - q[2], q[4] - q[3], q[6] - q[3], q[5] - q[4], q[5] - q[0]);
         } else {
             const long long* q = &h[(size_t)blk * 32];
-            printf("DIAGPROF2 %s blk %d cycles: load %lld | phases", DT<T>::name(), blk, q[1] - q[0]);
-            for (int ph = 0; ph < 18; ++ph) printf(" %lld", q[2 + ph] - q[1 + ph]);
-            printf(" | storeW %lld | total %lld\n", q[20] - q[19], q[20] - q[0]);
+            printf("DIAGPROF3 %s blk %d cycles: load %lld | panel0 %lld | steps", DT<T>::name(), blk, q[1] - q[0], q[2] - q[1]);
+            for (int s = 0; s < 7; ++s) printf(" %lld", q[3 + s] - q[2 + s]);
+            printf(" | storeL %lld | inv16 %lld | merges %lld | storeW %lld | total %lld\n", q[10] - q[9], q[11] - q[10], q[12] - q[11], q[13] - q[12], q[13] - q[0]);
         }
+    }
+}
+
+// --perf-trsm: the 2048-column solve of the posterior path at N = 16384 (cfg2) / 32768 fp32 (cfg3), in place and out of place
+template <typename T>
+static void perf_trsm(int n, int nrhs) {
+    auto hx = randv<T>((size_t)n * 8);
+    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n)), Bm((size_t)n * nrhs), Xo((size_t)n * nrhs);
+    Dev<int> info(1);
+    X.up(hx);
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    info.zero();
+    gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, 8, 0, X.p, n, 8, 0, 8, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+    gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, 0, nullptr);
+    auto hb = randv<T>((size_t)n * nrhs);
+    Timer tm;
+    for (int sb : {512, 1024, 2048}) {
+        Dev<T> dsb((size_t)((n + sb - 1) / sb) * sb * sb), tmpm((size_t)((n + sb - 1) / sb) * sb * sb / 4 + 16), tmp((size_t)sb * nrhs);
+        gpk_trtri_merge(DT<T>::v, K.p, n, n, 0, 1, dinv.p, sb, dsb.p, tmpm.p, nullptr);
+        for (int oop = 0; oop < 2; ++oop)
+            for (int rep = 0; rep < 3; ++rep) {
+                Bm.up(hb);
+                tm.start();
+                if (oop) gpk_trsm_lower_to(DT<T>::v, K.p, n, n, 0, dsb.p, sb, Bm.p, nrhs, nrhs, 0, Xo.p, nrhs, 0, 1, nullptr);
+                else gpk_trsm_lower(DT<T>::v, K.p, n, n, 0, dsb.p, sb, Bm.p, nrhs, nrhs, 0, tmp.p, 1, nullptr);
+                const float ms = tm.stop();
+                if (rep) printf("PERFTRSM %s n=%d nrhs=%d sb=%d %s  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), n, nrhs, sb, oop ? "out-of-place" : "in-place    ", ms,
+                                (double)n * n * nrhs / ms * 1e-9);
+            }
     }
 }
 
@@ -1514,9 +1568,9 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
             rsq_precision();
-            for (int v2 = 0; v2 < 2; ++v2) {
-                diag_phase_profile<double>(atoi(argv[i + 1]), v2 != 0);
-                diag_phase_profile<float>(atoi(argv[i + 1]), v2 != 0);
+            for (int ver = 0; ver < 2; ++ver) {
+                diag_phase_profile<double>(atoi(argv[i + 1]), ver);
+                diag_phase_profile<float>(atoi(argv[i + 1]), ver);
             }
             return 0;
         }
@@ -1534,6 +1588,7 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--census")) { census(); return 0; }
         if (!strcmp(argv[i], "--perf-kmat")) { perf_kmat(); return 0; }
+        if (!strcmp(argv[i], "--perf-trsm")) { perf_trsm<double>(16384, 2048); perf_trsm<float>(32768, 2048); return 0; }
         if (!strcmp(argv[i], "--kmat")) {                      // only the kernel-matrix checks, both kernels
             for (int band = 1; band >= 0; --band) { gpk_tune(12, band); test_kmat<double>(); test_kmat<float>(); }
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);

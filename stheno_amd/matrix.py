@@ -33,7 +33,11 @@ class _Config:
     #: its outer block = the order of the explicitly inverted diagonal blocks: 512 below `potrf_lookahead_wide_from`, else the
     #: per-dtype value (measured on MI355X, fp64 / fp32 alike: N = 8192: 6.95 ms at 512, 7.42 at 1024, 7.33 plain;
     #: N = 12288: 15.1 / 15.6 / 16.8; N = 14336: 21.5 / 21.2 / 23.7; N = 16384: 29.8 / 28.7 / 32.6)
-    potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 1024}
+    #: fp32 stays at 512-blocks at every order: the rows below a diagonal block are multiplied by its EXPLICIT inverse, and in fp32 the
+    #: posterior mean pays for the width of that inverse -- cfg3 at its full N = 32768 against fp64 on the device: mean error
+    #: 1.00e-3 with 1024-blocks, 7.3e-4 with 512-blocks (6.2e-4 with 256-block solves on top), 1.6e-3 with 2048; 3 % slower
+    #: (scripts/dev_fp32_fullsize_accuracy.py).  north_star's fp32 bar is 1e-3.
+    potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 512}
     potrf_lookahead_wide_from = 14336
 
 
@@ -46,7 +50,8 @@ def _solve_block(n, nrhs, fp64=True):
     launch-latency-bound (512-blocks); the many-right-hand-side sweep runs on the MFMA GEMM, where
     bigger blocks mean fewer, better-filled launches (fp64: 1024 from n = 8192, 2048 from n = 32768;
     in fp32 the posterior mean loses accuracy with the block size -- 3e-4 / 6e-4 / 1.1e-3 / 2.4e-3 relative
-    at 128 / 512 / 1024 / 2048 for cfg3's kernel at N = 8192 -- so fp32 stays at 512); with far more
+    at 128 / 512 / 1024 / 2048 for cfg3's kernel at N = 8192, and at its full N = 32768 7.3e-4 / 6.2e-4 with 512 / 256 -- so fp32
+    takes 256 for the many-column solve); with far more
     right-hand sides than unknowns (pseudo-point path: M x N with N >> M; accuracy measured insensitive
     to the block size there) the whole factor is inverted once (M^3/3 flops) and the solve is ONE
     triangular GEMM."""
@@ -56,10 +61,11 @@ def _solve_block(n, nrhs, fp64=True):
         return 2048
     if fp64 and n >= 8192:
         return 1024
-    if n >= 2048:
-        return 512
+    if n >= 2048 and (fp64 or nrhs <= 8):
+        return 512       # (fp32: the single-column sweep of logpdf keeps the 512-blocks the look-ahead leaves behind)
     if n >= 512:
-        return 256
+        return 256       # fp32 with many right-hand sides at every order: accuracy of the posterior mean (config.potrf_lookahead_nb;
+                         # the recursive solve makes small blocks cheap)
     return 128
 
 

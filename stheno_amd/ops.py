@@ -259,7 +259,8 @@ class HipBackend:
 
     @_on_operand_device
     def tri_solve_(self, l, dinv_sb, sb, b):
-        """``b <- L^{-1} b`` in place; ``b`` is (..., n, nrhs) with unit inner stride."""
+        """``L^{-1} b``; ``b`` is (..., n, nrhs) with unit inner stride and is OVERWRITTEN (with the solution for up to 8 columns,
+        with intermediate values otherwise): use the return value."""
         l3, _ = _as3(l)
         b3, _ = _as3(b)
         if b3.data_ptr() != b.data_ptr():
@@ -271,16 +272,20 @@ class HipBackend:
             raise ValueError("right-hand side does not match the factor")
         if n == 0 or nrhs == 0:
             return b
-        tmp = torch.empty((B, sb, nrhs), dtype=b.dtype, device=b.device)
         if nrhs <= 8:
+            tmp = torch.empty((B, sb, nrhs), dtype=b.dtype, device=b.device)
             code = self.lib.gpk_trsv_lower(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), self._ptr(dinv_sb), sb,
                                            self._ptr(b3), nrhs, _ld(b3), _bs(b3), self._ptr(tmp), B, self._stream())
             self._st(code, "gpk_trsv_lower")
-        else:
-            code = self.lib.gpk_trsm_lower(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), self._ptr(dinv_sb), sb,
-                                           self._ptr(b3), nrhs, _ld(b3), _bs(b3), self._ptr(tmp), B, self._stream())
-            self._st(code, "gpk_trsm_lower")
-        return b
+            return b
+        # many right-hand sides: the recursive blocked solve, out of place -- solved blocks go to a second buffer (no copy per
+        # block), `b` is used up as workspace; the caller takes the return value (Chol.solve_)
+        x = torch.empty(b.shape, dtype=b.dtype, device=b.device)
+        x3, _ = _as3(x)
+        code = self.lib.gpk_trsm_lower_to(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), self._ptr(dinv_sb), sb,
+                                          self._ptr(b3), nrhs, _ld(b3), _bs(b3), self._ptr(x3), _ld(x3), _bs(x3), B, self._stream())
+        self._st(code, "gpk_trsm_lower_to")
+        return x
 
     # -- products ------------------------------------------------------------
     @_on_operand_device

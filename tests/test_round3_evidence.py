@@ -115,9 +115,12 @@ def test_config3_full_size_residuals_and_fp64_on_device():
 
 
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 14336), (torch.float32, 14464)])
-def test_lookahead_1024_blocks_against_lapack(dtype, n):
-    """``Chol.factor_`` at an order that takes the 1024-block look-ahead path, against ``np.linalg.cholesky`` (LAPACK on the host)."""
+def test_lookahead_wide_blocks_against_lapack(dtype, n):
+    """``Chol.factor_`` at an order that takes the look-ahead path with the block width the headline configurations run -- 1024 in
+    fp64 (cfg2), 512 in fp32 (cfg3: accuracy, ``matrix.config.potrf_lookahead_nb``) -- against ``np.linalg.cholesky`` (LAPACK, host)."""
     assert n >= matrix.config.potrf_lookahead_wide_from
+    nb = matrix.config.potrf_lookahead_nb[dtype]
+    assert nb == (1024 if dtype == torch.float64 else 512)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(n, 8, generator=g, dtype=torch.float64).to(dtype).to(DEV)
     k = st.EQ()
@@ -125,17 +128,17 @@ def test_lookahead_1024_blocks_against_lapack(dtype, n):
     a.diagonal().add_(NOISE)
     ref = np.linalg.cholesky(a.double().cpu().numpy())
     chol = matrix.Chol.factor_(a.clone())
-    assert chol.lookahead_nb == 1024            # the 1024-block look-ahead path ran
+    assert chol.lookahead_nb == nb              # the look-ahead path ran, with that block width
     L = chol.lower().double().cpu().numpy()
     err = np.max(np.abs(L - ref)) / np.max(np.abs(ref))
     assert err < (1e-11 if dtype == torch.float64 else 2e-4), err
-    # the 1024-block inverses the look-ahead leaves behind are the inverses of L's diagonal blocks
+    # the block inverses the look-ahead leaves behind are the inverses of L's diagonal blocks
     be = ops.get_backend()
-    _, info, dnb = be.potrf_(a.clone(), 0, lookahead_nb=1024)
+    _, info, dnb = be.potrf_(a.clone(), 0, lookahead_nb=nb)
     assert int(info.max()) == 0
     w1 = dnb[0, 1].double().cpu().numpy()
-    blk = ref[1024:2048, 1024:2048]
-    assert np.max(np.abs(w1 @ blk - np.eye(1024))) < (1e-9 if dtype == torch.float64 else 5e-3)
+    blk = ref[nb:2 * nb, nb:2 * nb]
+    assert np.max(np.abs(w1 @ blk - np.eye(nb))) < (1e-9 if dtype == torch.float64 else 5e-3)
 
 
 def test_native_selftest_binary_reports_no_failure():
