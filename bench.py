@@ -124,7 +124,7 @@ def pmc_traffic(name, w, kernel):
     figure is read from ``profiles/``; ``None`` if no pass exists for this workload / kernel."""
     if w["n"] != WORKLOADS[name]["n"]:
         return None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
         if os.path.exists(path):
             with open(path) as f:

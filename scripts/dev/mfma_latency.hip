@@ -59,6 +59,26 @@ __global__ __launch_bounds__(256, 1) void kacc(double* out, long long* cyc, int 
     out[threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[slot] = t1 - t0;
 }
+// NW waves per SIMD (256 * NW threads), NACC independent accumulators each: aggregate issue rate of the matrix pipe
+template <int NW, int NACC>
+__global__ __launch_bounds__(256 * NW, NW) void kwaves(double* out, long long* cyc, int n, int slot) {
+    const int lane = threadIdx.x & 63;
+    f64x4 c[NACC];
+    for (int q = 0; q < NACC; ++q) c[q] = f64x4{1.0 + q, 0.5, 0.25, 0.125};
+    const double a = 1e-3 * lane, b = 1e-3;
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) c[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[q], 0, 0, 0);
+    }
+    __syncthreads();
+    const long long t1 = __builtin_readcyclecounter();
+    double s = 0;
+    for (int q = 0; q < NACC; ++q) s += c[q][0] + c[q][3];
+    out[threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[slot] = t1 - t0;
+}
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k32(float* out, long long* cyc, int n) {
     const int lane = threadIdx.x & 63;
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(256, 1) void k32(float* out, long long* cyc, int n)
 }
 int main() {
     double* o; float* of; long long* c;
-    hipMalloc(&o, 4096); hipMalloc(&of, 4096); hipMalloc(&c, 32 * 8); hipMemset(c, 0, 256);
+    hipMalloc(&o, 16384); hipMalloc(&of, 4096); hipMalloc(&c, 32 * 8); hipMemset(c, 0, 256);
     const int n = 2000;
     for (int rep = 0; rep < 2; ++rep) {
         hipLaunchKernelGGL(k64<0>, dim3(1), dim3(256), 0, 0, o, c, n);
@@ -97,10 +117,21 @@ int main() {
         hipLaunchKernelGGL((kacc<16, false>), dim3(1), dim3(256), 0, 0, o, c, n, 21);
         hipLaunchKernelGGL((kacc<4, true>), dim3(1), dim3(256), 0, 0, o, c, n, 22);
         hipLaunchKernelGGL((kacc<16, true>), dim3(1), dim3(256), 0, 0, o, c, n, 23);
+        hipLaunchKernelGGL((kwaves<1, 8>), dim3(1), dim3(256), 0, 0, o, c, n, 24);
+        hipLaunchKernelGGL((kwaves<2, 8>), dim3(1), dim3(512), 0, 0, o, c, n, 25);
+        hipLaunchKernelGGL((kwaves<3, 8>), dim3(1), dim3(768), 0, 0, o, c, n, 26);
+        hipLaunchKernelGGL((kwaves<4, 8>), dim3(1), dim3(1024), 0, 0, o, c, n, 27);
+        hipLaunchKernelGGL((kwaves<4, 4>), dim3(1), dim3(1024), 0, 0, o, c, n, 28);
+        hipLaunchKernelGGL((kwaves<2, 16>), dim3(1), dim3(512), 0, 0, o, c, n, 29);
         hipDeviceSynchronize();
     }
     long long h[32];
     hipMemcpy(h, c, 256, hipMemcpyDeviceToHost);
+    {
+        const int nw[] = {1, 2, 3, 4, 4, 2}, na[] = {8, 8, 8, 8, 4, 16};
+        for (int i = 0; i < 6; ++i)
+            printf("LAT f64 %d waves per SIMD x %2d accumulators: %6.1f cycles per MFMA per SIMD (pipe: 64)\n", nw[i], na[i], (double)h[24 + i] / n / na[i] / nw[i]);
+    }
     const int nacc[] = {1, 2, 3, 4, 8, 16, 4, 16};
     for (int i = 0; i < 8; ++i)
         printf("LAT f64 %2d independent accumulators, %s: %7.1f cycles per MFMA\n", nacc[i], i < 6 ? "4 waves (one per SIMD)" : "ONE wave on the CU     ", (double)h[16 + i] / n / nacc[i]);
