@@ -16,7 +16,7 @@ timeout 200 ./gpk_selftest --diagprof 2048 > $O/r03_diag_kernel_phases.log 2>&1
 ( cd $R/scripts/dev && timeout 60 ./mfma_latency ) > $O/r03_mfma_latency.log 2>&1
 cd /tmp
 for w in dense_f64 sum_f32 batched_f32 sparse_f32; do
-  timeout 400 python $R/bench.py --workload $w 2>/dev/null | tail -1 > $O/r03_bench_$w.json
+  timeout 400 python $R/bench.py --workload $w 2>/dev/null | grep "^{" | tail -1 > $O/r03_bench_$w.json
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -o s -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $O/stats_$w.log 2>&1
   F=$(find $O/stats_$w -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp $F $O/r03_bench_${w}_kernel_stats.csv
   if [ "$w" = dense_f64 ]; then
@@ -25,5 +25,5 @@ for w in dense_f64 sum_f32 batched_f32 sparse_f32; do
   rm -rf $O/stats_$w
   timeout 600 python $R/scripts/collect_pmc.py $w $O/r03_pmc_$w.json > $O/r03_pmc_$w.log 2>&1
 done
-GPK_BENCH_FORCE_DIST=1 NCCL_DEBUG=WARN MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python $R/bench.py --workload batched_f32 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r03_bench_batched_f32_rccl_1rank.json
+GPK_BENCH_FORCE_DIST=1 NCCL_DEBUG=WARN MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python $R/bench.py --workload batched_f32 --no-cpu-baseline 2>/dev/null | grep "^{" | tail -1 > $O/r03_bench_batched_f32_rccl_1rank.json
 ls -la $O | head -50

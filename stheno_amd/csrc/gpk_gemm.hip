@@ -145,16 +145,16 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
 // ---- global -> registers ---------------------------------------------------
 // `fast`: (EDGE kernels only) this tile's rows and this k-chunk lie fully inside the operand and
 // 16-byte loads are legal -- interior tiles of a ragged problem take the vector path too.
-template <typename T, int TS, bool KMAJ, bool EDGE>
-__device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], const T* __restrict__ base,
+template <typename T, int TS, bool KMAJ, bool EDGE, int NT = 256>
+__device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS * 8 / NT], const T* __restrict__ base,
                                       int64_t ld, int r0, int k0, int R, int K, int tid, bool fast) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
     if (KMAJ) {
         const int c = tid & 7, rr0 = tid >> 3;
 #pragma unroll
-        for (int i = 0; i < TS / 32; ++i) {
-            const int row = r0 + rr0 + 32 * i;
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int row = r0 + rr0 + (NT / 8) * i;
             const int k = k0 + c * VEC;
             const T* p = base + (int64_t)row * ld + k;
             if (!EDGE || fast) {
@@ -167,8 +167,8 @@ __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], c
     } else {
         constexpr int CPR = TS / VEC;   // 16-byte chunks per k-row
 #pragma unroll
-        for (int i = 0; i < TS / 32; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int id = tid + NT * i;
             const int krow = id / CPR, cc = id % CPR;
             const int k = k0 + krow;
             const int row = r0 + cc * VEC;
@@ -184,23 +184,23 @@ __device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS / 32], c
 }
 
 // ---- registers -> LDS --------------------------------------------------------
-template <typename T, int TS, bool KMAJ>
-__device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_t (&r)[TS / 32], int tid) {
+template <typename T, int TS, bool KMAJ, int NT = 256>
+__device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_t (&r)[TS * 8 / NT], int tid) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
     if (KMAJ) {
         const int c = tid & 7, rr0 = tid >> 3;
 #pragma unroll
-        for (int i = 0; i < TS / 32; ++i) {
-            const int rr = rr0 + 32 * i;
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int rr = rr0 + (NT / 8) * i;
             const int off = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4);
             *reinterpret_cast<vec_t*>(lds + off) = r[i];
         }
     } else {
         constexpr int CPR = TS / VEC;
 #pragma unroll
-        for (int i = 0; i < TS / 32; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int id = tid + NT * i;
             const int krow = id / CPR, cc = id % CPR;
             const int off = krow * ((TS + 16) * (int)sizeof(T)) + cc * 16;
             *reinterpret_cast<vec_t*>(lds + off) = r[i];
@@ -228,15 +228,24 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // One output tile (ti, tj) of one problem, computed by the calling workgroup (256 threads).  `smem`:
 // 2 * (1 + NCT) * op_bytes(TS) bytes of LDS, free on entry; every wave has passed a barrier after its
 // last LDS read when the function returns.
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT>
+// NW: waves of the workgroup, as an (NW / 2) x 2 grid over the tile.  NW = 4 (256 threads): 64 x 64 of a 128-tile per wave -- what
+// every kernel of this file instantiates.  NW = 8 (512 threads, 32 x 64 per wave, two workgroups = FOUR waves per SIMD) was built
+// and measured in round 3 on the hypothesis that two waves per SIMD starve the matrix pipe whenever one of them waits: same
+// results, 2-4 % SLOWER (fp64 8192^3 68.6 vs 71.4 TFLOP/s, trailing update 59.6 vs 60.8, POTRF N = 16384 28.6 vs 28.1 ms); the
+// kernels were removed, the parameter stays.
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
                                           long long* prof = nullptr) {
     if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
-    constexpr int FR = TS / 32;          // 16x16 fragments per wave in each direction
-    constexpr int WT = TS / 2;           // wave sub-tile edge
+    constexpr int NT = 64 * NW;          // threads
+    constexpr int NV = TS * 8 / NT;      // 16-byte vectors a thread moves per operand tile and k-chunk
+    constexpr int FR = TS / 32;          // 16x16 fragments per wave along the columns
+    constexpr int FRM = TS / (8 * NW);   // ... along the rows
+    constexpr int WT = TS / 2;           // wave sub-tile width
+    constexpr int WTM = 16 * FRM;        // ... height
     constexpr int OPB = op_bytes(TS), STAGE = (1 + NCT) * OPB;
 
     const int tid = threadIdx.x;
@@ -253,17 +262,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 
     const int m0 = ti * TS, n0 = tj * TS * NCT;
 
-    acc_t acc[NCT][FR][FR];
+    acc_t acc[NCT][FRM][FR];
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
         if (p.has_beta) {
 #pragma unroll
-            for (int fi = 0; fi < FR; ++fi)
+            for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
                 for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
+                        const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
                         const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
                         T v = T(0);
                         if (!EDGE || (row < p.M && col < p.N)) v = Cin[(int64_t)row * p.ldcin + col];
@@ -271,7 +280,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                     }
         } else {
 #pragma unroll
-            for (int fi = 0; fi < FR; ++fi)
+            for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
                 for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
@@ -288,23 +297,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // (panel / merge / solve), where a workgroup is often alone on its CU: they keep TWO k-chunks of
     // global loads in flight (PF2); the 128-tile kernel hides the latency with its second workgroup.
     constexpr bool PF2 = (TS <= 64);
-    vec_t ra[PF2 ? 2 : 1][FR], rb[PF2 ? 2 : 1][NCT][FR];
+    vec_t ra[PF2 ? 2 : 1][NV], rb[PF2 ? 2 : 1][NCT][NV];
 
     const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS * NCT <= p.N);
     auto issue = [&](auto set_c, int kc) {           // global -> register set `set`
         constexpr int set = decltype(set_c)::value;
         const bool k_in = (kc + 1) * BK <= p.K;
-        gload<T, TS, A_KMAJ, EDGE>(ra[set], A, p.lda, m0, kc * BK, p.M, p.K, tid, a_in && k_in);
+        gload<T, TS, A_KMAJ, EDGE, NT>(ra[set], A, p.lda, m0, kc * BK, p.M, p.K, tid, a_in && k_in);
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
-            gload<T, TS, B_KMAJ, EDGE>(rb[set][c], B, p.ldb, n0 + c * TS, kc * BK, p.N, p.K, tid, b_in && k_in);
+            gload<T, TS, B_KMAJ, EDGE, NT>(rb[set][c], B, p.ldb, n0 + c * TS, kc * BK, p.N, p.K, tid, b_in && k_in);
     };
     auto commit = [&](auto set_c, int stage) {       // register set -> LDS stage
         constexpr int set = decltype(set_c)::value;
         char* dA = smem + stage * STAGE;
-        sstore<T, TS, A_KMAJ>(dA, ra[set], tid);
+        sstore<T, TS, A_KMAJ, NT>(dA, ra[set], tid);
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ>(dA + (1 + c) * OPB, rb[set][c], tid);
+        for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ, NT>(dA + (1 + c) * OPB, rb[set][c], tid);
     };
     auto mma = [&](int stage) {
         // scheduler hint: interleave the LDS reads with the MFMAs of this k-chunk (measured +2 % for fp64,
@@ -322,12 +331,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int pp = 0; pp < BK / 8; ++pp) {
-                f2 a2[FR], b2[NCT][FR];
+                f2 a2[FRM], b2[NCT][FR];
                 const int u = pp * 4 + kq;           // 8-byte unit of the 128-byte row
                 const int uo = (((u >> 1) ^ swz) << 4) + (u & 1) * 8;
 #pragma unroll
+                for (int f = 0; f < FRM; ++f) a2[f] = *reinterpret_cast<const f2*>(sA + (wm * WTM + f * 16 + lr) * 128 + uo);
+#pragma unroll
                 for (int f = 0; f < FR; ++f) {
-                    a2[f] = *reinterpret_cast<const f2*>(sA + (wm * WT + f * 16 + lr) * 128 + uo);
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
                         b2[c][f] = *reinterpret_cast<const f2*>(sB + c * OPB + (wn * WT + f * 16 + lr) * 128 + uo);
@@ -337,7 +347,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                        for (int fi = 0; fi < FR; ++fi)
+                        for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
                             for (int fj = 0; fj < FR; ++fj)
                                 acc[c][fi][fj] = Traits<T>::mfma((T)a2[fi][e], (T)b2[c][fj][e], acc[c][fi][fj]);
@@ -346,11 +356,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            T a[FR], bb[NCT][FR];
+            T a[FRM], bb[NCT][FR];
             const int k = kk * 4 + kq;
 #pragma unroll
+            for (int f = 0; f < FRM; ++f) a[f] = fragread<T, TS, A_KMAJ>(sA, wm * WTM + f * 16, lr, k, swz);
+#pragma unroll
             for (int f = 0; f < FR; ++f) {
-                a[f] = fragread<T, TS, A_KMAJ>(sA, wm * WT + f * 16, lr, k, swz);
 #pragma unroll
                 for (int c = 0; c < NCT; ++c)
                     bb[c][f] = fragread<T, TS, B_KMAJ>(sB + c * OPB, wn * WT + f * 16, lr, k, swz);
@@ -358,7 +369,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                for (int fi = 0; fi < FR; ++fi)
+                for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
                     for (int fj = 0; fj < FR; ++fj)
                         acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
@@ -410,12 +421,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int fi = 0; fi < FR; ++fi)
+        for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
             for (int fj = 0; fj < FR; ++fj)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + wm * WT + fi * 16 + Traits<T>::crow(lane, i);
+                    const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
                     const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
                     if (!EDGE || (row < p.M && col < p.N))
                         C[(int64_t)row * p.ldc + col] = p.alpha * acc[c][fi][fj][i];
@@ -475,7 +486,7 @@ struct PersistArgs {
     long long* prof;          // development aid: 8 slots (6 stamps) for each of the first 8 tiles of every workgroup (nullable)
 };
 
-template <typename T, int TS, bool EDGE>
+template <typename T, int TS, bool EDGE, int NW = 4>
 __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem) {
     // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast
     // word lives in the unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel
@@ -531,7 +542,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             if (ok && quarter) {              // the last, partial round of the launch: 64 x 64 quarters of a 128-tile
                 const int ti2 = 2 * ti + (quad >> 1), tj2 = 2 * tj + (quad & 1);
                 if (!((g.lower_only && tj2 > ti2) || ti2 * 64 >= g.M || tj2 * 64 >= g.N))
-                    gemm_tile<T, 64, true, true, EDGE, 1>(g, ti2, tj2, 0, 0, smem, nullptr);
+                    gemm_tile<T, 64, true, true, EDGE, 1, NW>(g, ti2, tj2, 0, 0, smem, nullptr);
                 ok = false;
             }
         }
@@ -540,7 +551,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             ++nlocal;
 #pragma unroll 1
             for (int r = 0; r < reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
-                gemm_tile<T, TS, true, true, EDGE, 1>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem, pr);
+                gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem, pr);
         }
         if (tid == 0) s_tile = nxt;
         __syncthreads();

@@ -1026,11 +1026,12 @@ static void la_clock(int n, int nb, int warm = 0) {
 
 // kernel-matrix kernel alone, the shapes of the four GPU configs:  --perf-kmat
 template <typename T>
-static void perf_kmat_case(const char* nm, int nterms, const int* kinds, int64_t n, int64_t m, int d, int batch, int lower) {
+static void perf_kmat_case(const char* nm, int nterms, const int* kinds, int64_t n, int64_t m, int d, int batch, int lower, int ldpad = 0) {
     const bool sym = (m == 0);
     if (sym) m = n;
+    const int64_t ldk = m + ldpad;
     auto hx = randv<T>((size_t)batch * n * d);
-    Dev<T> X(hx.size()), Y(sym ? 1 : (size_t)m * d), K((size_t)batch * n * m);
+    Dev<T> X(hx.size()), Y(sym ? 1 : (size_t)m * d), K((size_t)batch * n * ldk);
     X.up(hx);
     if (!sym) Y.up(randv<T>((size_t)m * d));
     double var[2] = {1.0, 1.0}, il[2] = {1.0, 1.0};
@@ -1040,7 +1041,7 @@ static void perf_kmat_case(const char* nm, int nterms, const int* kinds, int64_t
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
             tm.start();
-            gpk_kmat(DT<T>::v, kinds, var, il, nterms, X.p, n, d, n * d, sym ? X.p : Y.p, m, d, sym ? n * d : 0, d, K.p, m, n * m, batch, lower, sym ? 1 : 0, 0.1, nullptr, 0, 0, nullptr);
+            gpk_kmat(DT<T>::v, kinds, var, il, nterms, X.p, n, d, n * d, sym ? X.p : Y.p, m, d, sym ? n * d : 0, d, K.p, ldk, n * ldk, batch, lower, sym ? 1 : 0, 0.1, nullptr, 0, 0, nullptr);
             const float ms = tm.stop();
             if (rep) best = std::min(best, ms);
         }
@@ -1052,6 +1053,10 @@ static void perf_kmat_case(const char* nm, int nterms, const int* kinds, int64_t
 static void perf_kmat() {
     const int eq[1] = {GPK_K_EQ}, eql[2] = {GPK_K_EQ, GPK_K_LINEAR}, m52[1] = {GPK_K_MATERN52};
     perf_kmat_case<double>("cfg2 N=16384 D=8 EQ lower", 1, eq, 16384, 0, 8, 1, 1);
+    perf_kmat_case<double>("cfg2, ld = N + 16", 1, eq, 16384, 0, 8, 1, 1, 16);
+    perf_kmat_case<double>("cfg2, ld = N + 80", 1, eq, 16384, 0, 8, 1, 1, 80);
+    perf_kmat_case<double>("cfg2 full matrix", 1, eq, 16384, 0, 8, 1, 0);
+    perf_kmat_case<double>("N=16000 D=8 EQ lower", 1, eq, 16000, 0, 8, 1, 1);
     perf_kmat_case<float>("N=16384 D=8 EQ lower", 1, eq, 16384, 0, 8, 1, 1);
     perf_kmat_case<float>("cfg3 N=32768 D=4 EQ+Lin lower", 2, eql, 32768, 0, 4, 1, 1);
     perf_kmat_case<float>("cfg4 512xN=2048 D=3 EQ lower", 1, eq, 2048, 0, 3, 512, 1);
