@@ -830,8 +830,13 @@ class PosteriorMean(Mean):
 
     def _whitened_residual(self):
         if self._w is None:
-            r = uprank(self.y) - self.m_z(self.z)
-            self._w = self.K_z.chol().solve(r)          # (..., N, 1)
+            y = uprank(self.y)
+            r = y - self.m_z(self.z)
+            chol = self.K_z.chol()
+            if isinstance(self.m_z, ZeroMean) and hasattr(chol, "solve_residual"):
+                self._w = chol.solve_residual(r, y)     # shared with the log-density of the same observations
+            else:
+                self._w = chol.solve(r)                 # (..., N, 1)
         return self._w
 
     def __call__(self, x, cache=None):

@@ -76,6 +76,7 @@ class FDD(Normal):
 
         Normal.__init__(self, lambda: p.mean(xr), var, var_diag=var_diag, mean_var=mean_var,
                         mean_var_diag=mean_var_diag)
+        self._zero_mean = isinstance(p.mean, _k.ZeroMean)
 
     def logpdf(self, x):
         """``Normal.logpdf`` plus a guard: a value that came out cut off from the autograd graph although the process

@@ -301,3 +301,39 @@ def test_nan_scan_can_be_switched_off():
         assert rel((f | (f(T(x), 0.2), T(y)))(T(x[:5])).mean, post_want.cpu().numpy()) < 1e-12
     finally:
         config.check_nan = True
+
+
+def test_whitened_observations_are_solved_for_once(any_backend, monkeypatch):
+    """Round 3: the log-density (``random.py:276``) and the posterior mean (``observations.py:161-168``) of the same observations both
+    need ``L^{-1} y``; with a zero prior mean the factor hands the second asker the first one's result -- and notices when ``y``
+    has changed in place in between."""
+    from stheno_amd import matrix
+
+    dev = torch.device(DEVICE[0])
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 2, generator=g, dtype=torch.float64).to(dev)
+    y = torch.randn(300, 1, generator=g, dtype=torch.float64).to(dev)
+    xs = torch.randn(7, 2, generator=g, dtype=torch.float64).to(dev)
+    calls = []
+    orig = matrix.Chol.solve
+    monkeypatch.setattr(matrix.Chol, "solve", lambda self, b: (calls.append(tuple(b.shape)), orig(self, b))[1])
+
+    f = st.GP(st.EQ())
+    fdd = f(x, 0.1)
+    lp = fdd.logpdf(y)
+    post = f | (fdd, y)
+    mean, var = post(xs).marginals()
+    assert calls.count((300, 1)) == 1                  # one single-column solve for both
+    # the same numbers as without the shortcut
+    f2 = st.GP(st.EQ())
+    mean2, var2 = (f2 | (f2(x, 0.1), y))(xs).marginals()
+    assert torch.equal(mean, mean2) and torch.equal(var, var2)
+    ref = O.gp_logpdf([("eq", 1.0, 1.0)], x.cpu().numpy(), 0.1, y.cpu().numpy())
+    assert abs(float(lp) - ref) < 1e-9 * abs(ref)
+    # y modified in place after the log-density: the posterior must see the new values
+    f3 = st.GP(st.EQ())
+    fdd3 = f3(x, 0.1)
+    fdd3.logpdf(y)
+    y.mul_(2.0)
+    mean3, _ = (f3 | (fdd3, y))(xs).marginals()
+    assert torch.allclose(mean3, 2.0 * mean2, rtol=1e-10, atol=0)

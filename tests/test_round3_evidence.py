@@ -175,6 +175,27 @@ def test_rccl_one_rank_process_group_on_the_device():
     assert out["allgather_512_logpdfs_us"] > 0
 
 
+def test_sparse_readme_example_at_its_own_size_against_the_oracle():
+    """``readme_example10_sparse.py:8-29`` at its own size (N = 50 000, M = 20, noise 0.5, 100 prediction points; plain ``EQ()``
+    instead of the periodic kernel, which is outside the accelerated path): ELBO, approximate posterior mean and credible bounds
+    against the oracle at the SAME size."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import time_sparse_readme10 as ex
+    from oracle import gp_oracle as O
+
+    t = ex.inputs(DEV)
+    elbo, mean, lower, upper = ex.run(t)
+    h = {k: v.cpu().numpy() for k, v in t.items()}
+    terms = [("eq", 1.0, 1.0)]
+    ref_elbo = float(O.pseudo_obs(terms, h["x_obs"], 0.5, h["y_obs"][:, None], h["x_ind"])["elbo"])
+    ref_m, _, ref_v = O.pseudo_posterior(terms, h["x_obs"], 0.5, h["y_obs"][:, None], h["x_ind"], h["x"], full_cov=False)
+    assert abs(float(elbo) - ref_elbo) <= 1e-6 * abs(ref_elbo)
+    assert np.max(np.abs(mean.cpu().numpy() - ref_m)) <= 1e-6 * np.max(np.abs(ref_m))
+    sd = 1.96 * np.sqrt(np.maximum(ref_v, 0))
+    assert np.max(np.abs(lower.cpu().numpy() - (ref_m - sd))) <= 1e-6 * np.max(np.abs(ref_m - sd))
+    assert np.max(np.abs(upper.cpu().numpy() - (ref_m + sd))) <= 1e-6 * np.max(np.abs(ref_m + sd))
+
+
 def test_potrf_lookahead_inside_a_stream_capture():
     """``include/gpk.h``: "under stream capture it joins the capture".  Capture one look-ahead factorisation into a graph,
     replay it on fresh data, compare with the eager result."""
