@@ -233,7 +233,10 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // and measured in round 3 on the hypothesis that two waves per SIMD starve the matrix pipe whenever one of them waits: same
 // results, 2-4 % SLOWER (fp64 8192^3 68.6 vs 71.4 TFLOP/s, trailing update 59.6 vs 60.8, POTRF N = 16384 28.6 vs 28.1 ms); the
 // kernels were removed, the parameter stays.
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4>
+// TRIB: the B operand (N x K) is LOWER TRIANGULAR and the tile starts at column 0 of it (the panel solve P inv(L_cc)^T of the
+// Cholesky): a 16-column fragment at columns j0.. only needs k < j0 + 16, the MFMAs beyond are skipped per fragment and per group of
+// k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
                                           long long* prof = nullptr) {
     if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
@@ -315,7 +318,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
         for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ, NT>(dA + (1 + c) * OPB, rb[set][c], tid);
     };
-    auto mma = [&](int stage) {
+    auto mma = [&](int stage, int kc) {
         // scheduler hint: interleave the LDS reads with the MFMAs of this k-chunk (measured +2 % for fp64,
         // -7 % for fp32, whose paired-k reads already leave fewer LDS instructions)
         if constexpr (sizeof(T) == 8) __builtin_amdgcn_iglp_opt(0);
@@ -347,10 +350,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
                     for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                        for (int fi = 0; fi < FRM; ++fi)
+                        for (int fj = 0; fj < FR; ++fj) {
+                            if constexpr (TRIB) {        // (wave-uniform) the 8 k values of this group all lie right of the fragment's columns
+                                if (kc * BK + pp * 8 >= c * TS + wn * WT + fj * 16 + 16) continue;
+                            }
 #pragma unroll
-                            for (int fj = 0; fj < FR; ++fj)
+                            for (int fi = 0; fi < FRM; ++fi)
                                 acc[c][fi][fj] = Traits<T>::mfma((T)a2[fi][e], (T)b2[c][fj][e], acc[c][fi][fj]);
+                        }
             }
             return;
         }
@@ -369,10 +376,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
             for (int c = 0; c < NCT; ++c)
 #pragma unroll
-                for (int fi = 0; fi < FRM; ++fi)
+                for (int fj = 0; fj < FR; ++fj) {
+                    if constexpr (TRIB) {
+                        if (kc * BK + kk * 4 >= c * TS + wn * WT + fj * 16 + 16) continue;
+                    }
 #pragma unroll
-                    for (int fj = 0; fj < FR; ++fj)
-                        acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
+                    for (int fi = 0; fi < FRM; ++fi) acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
+                }
         }
     };
     typedef std::integral_constant<int, 0> S0;
@@ -390,13 +400,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         for (int kc = kc0; kc < nk; kc += 2) {
             // LDS stage 0 holds chunk kc, register set 1 holds chunk kc + 1
             if (kc + 2 < nk) issue(S0{}, kc + 2);
-            mma(0);
+            mma(0, kc);
             if (kc + 1 >= nk) break;
             commit(S1{}, 1);
             __syncthreads();
             // LDS stage 1 holds chunk kc + 1, register set 0 holds chunk kc + 2
             if (kc + 3 < nk) issue(S1{}, kc + 3);
-            mma(1);
+            mma(1, kc + 1);
             if (kc + 2 < nk) commit(S0{}, 0);
             __syncthreads();
         }
@@ -407,7 +417,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         for (int kc = kc0; kc < nk; ++kc) {
             const bool more = (kc + 1 < nk);
             if (more) issue(S0{}, kc + 1);
-            mma((kc - kc0) & 1);
+            mma((kc - kc0) & 1, kc);
             if (more) commit(S0{}, (kc + 1 - kc0) & 1);
             __syncthreads();
         }
@@ -456,6 +466,16 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
     }
     if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
     gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
+}
+
+// The panel solve of the blocked Cholesky,  P <- P inv(L_cc)^T  (both operands k-contiguous, one workgroup owns all 128 columns of its
+// rows: in place), with the zero half of the triangular operand skipped fragment by fragment (gemm_tile, TRIB).
+template <typename T, int TS, bool EDGE, int NCT>
+__global__ __launch_bounds__(256, 2) void gemm_trib_kernel(GemmArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (1 + NCT) * op_bytes(TS)];
+    int ti, tj;
+    if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
+    gemm_tile<T, TS, true, true, EDGE, NCT, 4, true>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
 
 // ---- persistent variant: a resident set of workgroups pulls tiles of up to two problems ("segments")
@@ -616,6 +636,7 @@ Prof g_prof;
 
 int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
 int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
+int g_trib = 1;                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
 int g_split_tail = 1;               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
@@ -653,6 +674,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 8) g_persist_small_below = value;
     if (key == 13) g_colmajor_ratio = (int)value;
     if (key == 31) g_split_tail = (int)value;
+    if (key == 36) g_trib = (int)value;
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -785,7 +807,14 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         const double fl = (lower_only ? 1.0 : 2.0) * ((flags & (2 | 4 | 8)) ? 0.5 : 1.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
         slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), fl, stream);
     }
-    if (nct == 2) {
+    const bool trib = (flags & 16) && g_trib && a_kmaj && b_kmaj && g.tiles_n == 1 && N <= 128 && g.split_from == INT32_MAX;
+    if (trib && nct == 2) {
+        if (edge) hipLaunchKernelGGL((gemm_trib_kernel<T, 64, true, 2>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_trib_kernel<T, 64, false, 2>), grid, dim3(256), 0, stream, g);
+    } else if (trib && ts == 128 && nct == 1) {
+        if (edge) hipLaunchKernelGGL((gemm_trib_kernel<T, 128, true, 1>), grid, dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((gemm_trib_kernel<T, 128, false, 1>), grid, dim3(256), 0, stream, g);
+    } else if (nct == 2) {
         if (edge)
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, true, 2>), grid, dim3(256), 0, stream, g);
         else
@@ -1082,7 +1111,7 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(PanelStepArgs<T> p) 
         strip = cb * NCT + r;
     }
     if (cb == 0) {
-        gemm_tile<T, TS, true, true, EDGE, NCT>(p.trsm, strip, 0, 0, 0, smem);
+        gemm_tile<T, TS, true, true, EDGE, NCT, 4, true>(p.trsm, strip, 0, 0, 0, smem);      // (TRIB: inv(L_cc) is lower triangular)
         __syncthreads();                        // every wave's stores of the strip are out (vmcnt drained before the barrier)
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

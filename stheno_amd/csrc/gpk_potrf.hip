@@ -786,7 +786,7 @@ int potrf_panel(const PanelCtx<T>& x, int64_t c0, int64_t w) {
         T* P = x.A + r1 * x.ld + c0;
         const T* Wc = x.dinv + (c0 / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
         return gpk_gemm_launch<T>(true, true, x.n - r1, GPK_DB, GPK_DB, T(1), P, x.ld, x.bstride, Wc, GPK_DB,
-                                  x.dstride, T(0), P, x.ld, x.bstride, x.batch, false, x.stream);
+                                  x.dstride, T(0), P, x.ld, x.bstride, x.batch, 16, x.stream);     // (16: B is lower triangular from column 0)
     }
     const int64_t h = w / 2;
     int st = potrf_panel<T>(x, c0, h);
