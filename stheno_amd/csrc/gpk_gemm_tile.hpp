@@ -1,0 +1,349 @@
+// gpk_gemm_tile.hpp -- the workgroup-level MFMA tile of the library: one TS x (NCT * TS) output tile of
+//   C[m][n] = alpha * sum_k a(m,k) b(n,k) + beta * C[m][n]
+// computed by the calling workgroup from register-staged, double-buffered LDS operand tiles (design notes at the top of
+// gpk_gemm.hip).  Device code only; included by gpk_gemm.hip (every GEMM kernel) and gpk_potrf.hip (the pipelined panel
+// factorisation, whose worker workgroups run panel solves and rank-128 updates as tasks).
+#pragma once
+#include "gpk_common.hpp"
+#include <type_traits>
+
+namespace {
+
+// One operand tile of TS rows in LDS, either image: k-contiguous [TS][128 B] or
+// row-contiguous [BK][TS + 16] (BK * sizeof(T) = 128 B), so (TS + 16) * 128 bytes cover both.
+constexpr int op_bytes(int ts) { return (ts + 16) * 128; }
+
+template <typename T>
+struct GemmArgs {
+    const T* A;
+    const T* B;
+    T* C;
+    const T* Cin;               // where beta * C is read from (== C unless the update goes out of place)
+    int64_t lda, ldb, ldc, ldcin, sA, sB, sC;
+    int64_t sA2, sB2, sC2;      // second (blockIdx.z) batch level
+    int M, N, K;
+    T alpha, beta_over_alpha;
+    int has_beta;
+    int tiles_m, tiles_n;
+    int lower_only;
+    int vec_ok;       // pointers / leading dimensions allow 16-byte loads
+    int tri_k;        // operands are lower-triangular in k (zero for k < row index): start at k = m0
+    int tri_k_lo;     // A (M x K) is lower triangular (zero for k > row): stop at k = m0 + TS; tile rows run
+                      // longest-first (bottom rows first)
+    int tri_k_lo_b;   // B (N x K) is lower triangular (zero for k > column index n): stop at k = n0 + tile width
+    int colmajor;     // column-major tile order (rectangular problems with many more tile columns than tile rows)
+    int pair_cols;    // persistent kernel, tri_k_lo_b: one task = column tiles c and tiles_n - 1 - c of a tile row
+    int swizzle;
+    int tri_pairs;    // triangular enumeration by row pairs / 8-column chunks (see decode_tile)
+    int n_super;
+    int SN;
+    int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
+                      // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
+};
+
+// ---- global -> registers ---------------------------------------------------
+// `fast`: (EDGE kernels only) this tile's rows and this k-chunk lie fully inside the operand and
+// 16-byte loads are legal -- interior tiles of a ragged problem take the vector path too.
+template <typename T, int TS, bool KMAJ, bool EDGE, int NT = 256>
+__device__ __forceinline__ void gload(typename Traits<T>::vec_t (&r)[TS * 8 / NT], const T* __restrict__ base,
+                                      int64_t ld, int r0, int k0, int R, int K, int tid, bool fast) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    if (KMAJ) {
+        const int c = tid & 7, rr0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int row = r0 + rr0 + (NT / 8) * i;
+            const int k = k0 + c * VEC;
+            const T* p = base + (int64_t)row * ld + k;
+            if (!EDGE || fast) {
+                r[i] = *reinterpret_cast<const vec_t*>(p);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) r[i][v] = (row < R && k + v < K) ? p[v] : T(0);
+            }
+        }
+    } else {
+        constexpr int CPR = TS / VEC;   // 16-byte chunks per k-row
+#pragma unroll
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int id = tid + NT * i;
+            const int krow = id / CPR, cc = id % CPR;
+            const int k = k0 + krow;
+            const int row = r0 + cc * VEC;
+            const T* p = base + (int64_t)k * ld + row;
+            if (!EDGE || fast) {
+                r[i] = *reinterpret_cast<const vec_t*>(p);
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) r[i][v] = (k < K && row + v < R) ? p[v] : T(0);
+            }
+        }
+    }
+}
+
+// ---- registers -> LDS --------------------------------------------------------
+template <typename T, int TS, bool KMAJ, int NT = 256>
+__device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_t (&r)[TS * 8 / NT], int tid) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    if (KMAJ) {
+        const int c = tid & 7, rr0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int rr = rr0 + (NT / 8) * i;
+            const int off = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4);
+            *reinterpret_cast<vec_t*>(lds + off) = r[i];
+        }
+    } else {
+        constexpr int CPR = TS / VEC;
+#pragma unroll
+        for (int i = 0; i < TS * 8 / NT; ++i) {
+            const int id = tid + NT * i;
+            const int krow = id / CPR, cc = id % CPR;
+            const int off = krow * ((TS + 16) * (int)sizeof(T)) + cc * 16;
+            *reinterpret_cast<vec_t*>(lds + off) = r[i];
+        }
+    }
+}
+
+// ---- LDS -> MFMA operand -----------------------------------------------------
+// rowbase: first tile row of this 16-row fragment; lr = lane & 15; k = element index in chunk.
+template <typename T, int TS, bool KMAJ>
+__device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int k, int swz) {
+    constexpr int VEC = Traits<T>::VEC;
+    int off;
+    if (KMAJ) {
+        const int chunk = k / VEC, within = k % VEC;
+        off = (rowbase + lr) * 128 + ((chunk ^ swz) << 4) + within * (int)sizeof(T);
+    } else {
+        off = k * ((TS + 16) * (int)sizeof(T)) + (rowbase + lr) * (int)sizeof(T);
+    }
+    return *reinterpret_cast<const T*>(lds + off);
+}
+
+// NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
+// Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
+// One output tile (ti, tj) of one problem, computed by the calling workgroup (256 threads).  `smem`:
+// 2 * (1 + NCT) * op_bytes(TS) bytes of LDS, free on entry; every wave has passed a barrier after its
+// last LDS read when the function returns.
+// NW: waves of the workgroup, as an (NW / 2) x 2 grid over the tile.  NW = 4 (256 threads): 64 x 64 of a 128-tile per wave -- what
+// every kernel of this file instantiates.  NW = 8 (512 threads, 32 x 64 per wave, two workgroups = FOUR waves per SIMD) was built
+// and measured in round 3 on the hypothesis that two waves per SIMD starve the matrix pipe whenever one of them waits: same
+// results, 2-4 % SLOWER (fp64 8192^3 68.6 vs 71.4 TFLOP/s, trailing update 59.6 vs 60.8, POTRF N = 16384 28.6 vs 28.1 ms); the
+// kernels were removed, the parameter stays.
+// TRIB: the B operand (N x K) is LOWER TRIANGULAR and the tile starts at column 0 of it (the panel solve P inv(L_cc)^T of the
+// Cholesky): a 16-column fragment at columns j0.. only needs k < j0 + 16, the MFMAs beyond are skipped per fragment and per group of
+// k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false>
+__device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
+                                          long long* prof = nullptr) {
+    if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
+    typedef typename Traits<T>::acc_t acc_t;
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int BK = Traits<T>::BK;
+    constexpr int NT = 64 * NW;          // threads
+    constexpr int NV = TS * 8 / NT;      // 16-byte vectors a thread moves per operand tile and k-chunk
+    constexpr int FR = TS / 32;          // 16x16 fragments per wave along the columns
+    constexpr int FRM = TS / (8 * NW);   // ... along the rows
+    constexpr int WT = TS / 2;           // wave sub-tile width
+    constexpr int WTM = 16 * FRM;        // ... height
+    constexpr int OPB = op_bytes(TS), STAGE = (1 + NCT) * OPB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, kq = lane >> 4;
+    const int swz = (lr >> 1) & 7;
+
+    const T* __restrict__ A = p.A + b * p.sA + b2 * p.sA2;
+    const T* __restrict__ B = p.B + b * p.sB + b2 * p.sB2;
+    T* __restrict__ C = p.C + b * p.sC + b2 * p.sC2;
+    const T* __restrict__ Cin = p.Cin + b * p.sC + b2 * p.sC2;
+
+    const int m0 = ti * TS, n0 = tj * TS * NCT;
+
+    acc_t acc[NCT][FRM][FR];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        if (p.has_beta) {
+#pragma unroll
+            for (int fi = 0; fi < FRM; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < FR; ++fj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
+                        const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
+                        T v = T(0);
+                        if (!EDGE || (row < p.M && col < p.N)) v = Cin[(int64_t)row * p.ldcin + col];
+                        acc[c][fi][fj][i] = v * p.beta_over_alpha;
+                    }
+        } else {
+#pragma unroll
+            for (int fi = 0; fi < FRM; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < FR; ++fj)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[c][fi][fj][i] = T(0);
+        }
+    }
+
+    int nk = (p.K + BK - 1) / BK;
+    if (p.tri_k_lo) nk = min(nk, (m0 + TS + BK - 1) / BK);   // A vanishes right of its diagonal
+    if (p.tri_k_lo_b) nk = min(nk, (n0 + TS * NCT + BK - 1) / BK);   // B vanishes right of its diagonal
+    int kc0 = p.tri_k ? m0 / BK : 0;            // all-zero k-chunks of triangular operands are skipped
+    if (kc0 > nk - 1) kc0 = nk > 0 ? nk - 1 : 0;
+    // Register staging.  Small tiles (TS = 64) serve the narrow, latency-bound GEMMs of the path
+    // (panel / merge / solve), where a workgroup is often alone on its CU: they keep TWO k-chunks of
+    // global loads in flight (PF2); the 128-tile kernel hides the latency with its second workgroup.
+    constexpr bool PF2 = (TS <= 64);
+    vec_t ra[PF2 ? 2 : 1][NV], rb[PF2 ? 2 : 1][NCT][NV];
+
+    const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS * NCT <= p.N);
+    auto issue = [&](auto set_c, int kc) {           // global -> register set `set`
+        constexpr int set = decltype(set_c)::value;
+        const bool k_in = (kc + 1) * BK <= p.K;
+        gload<T, TS, A_KMAJ, EDGE, NT>(ra[set], A, p.lda, m0, kc * BK, p.M, p.K, tid, a_in && k_in);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+            gload<T, TS, B_KMAJ, EDGE, NT>(rb[set][c], B, p.ldb, n0 + c * TS, kc * BK, p.N, p.K, tid, b_in && k_in);
+    };
+    auto commit = [&](auto set_c, int stage) {       // register set -> LDS stage
+        constexpr int set = decltype(set_c)::value;
+        char* dA = smem + stage * STAGE;
+        sstore<T, TS, A_KMAJ, NT>(dA, ra[set], tid);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ, NT>(dA + (1 + c) * OPB, rb[set][c], tid);
+    };
+    auto mma = [&](int stage, int kc) {
+        // scheduler hint: interleave the LDS reads with the MFMAs of this k-chunk (measured +2 % for fp64,
+        // -7 % for fp32, whose paired-k reads already leave fewer LDS instructions)
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_iglp_opt(0);
+        const char* sA = smem + stage * STAGE;
+        const char* sB = sA + OPB;
+        if constexpr (sizeof(T) == 4 && A_KMAJ && B_KMAJ) {
+            // fp32, both operands k-contiguous: a lane fetches TWO consecutive k values with one
+            // ds_read_b64 and feeds them to two successive MFMAs.  The contraction order inside the
+            // chunk is permuted identically for A and B (step 2p+e, lane group kq <-> k = 8p + 2kq + e),
+            // which is harmless for a sum.  Halves the LDS read instructions and removes the 2-way
+            // bank conflict of ds_read_b32 on a 128-byte row pitch (bank = dword mod 32: the two
+            // rows 2a, 2a+1 of a 32-lane group alias); the b64 pattern equals the fp64 one.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int pp = 0; pp < BK / 8; ++pp) {
+                f2 a2[FRM], b2[NCT][FR];
+                const int u = pp * 4 + kq;           // 8-byte unit of the 128-byte row
+                const int uo = (((u >> 1) ^ swz) << 4) + (u & 1) * 8;
+#pragma unroll
+                for (int f = 0; f < FRM; ++f) a2[f] = *reinterpret_cast<const f2*>(sA + (wm * WTM + f * 16 + lr) * 128 + uo);
+#pragma unroll
+                for (int f = 0; f < FR; ++f) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+                        b2[c][f] = *reinterpret_cast<const f2*>(sB + c * OPB + (wn * WT + f * 16 + lr) * 128 + uo);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                        for (int fj = 0; fj < FR; ++fj) {
+                            if constexpr (TRIB) {        // (wave-uniform) the 8 k values of this group all lie right of the fragment's columns
+                                if (kc * BK + pp * 8 >= c * TS + wn * WT + fj * 16 + 16) continue;
+                            }
+#pragma unroll
+                            for (int fi = 0; fi < FRM; ++fi)
+                                acc[c][fi][fj] = Traits<T>::mfma((T)a2[fi][e], (T)b2[c][fj][e], acc[c][fi][fj]);
+                        }
+            }
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            T a[FRM], bb[NCT][FR];
+            const int k = kk * 4 + kq;
+#pragma unroll
+            for (int f = 0; f < FRM; ++f) a[f] = fragread<T, TS, A_KMAJ>(sA, wm * WTM + f * 16, lr, k, swz);
+#pragma unroll
+            for (int f = 0; f < FR; ++f) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    bb[c][f] = fragread<T, TS, B_KMAJ>(sB + c * OPB, wn * WT + f * 16, lr, k, swz);
+            }
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int fj = 0; fj < FR; ++fj) {
+                    if constexpr (TRIB) {
+                        if (kc * BK + kk * 4 >= c * TS + wn * WT + fj * 16 + 16) continue;
+                    }
+#pragma unroll
+                    for (int fi = 0; fi < FRM; ++fi) acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
+                }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, PF2 ? 1 : 0> S1;
+
+    if (prof != nullptr && threadIdx.x == 0) {      // C tile requested, accumulators being initialised
+        prof[1] = wall_clock64();
+        prof[4] = (long long)__builtin_readcyclecounter();   // shader-clock ticks: with the 100 MHz stamps they give the clock the k loop ran at
+    }
+    if (PF2) {
+        issue(S0{}, kc0);
+        if (kc0 + 1 < nk) issue(S1{}, kc0 + 1);
+        commit(S0{}, 0);
+        __syncthreads();
+        for (int kc = kc0; kc < nk; kc += 2) {
+            // LDS stage 0 holds chunk kc, register set 1 holds chunk kc + 1
+            if (kc + 2 < nk) issue(S0{}, kc + 2);
+            mma(0, kc);
+            if (kc + 1 >= nk) break;
+            commit(S1{}, 1);
+            __syncthreads();
+            // LDS stage 1 holds chunk kc + 1, register set 0 holds chunk kc + 2
+            if (kc + 3 < nk) issue(S1{}, kc + 3);
+            mma(1, kc + 1);
+            if (kc + 2 < nk) commit(S0{}, 0);
+            __syncthreads();
+        }
+    } else {
+        issue(S0{}, kc0);
+        commit(S0{}, 0);
+        __syncthreads();
+        for (int kc = kc0; kc < nk; ++kc) {
+            const bool more = (kc + 1 < nk);
+            if (more) issue(S0{}, kc + 1);
+            mma((kc - kc0) & 1, kc);
+            if (more) commit(S0{}, (kc + 1 - kc0) & 1);
+            __syncthreads();
+        }
+    }
+
+    if (prof != nullptr && threadIdx.x == 0) {      // k loop done
+        prof[2] = wall_clock64();
+        prof[5] = (long long)__builtin_readcyclecounter();
+    }
+    // (in-place use: every global read of this workgroup's rows of A happened above)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int fi = 0; fi < FRM; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < FR; ++fj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
+                    const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
+                    if (!EDGE || (row < p.M && col < p.N))
+                        C[(int64_t)row * p.ldc + col] = p.alpha * acc[c][fi][fj][i];
+                }
+    if (prof != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);          // (profiling only) stores retired
+        if (threadIdx.x == 0) prof[3] = wall_clock64();
+    }
+}
+
+}  // namespace

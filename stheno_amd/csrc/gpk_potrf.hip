@@ -20,6 +20,8 @@
 // inv(L_cc) blocks are kept: gpk_solve.hip turns every triangular solve of the
 // path into GEMM/GEMV work with them.
 #include "gpk_common.hpp"
+#include "gpk_gemm_tile.hpp"
+#include "gpk_potrf_pipe.hpp"
 #include <vector>
 
 namespace {
@@ -510,92 +512,142 @@ __device__ __forceinline__ void panel_chol(T* __restrict__ S, T* __restrict__ rd
     }
 }
 
-// One level of the recursive-doubling inversion on NW waves (see invert_level): the NPAIR * TPP output tiles are dealt round-robin
-// to the waves, each wave advances its (at most PER) tiles together, and every tile accumulates into TWO accumulators (even / odd
-// k-steps, summed at the end): a dependent fp64 MFMA costs ~180 cycles, so the levels with one tile per wave are chain-bound, not
-// pipe-bound.  (Skipping the k-blocks in which the triangular operand vanishes -- 3/8 of the last level -- was tried with
-// wave-uniform predicates around the loads and MFMAs: 17.3k -> 20.2k cycles for the three levels, the branches cost more than
-// the MFMAs they save.)
-template <typename T, int H, int NW>
-__device__ __forceinline__ void invert_level_w(T* S, int wave, int lane, int lr, int kq) {
-    typedef typename Traits<T>::acc_t acc_t;
-    constexpr int HB = H / 16, TPP = HB * HB, NPAIR = GPK_DB / (2 * H), NTILE = NPAIR * TPP, PER = (NTILE + NW - 1) / NW;
-    int ti[PER], tj[PER], o[PER];
-    bool on[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int item = wave + NW * q;
-        on[q] = item < NTILE;
-        const int it = on[q] ? item : 0;
-        const int t = it % TPP;
-        ti[q] = t / HB;
-        tj[q] = t % HB;
-        o[q] = (it / TPP) * 2 * H;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        acc_t acc[PER][2];
-#pragma unroll
-        for (int q = 0; q < PER; ++q)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) acc[q][e][0] = acc[q][e][1] = acc[q][e][2] = acc[q][e][3] = T(0);
-#pragma unroll
-        for (int kb = 0; kb < HB; ++kb) {
-            T av[PER][4], bv[PER][4];
-#pragma unroll
-            for (int q = 0; q < PER; ++q)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 16 * kb + 4 * kk + kq;
-                    if (pass == 0) {   // T = C * Ainv
-                        av[q][kk] = S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + k];
-                        bv[q][kk] = S[(o[q] + k) * LDP + o[q] + 16 * tj[q] + lr];
-                    } else {           // C' = -Dinv * T
-                        av[q][kk] = -S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + H + k];
-                        bv[q][kk] = S[(o[q] + H + k) * LDP + o[q] + 16 * tj[q] + lr];
-                    }
-                }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int q = 0; q < PER; ++q) acc[q][kk & 1] = Traits<T>::mfma(av[q][kk], bv[q][kk], acc[q][kk & 1]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PER; ++q)
-            if (on[q]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    S[(o[q] + H + 16 * ti[q] + Traits<T>::crow(lane, i)) * LDP + o[q] + 16 * tj[q] + lr] = acc[q][0][i] + acc[q][1][i];
-            }
-        __syncthreads();
-    }
-}
+// ---- the inverse of the block, grown during its factorisation ----
+// inv(L) is built ROW BLOCK by row block (16 rows): row block r only needs the rows 0..r of L, which are final as soon as micro-panel
+// r has been factorised, and the row blocks of inv(L) above it:
+//     W_rr = inv(L_rr)                                     one 16-lane group, substitution (the reciprocal pivots are at hand)
+//     W_rc = -W_rr  sum_{k=c}^{r-1} L_rk W_kc      c < r   one wave per tile: a chain of 4 (r - c) + 4 MFMAs
+// so row block s-1 is computed in the shadow of the factorisation of micro-panel s+1, by waves that would otherwise wait at the
+// barrier (the panel chain is one wave; the rank-16 updates of the others take a fraction of its time), and only the last two row
+// blocks are left when the factorisation ends: ~9k cycles instead of the ~21k of inverting the finished block by recursive doubling
+// (three levels of two dependent products each, eight barriers) -- measured in profiles/r03_experiments.md.
+// Storage: the strictly-lower tiles W_rc go where S has nothing -- ABOVE the diagonal, at tile position (c, r), untransposed inside
+// the tile -- and the diagonal tiles W_rr into D16 (pitch DP16: conflict-free as MFMA operand); inverse_at() reads the result back.
+// The long chains are given to waves that do not share a SIMD with the panel wave (wave w runs on SIMD w % 4; wave 0, and wave 1
+// while two waves factorise, hold the dependent scalar chain of the panel).
+constexpr int DP16 = 18;
+constexpr int D3_LDS_ELEMS = GPK_DB * LDP + GPK_DB + 8 * 16 * DP16;
 
 template <typename T>
-__global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> p) {
-    __shared__ __attribute__((aligned(16))) T S[GPK_DB * LDP + GPK_DB];
-    T* rdiag = S + GPK_DB * LDP;
+__device__ __forceinline__ T inverse_at(const T* __restrict__ S, int r, int c) {
+    // one LDS read at a selected index (the tiles of a wave's lanes differ: branches here cost 4x the whole write-back)
+    const int tr = r >> 4, tc = c >> 4;
+    const int lower = (16 * tc + (r & 15)) * LDP + 16 * tr + (c & 15);
+    const int diag = GPK_DB * LDP + GPK_DB + r * DP16 + (c & 15);       // D16 sits behind the block and the reciprocal pivots
+    const T v = S[tr > tc ? lower : diag];
+    return tr >= tc ? v : T(0);
+}
 
-    const int tid = threadIdx.x;
+// W_qq = inv(L_qq) by lanes 0..15 of the calling wave: lane lr solves for column lr of the inverse, right-looking (x_i is final once
+// the columns before it have been applied; column i + 1 of L is requested while column i is applied)
+template <typename T>
+__device__ __forceinline__ void inverse_diag_tile(const T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, int q, int lane) {
+    if (lane >= 16) return;
+    const int c0 = 16 * q, lr = lane;
+    T x[16], v[16], rd[16], col[2][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = (i == lr) ? T(1) : T(0);
+        rd[i] = rdiag[c0 + i];
+    }
+#pragma unroll
+    for (int r = 1; r < 16; ++r) col[0][r] = S[(c0 + r) * LDP + c0];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i + 1 < 16) {
+#pragma unroll
+            for (int r = i + 2; r < 16; ++r) col[(i + 1) & 1][r] = S[(c0 + r) * LDP + c0 + i + 1];
+        }
+        x[i] = v[i] * rd[i];
+#pragma unroll
+        for (int r = i + 1; r < 16; ++r) v[r] -= col[i & 1][r] * x[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) D16[(c0 + i) * DP16 + lr] = x[i];     // (zeros above the diagonal)
+}
+
+// W_rc (c < r) by the calling wave.  The final product takes the accumulator AS the B operand: register i of lane group g holds row
+// crow(lane, i) of the sum, so MFMA step i contracts over k = crow(lane, i) with A = -W_rr[lr][k] -- no layout change needed.
+template <typename T>
+__device__ __forceinline__ void inverse_tile(T* __restrict__ S, const T* __restrict__ D16, int r, int c, int lane, int lr, int kq) {
+    typedef typename Traits<T>::acc_t acc_t;
+    acc_t a0, a1;
+    a0[0] = a0[1] = a0[2] = a0[3] = T(0);
+    a1 = a0;
+    // the operands of step k + 1 are requested before the MFMAs of step k are issued (a lone wave issues an MFMA every ~140 cycles:
+    // the LDS latency of a step fits behind the four of the step before)
+    T av[2][4], bv[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        av[0][kk] = S[(16 * r + lr) * LDP + 16 * c + 4 * kk + kq];
+        bv[0][kk] = D16[(16 * c + 4 * kk + kq) * DP16 + lr];
+    }
+    for (int k = c; k < r; k += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (k + h < r) {
+                if (k + h + 1 < r) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        av[1 - h][kk] = S[(16 * r + lr) * LDP + 16 * (k + h + 1) + 4 * kk + kq];
+                        bv[1 - h][kk] = S[(16 * c + 4 * kk + kq) * LDP + 16 * (k + h + 1) + lr];
+                    }
+                }
+                a0 = Traits<T>::mfma(av[h][0], bv[h][0], a0);
+                a1 = Traits<T>::mfma(av[h][1], bv[h][1], a1);
+                a0 = Traits<T>::mfma(av[h][2], bv[h][2], a0);
+                a1 = Traits<T>::mfma(av[h][3], bv[h][3], a1);
+            }
+        }
+    }
+    acc_t out;
+    out[0] = out[1] = out[2] = out[3] = T(0);
+    T wr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = -D16[(16 * r + lr) * DP16 + Traits<T>::crow(lane, i)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out = Traits<T>::mfma(wr[i], a0[i] + a1[i], out);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[(16 * c + Traits<T>::crow(lane, i)) * LDP + 16 * r + lr] = out[i];
+}
+
+// The calling wave's share of: the tiles (row, 0 .. row-1) of the inverse (row < 0: none) and the diagonal tiles `diag`, `diag2` (< 0:
+// none).  Jobs in order of length (tile 0 first, the diagonal tiles last) go to the waves 7, 3, 6, 2, 5, 1, 4, 0.
+template <typename T>
+__device__ __forceinline__ void inverse_jobs(T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, int row, int diag,
+                                             int diag2, int wave, int lane, int lr, int kq) {
+    const int slot = (wave & 3) == 3 ? (wave == 7 ? 0 : 1) : ((wave & 3) == 2 ? (wave == 6 ? 2 : 3) : ((wave & 3) == 1 ? (wave == 5 ? 4 : 5) : (wave == 4 ? 6 : 7)));
+    const int ntile = row > 0 ? row : 0;
+    if (slot < ntile) inverse_tile<T>(S, D16, row, slot, lane, lr, kq);
+    else if (slot == ntile && diag >= 0) inverse_diag_tile<T>(S, rdiag, D16, diag, lane);
+    else if (slot == ntile + 1 && diag2 >= 0) inverse_diag_tile<T>(S, rdiag, D16, diag2, lane);
+}
+
+// One 128x128 diagonal block by the calling workgroup (D3_THREADS threads): A = the block's first element (leading dimension ld),
+// nv = its valid order (identity-padded to 128), S / rdiag = D3_LDS_ELEMS elements of LDS (block, reciprocal pivots, diagonal tiles of the inverse).  LOAD = false: S already
+// holds the block (lower triangle, zeros above the diagonal, identity padding) -- the pipelined panel factorisation builds the
+// next block there.  W (nullable) receives inv(L); `zero_next` clears the first 4 KiB behind it.  prof: this thread's stamp
+// slots (nullptr except for one thread of a profiled workgroup).  On return every thread's global stores have been ISSUED.
+template <typename T, bool LOAD>
+__device__ __forceinline__ void diag3_block(T* __restrict__ S, T* __restrict__ rdiag, T* __restrict__ A, int64_t ld, int nv,
+                                            T* __restrict__ W, int* info, int info_off, int zero_next, long long* prof) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));        // (called from a loop: nothing derived from the thread index is worth keeping across iterations -- hoisted, it spills)
+    T* __restrict__ D16 = rdiag + GPK_DB;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
-    const int64_t b = blockIdx.x;
-    T* __restrict__ A = p.A + b * p.bstride + p.off * p.ld + p.off;
-    const int rem = p.n - (int)p.off;
-    const int nv = rem < GPK_DB ? rem : GPK_DB;
 
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
     constexpr int CPR = GPK_DB / VEC;                    // 16-byte chunks per row
     constexpr int PER = GPK_DB * CPR / D3_THREADS;       // chunks per thread
-    const bool vec_io = (nv == GPK_DB) && ((uintptr_t)A % 16 == 0) && (p.ld % VEC == 0);
-    long long* prof = (p.prof != nullptr && blockIdx.x == 0 && tid == 0) ? p.prof + (p.off / GPK_DB) * 32 : nullptr;
+    const bool vec_io = (nv == GPK_DB) && ((uintptr_t)A % 16 == 0) && (ld % VEC == 0);
     if (prof) prof[0] = (long long)__builtin_readcyclecounter();
 
     // ---- phase 0: load the lower triangle; pad with identity; zeros above the diagonal ----
-    if (vec_io) {
+    if (!LOAD) {
+    } else if (vec_io) {
         // all global loads of a thread are in flight before its first LDS store (one latency, not one per chunk)
         vec_t buf[PER];
 #pragma unroll
@@ -603,7 +655,7 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> 
             const int id = tid + D3_THREADS * i;
             const int r = id / CPR, c = (id % CPR) * VEC;
             const int cc = (c <= r) ? c : 0;             // (above the diagonal: a harmless in-bounds address, the value is dropped below)
-            buf[i] = *reinterpret_cast<const vec_t*>(A + (int64_t)r * p.ld + cc);
+            buf[i] = *reinterpret_cast<const vec_t*>(A + (int64_t)r * ld + cc);
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -620,7 +672,7 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> 
             for (int i = 0; i < 8; ++i) {
                 const int idx = base + tid + D3_THREADS * i;
                 const int r = idx >> 7, c = idx & 127;
-                buf[i] = (r < nv && c <= r) ? A[(int64_t)r * p.ld + c] : ((r == c) ? T(1) : T(0));
+                buf[i] = (r < nv && c <= r) ? A[(int64_t)r * ld + c] : ((r == c) ? T(1) : T(0));
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -629,13 +681,13 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> 
             }
         }
     }
-    __syncthreads();
+    if (LOAD) __syncthreads();
     if (prof) prof[1] = (long long)__builtin_readcyclecounter();
 
-    // ---- phase 1: factorise ----
+    // ---- phase 1: factorise; the inverse grows row block by row block in the shadow of the panel factorisations ----
     {
         const int np = panel_waves(0);
-        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane, p.info + b, (int)p.off + p.info_base);
+        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane, info, info_off);
     }
     __syncthreads();
     if (prof) prof[2] = (long long)__builtin_readcyclecounter();
@@ -644,12 +696,15 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> 
         // (U1) micro-column s+1 by column s: 7 - s tiles, one per wave
         rank16_update<T>(S, c0, 0, s, 7 - s, wave, D3_WAVES, lane, lr, kq);
         __syncthreads();
-        // panel s+1 on its waves  ||  (U2) column s applied to the remaining tiles on the others
+        // panel s+1 on its waves  ||  (U2) column s applied to the remaining tiles on the others, then their share of the inverse
         const int np = panel_waves(s + 1);
-        if (wave < np)
-            panel_chol<T>(S, rdiag, s + 1, wave, lane, p.info + b, (int)p.off + p.info_base);
-        else
+        if (wave < np) {
+            panel_chol<T>(S, rdiag, s + 1, wave, lane, info, info_off);
+        } else {
             rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - np, D3_WAVES - np, lane, lr, kq);
+            // (step 0 is bound by its 21 trailing tiles, not by the panel: the first diagonal tile waits for step 1)
+            if (W != nullptr && s > 0) inverse_jobs<T>(S, rdiag, D16, s - 1, s, s == 1 ? 0 : -1, wave, lane, lr, kq);
+        }
         __syncthreads();
         if (prof) prof[3 + s] = (long long)__builtin_readcyclecounter();
     }
@@ -669,78 +724,351 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> 
             const int id = tid + D3_THREADS * i;
             const int r = id / CPR, c = (id % CPR) * VEC;
             if (c + VEC - 1 <= r) {
-                *reinterpret_cast<vec_t*>(A + (int64_t)r * p.ld + c) = wbuf[i];
+                *reinterpret_cast<vec_t*>(A + (int64_t)r * ld + c) = wbuf[i];
             } else if (c <= r) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-                    if (c + v <= r) A[(int64_t)r * p.ld + c + v] = wbuf[i][v];
+                    if (c + v <= r) A[(int64_t)r * ld + c + v] = wbuf[i][v];
             }
         }
     } else {
         for (int idx = tid; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
             const int r = idx >> 7, c = idx & 127;
-            if (r < nv && c <= r) A[(int64_t)r * p.ld + c] = S[r * LDP + c];
+            if (r < nv && c <= r) A[(int64_t)r * ld + c] = S[r * LDP + c];
         }
     }
-    if (p.dinv == nullptr) return;
-    // phase 2's reads of S are complete before the in-place inversion -- a barrier that waits for the LDS only: __syncthreads()
-    // would also wait for the write-back of L to RETIRE (s_waitcnt vmcnt(0)), ~5k cycles of nothing (measured: "storeL 6.2k")
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (W == nullptr) return;
     if (prof) prof[10] = (long long)__builtin_readcyclecounter();
 
-    // ---- phase 3: invert L in place ----
-    // I. the eight 16x16 diagonal tiles: 16-lane group g of waves 0 / 1 owns tile 4 * wave + g, lane lr solves for column lr of
-    //    the inverse.  Right-looking: x_i is final once the columns before it have been applied, then column i of L updates the rows
-    //    below (independent FMAs: the dependent chain is one multiply + one FMA per step); column i + 1 is requested while column i
-    //    is applied (two waves per SIMD leave 256 registers per lane: the 120 multipliers of the fp64 tile would not fit)
-    if (wave < 2) {
-        const int c0 = 16 * (4 * wave + kq);
-        T x[16], v[16], rd[16], col[2][16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            v[i] = (i == lr) ? T(1) : T(0);
-            rd[i] = rdiag[c0 + i];
-        }
-#pragma unroll
-        for (int r = 1; r < 16; ++r) col[0][r] = S[(c0 + r) * LDP + c0];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i + 1 < 16) {
-#pragma unroll
-                for (int r = i + 2; r < 16; ++r) col[(i + 1) & 1][r] = S[(c0 + r) * LDP + c0 + i + 1];
-            }
-            x[i] = v[i] * rd[i];
-#pragma unroll
-            for (int r = i + 1; r < 16; ++r) v[r] -= col[i & 1][r] * x[i];
-        }
-        __builtin_amdgcn_sched_barrier(0);     // every multiplier has been read before the tile is overwritten (one lane group owns it)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[(c0 + i) * LDP + c0 + lr] = x[i];   // zeros above the diagonal
-    }
-    __syncthreads();
+    // ---- phase 3: the last two row blocks of the inverse (the write-back above only reads the lower triangle of S, the jobs
+    //      below only write above it and into D16: no barrier in between, and none that would wait for the stores to retire) ----
+    inverse_jobs<T>(S, rdiag, D16, 6, 7, -1, wave, lane, lr, kq);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (prof) prof[11] = (long long)__builtin_readcyclecounter();
-    // II. recursive doubling: [A 0; C D]^-1 = [Ai 0; -Di C Ai, Di].
-    invert_level_w<T, 16, D3_WAVES>(S, wave, lane, lr, kq);
-    invert_level_w<T, 32, D3_WAVES>(S, wave, lane, lr, kq);
-    invert_level_w<T, 64, D3_WAVES>(S, wave, lane, lr, kq);
+    inverse_jobs<T>(S, rdiag, D16, 7, -1, -1, wave, lane, lr, kq);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (prof) prof[12] = (long long)__builtin_readcyclecounter();
 
     // ---- phase 4: write inv(L) (identity-padded, zeros above the diagonal) ----
-    T* __restrict__ W = p.dinv + b * p.dinv_bstride + (p.off / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int id = tid + D3_THREADS * i;
         const int r = id / CPR, c = (id % CPR) * VEC;
         vec_t w;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) w[v] = S[r * LDP + c + v];
+        for (int v = 0; v < VEC; ++v) w[v] = inverse_at<T>(S, r, c + v);
         *reinterpret_cast<vec_t*>(W + (int64_t)r * GPK_DB + c) = w;
     }
-    if (p.zero_next && tid < 256) {
+    if (zero_next && tid < 256) {
         uint4* z = reinterpret_cast<uint4*>(W + (int64_t)GPK_DB * GPK_DB);
         z[tid] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (prof) prof[13] = (long long)__builtin_readcyclecounter();
+}
+
+
+template <typename T>
+__global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) T S[D3_LDS_ELEMS];
+    const int64_t b = blockIdx.x;
+    T* A = p.A + b * p.bstride + p.off * p.ld + p.off;
+    const int rem = p.n - (int)p.off;
+    T* W = p.dinv == nullptr ? nullptr : p.dinv + b * p.dinv_bstride + (p.off / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
+    long long* prof = (p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0) ? p.prof + (p.off / GPK_DB) * 32 : nullptr;
+    diag3_block<T, true>(S, S + GPK_DB * LDP, A, p.ld, rem < GPK_DB ? rem : GPK_DB, W, p.info + b, (int)p.off + p.info_base, p.zero_next, prof);
+}
+
+// ---------------------------------------------------------------------------
+// potrf_pipe_kernel -- a whole panel of the factorisation (its diagonal blocks, the solves below them, the rank-128 updates
+// inside the panel) in ONE launch, as a pipeline between workgroups (task list and dependency rules: gpk_potrf_pipe.hpp).
+//
+// Against one diagonal-block launch + one panel-step launch per 128 columns the chain loses, per step: two kernel boundaries
+// (drain, dispatch, ramp: ~3 us each between dependent launches), the global round trip of the next diagonal block (its last
+// update lands in LDS, where the factorisation wants it), and everything of the step that the next diagonal block does not
+// depend on -- the solves of the rows further down and their updates run on the worker workgroups WHILE the chain factorises.
+//
+//   workgroup 0 (the chain), per block j:   factorise + invert block j in LDS (diag3_block), publish inv(L_jj);
+//       X = A[block j+1, j] inv(L_jj)^T     the 128 rows the next diagonal block depends on: inv(L_jj) read from LDS, the rows
+//                                           straight from global memory into MFMA operand registers; X to global + LDS, published;
+//       S = A[j+1, j+1] - X X^T             lower tiles only, X from LDS, result to LDS = the input of the next factorisation.
+//   workgroups 1.. (workers):               solve / update tasks of 64 rows x 128 columns on the GEMM tile (eight waves), taken from
+//                                           an atomic counter in list order; progress words say when a piece is ready.
+// Flag protocol as in panel_step_kernel: data stores -> barrier (vmcnt drained) -> agent-scope release -> flag; consumers poll
+// with relaxed agent-scope loads, then agent-scope acquire -> barrier.  A poll that exceeds PIPE_SPIN_LIMIT iterations (seconds;
+// never seen) raises the abort word: every workgroup leaves and `info` reports -1 instead of hanging the device.
+// ---------------------------------------------------------------------------
+constexpr unsigned PIPE_SPIN_LIMIT = 1u << 22;
+
+template <typename T>
+struct PipeArgs {
+    T* A;              // element (c0, c0)
+    int64_t ld;
+    int m;             // rows from c0 to the end of the matrix
+    int w;             // columns of the panel
+    PipeShape sh;
+    T* dinv;           // slot of the panel's first diagonal block
+    unsigned* ctrl;    // pipe_ctrl_words(sh) zeroed words
+    int* info;
+    int info_off;      // added to the pivot orders (columns left of the panel)
+    int vec_ok;
+    int ntasks;
+    int off[GPK_PIPE_MAX_BLOCKS + 1];   // first task of step j
+    long long* prof;   // 32 stamps per diagonal block (nullable)
+};
+
+// wave 0 of the workgroup: lane i < count waits for *w_i == want.  false = aborted.
+__device__ __forceinline__ bool pipe_poll(unsigned* w, bool mine, unsigned want, unsigned* abort_word) {
+    unsigned it = 0;
+    for (;;) {
+        const bool ok = !mine || __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want;
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++it & 255u) == 0) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (it > PIPE_SPIN_LIMIT) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// all threads: wait for up to four words (w[i] == want[i], i < count), then acquire.  false = aborted (uniform).
+__device__ __forceinline__ bool pipe_wait(unsigned* w0, unsigned* w1, unsigned* w2, unsigned* w3, unsigned v0, unsigned v1,
+                                          unsigned v2, unsigned v3, int count, unsigned* abort_word, int* s_ctl) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        unsigned* w = tid == 0 ? w0 : (tid == 1 ? w1 : (tid == 2 ? w2 : w3));
+        const unsigned v = tid == 0 ? v0 : (tid == 1 ? v1 : (tid == 2 ? v2 : v3));
+        const bool mine = tid < count;
+        const bool ok = pipe_poll(mine ? w : w0, mine, v, abort_word);
+        if (tid == 0) {
+            s_ctl[1] = ok ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    return s_ctl[1] != 0;
+}
+
+// all threads: this workgroup's global stores are visible agent-wide before the words change
+__device__ __forceinline__ void pipe_publish(unsigned* w0, unsigned* w1, unsigned v) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(w0, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w1 != nullptr) __hip_atomic_store(w1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void pipe_chain(const PipeArgs<T>& p, T* __restrict__ S, int* s_ctl) {
+    typedef typename Traits<T>::acc_t acc_t;
+    T* rdiag = S + GPK_DB * LDP;
+    int tid_ = threadIdx.x;
+    int lane_ = tid_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int npb = p.sh.npb, nd = p.sh.nd, R = p.sh.R;
+    unsigned* abort_word = p.ctrl + 1;
+    unsigned* prog = p.ctrl + GPK_PIPE_CTRL_HEAD;
+    int64_t ld = p.ld;
+
+    {   // block 0 from global memory (the later ones are built in LDS)
+        const int nv = p.m < GPK_DB ? p.m : GPK_DB;
+        for (int idx = tid_; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
+            const int r = idx >> 7, c = idx & 127;
+            S[r * LDP + c] = (r < nv && c <= r) ? p.A[(int64_t)r * ld + c] : ((r == c) ? T(1) : T(0));
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < nd; ++j) {
+        // per-thread offsets (row * ld for every row a thread touches in a dozen phases) are loop-invariant: left alone, the compiler
+        // hoists them all out of this loop and spills most of them (640 bytes of scratch per lane, measured)
+        asm volatile("" : "+s"(ld));
+        asm volatile("" : "+v"(lane_), "+v"(tid_));
+        const int tid = tid_, lane = lane_;
+        const int lr = lane & 15, kq = lane >> 4;
+        T* Ab = p.A + (int64_t)GPK_DB * j * ld + GPK_DB * j;
+        const int rem = p.m - GPK_DB * j;
+        T* W = p.dinv + (int64_t)j * (GPK_DB * GPK_DB);
+        long long* prof = (p.prof != nullptr && tid == 0) ? p.prof + j * 32 : nullptr;
+        diag3_block<T, false>(S, rdiag, Ab, ld, rem < GPK_DB ? rem : GPK_DB, W, p.info, p.info_off + GPK_DB * j, 0, prof);
+        pipe_publish(p.ctrl + 16 + j, nullptr, 1u);
+        if (prof) prof[16] = (long long)__builtin_readcyclecounter();
+        if (j + 1 >= npb) break;
+
+        // ---- the rows of block j+1:  X = B inv(L_jj)^T ----
+        const int s1 = 2 * (j + 1);
+        const int nstr = (s1 + 1 < R) ? 2 : 1;
+        const int nr = (rem - GPK_DB < GPK_DB) ? rem - GPK_DB : GPK_DB;
+        unsigned* f0 = prog + (int64_t)s1 * npb + j;
+        unsigned* f1 = f0 + npb;
+        if (!pipe_wait(f0, f1, f0, f0, (unsigned)j, (unsigned)j, 0u, 0u, nstr, abort_word, s_ctl)) break;
+        if (prof) prof[17] = (long long)__builtin_readcyclecounter();
+        T* Bp = Ab + (int64_t)GPK_DB * ld;
+        {
+            const int row = 16 * wave + lr;
+            T areg[32];
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) areg[kk] = (row < nr) ? Bp[(int64_t)row * ld + 4 * kk + kq] : T(0);
+            acc_t xa[8];
+#pragma unroll
+            for (int cj = 0; cj < 8; ++cj) xa[cj][0] = xa[cj][1] = xa[cj][2] = xa[cj][3] = T(0);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                // inv(L_jj) is lower triangular: column fragment cj only has k < 16 cj + 16, so k-block kb goes to the fragments kb..7
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int kk = 4 * kb + k4;
+                    T wv[8];
+#pragma unroll
+                    for (int cj = kb; cj < 8; ++cj)       // inv(L_jj)[16 cj + lr][4 kk + kq] (layout: inverse_at)
+                        wv[cj] = (cj == kb) ? rdiag[GPK_DB + (16 * cj + lr) * DP16 + 4 * k4 + kq] : S[(16 * kb + lr) * LDP + 16 * cj + 4 * k4 + kq];
+#pragma unroll
+                    for (int cj = kb; cj < 8; ++cj) xa[cj] = Traits<T>::mfma(areg[kk], wv[cj], xa[cj]);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // (keeps the scheduler from hoisting all 144 operand reads: that spilled)
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with inv(L_jj)
+#pragma unroll
+            for (int cj = 0; cj < 8; ++cj)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * wave + Traits<T>::crow(lane, i), c = 16 * cj + lr;
+                    S[r * LDP + c] = xa[cj][i];
+                    if (r < nr) Bp[(int64_t)r * ld + c] = xa[cj][i];
+                }
+        }
+        pipe_publish(f0, nstr == 2 ? f1 : nullptr, (unsigned)(j + 1));
+        if (prof) prof[18] = (long long)__builtin_readcyclecounter();
+
+        // ---- diagonal block j+1:  S = C - X X^T  (lower tiles), built in LDS ----
+        if (!pipe_wait(f0 + 1, f1 + 1, f0, f0, (unsigned)j, (unsigned)j, 0u, 0u, nstr, abort_word, s_ctl)) break;
+        if (prof) prof[19] = (long long)__builtin_readcyclecounter();
+        T* Cp = Bp + GPK_DB;
+        {
+            constexpr int PER = 5;          // 36 lower tiles over 8 waves
+            int bi[PER], bj[PER];
+            acc_t ca[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int t = (wave + 8 * q < 36) ? wave + 8 * q : 0;
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= t) ++i;
+                bi[q] = i;
+                bj[q] = t - i * (i + 1) / 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 16 * bi[q] + Traits<T>::crow(lane, e), c = 16 * bj[q] + lr;
+                    ca[q][e] = (r < nr && c < nr) ? Cp[(int64_t)r * ld + c] : ((r == c) ? T(1) : T(0));
+                }
+            }
+            const bool five = wave < 4;
+#pragma unroll 4
+            for (int kk = 0; kk < 32; ++kk) {
+                T av[PER], bv[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    av[q] = -S[(16 * bi[q] + lr) * LDP + 4 * kk + kq];
+                    bv[q] = S[(16 * bj[q] + lr) * LDP + 4 * kk + kq];
+                }
+#pragma unroll
+                for (int q = 0; q < PER; ++q)
+                    if (q < 4 || five) ca[q] = Traits<T>::mfma(av[q], bv[q], ca[q]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with X
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+                if (q < 4 || five) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 16 * bi[q] + Traits<T>::crow(lane, e), c = 16 * bj[q] + lr;
+                        S[r * LDP + c] = (c <= r) ? ca[q][e] : T(0);
+                    }
+                }
+            // zeros in the 28 tiles above the diagonal (they held X)
+            for (int t = wave; t < 28; t += D3_WAVES) {
+                int i = 1;
+                while (i * (i + 1) / 2 <= t) ++i;
+                const int jj = t - i * (i - 1) / 2;         // strictly lower (i, jj) -> upper tile (jj, i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[(16 * jj + Traits<T>::crow(lane, e)) * LDP + 16 * i + lr] = T(0);
+            }
+        }
+        __syncthreads();
+        if (prof) prof[20] = (long long)__builtin_readcyclecounter();
+        if (j + 1 >= nd) {       // the last block of the matrix is factorised by a launch of its own: hand it over updated
+            for (int idx = tid; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
+                const int r = idx >> 7, c = idx & 127;
+                if (r < nr && c <= r) Cp[(int64_t)r * ld + c] = S[r * LDP + c];
+            }
+            break;
+        }
+    }
+    if (tid_ == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(p.info, -1);
+}
+
+template <typename T, bool EDGE>
+__device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, int* s_ctl) {
+    const int tid = threadIdx.x;
+    const int npb = p.sh.npb, R = p.sh.R;
+    unsigned* abort_word = p.ctrl + 1;
+    unsigned* prog = p.ctrl + GPK_PIPE_CTRL_HEAD;
+    GemmArgs<T> g;
+    g.lda = p.ld; g.ldc = p.ld; g.ldcin = p.ld;
+    g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
+    g.M = p.m; g.K = GPK_DB;
+    g.tiles_m = R;
+    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
+    g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
+    g.vec_ok = p.vec_ok;
+    int j = 0;
+    for (;;) {
+        if (tid == 0) s_ctl[0] = (int)__hip_atomic_fetch_add(p.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int t = s_ctl[0];
+        if (t >= p.ntasks) return;
+        while (t >= p.off[j + 1]) ++j;
+        const PipeTask tk = pipe_decode(p.sh, j, t - p.off[j]);
+        const T* Pj = p.A + GPK_DB * j;                        // column block j, rows from the top of the panel
+        unsigned* own = prog + (int64_t)tk.s * npb + j;
+        if (tk.cb < 0) {
+            // solve(j, s): the inverse of block j is out, every earlier update of the piece applied
+            if (!pipe_wait(p.ctrl + 16 + j, own, own, own, 1u, (unsigned)j, 0u, 0u, 2, abort_word, s_ctl)) return;
+            g.A = Pj; g.B = p.dinv + (int64_t)j * (GPK_DB * GPK_DB); g.C = const_cast<T*>(Pj); g.Cin = Pj;
+            g.ldb = GPK_DB;
+            g.N = GPK_DB;
+            g.alpha = T(1); g.beta_over_alpha = T(0); g.has_beta = 0;
+            g.tiles_n = 1;
+            gemm_tile<T, GPK_PIPE_STRIP, true, true, EDGE, 2, D3_WAVES, true>(g, tk.s, 0, 0, 0, smem);
+            pipe_publish(own, nullptr, (unsigned)(j + 1));
+        } else {
+            // update(j, s, cb): own strip and the rows of column block cb solved, the previous update of the piece applied
+            unsigned* b0 = prog + (int64_t)(2 * tk.cb) * npb + j;
+            const bool two = 2 * tk.cb + 1 < R;
+            unsigned* piece = prog + (int64_t)tk.s * npb + tk.cb;
+            if (!pipe_wait(own, b0, piece, two ? b0 + npb : own, (unsigned)(j + 1), (unsigned)(j + 1), (unsigned)j, (unsigned)(j + 1),
+                           4, abort_word, s_ctl))
+                return;
+            g.A = Pj; g.B = Pj; g.C = p.A; g.Cin = p.A;
+            g.ldb = p.ld;
+            g.N = p.w;
+            g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
+            g.tiles_n = npb;
+            gemm_tile<T, GPK_PIPE_STRIP, true, true, EDGE, 2, D3_WAVES, false>(g, tk.s, tk.cb, 0, 0, smem);
+            pipe_publish(piece, nullptr, (unsigned)(j + 1));
+        }
+    }
+}
+
+template <typename T, bool EDGE>
+__global__ __launch_bounds__(D3_THREADS, 2) void potrf_pipe_kernel(PipeArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) T S[D3_LDS_ELEMS];
+    __shared__ int s_ctl[4];
+    static_assert(sizeof(T) * D3_LDS_ELEMS >= 2 * 3 * op_bytes(GPK_PIPE_STRIP), "the worker's operand tiles live in the chain's block");
+    if (blockIdx.x == 0) pipe_chain<T>(p, S, s_ctl);
+    else pipe_worker<T, EDGE>(p, reinterpret_cast<char*>(S), s_ctl);
 }
 
 long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
@@ -763,6 +1091,7 @@ struct PanelCtx {
     int* info;
     hipStream_t stream;
     int info_base;
+    int max_wgs = 0;   // workgroups a persistent launch on `stream` may count on at once (0: every CU of the device; a CU-masked stream: its CUs)
 };
 
 // Factor the panel columns [c0, c0 + w) (rows c0..n), all updates from columns
@@ -829,8 +1158,85 @@ int potrf_panel_fused(const PanelCtx<T>& x, int64_t c0, int64_t w) {
 }
 int g_fused_step = 1;              // tuning knob (gpk_tune(32, v)): single matrices take potrf_panel_fused
 
+int g_pipe = 0;                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
+int g_pipe_cus = 0;                // CUs of the current device (queried once)
+
+// The same panel in ONE launch (potrf_pipe_kernel) -- plus a memset of its control words and, when the panel reaches the last row of
+// the matrix, the diagonal-block kernel for the last block (the control words live in the `dinv` slot of the first diagonal block
+// the kernel does NOT factorise: the block behind the panel, or that last block).  GPK_OK + *done = false: the shape does not fit
+// (more than GPK_PIPE_MAX_BLOCKS blocks, control words beyond one slot), nothing was enqueued.
+template <typename T>
+int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done) {
+    *done = false;
+    const int64_t ke = (c0 + w < x.n) ? c0 + w : x.n;
+    const int64_t m = x.n - c0;
+    const bool last = (ke == x.n);
+    PipeShape sh;
+    sh.npb = (int)gpk_cdiv(ke - c0, GPK_DB);
+    sh.nd = last ? sh.npb - 1 : sh.npb;
+    sh.R = (int)gpk_cdiv(m, GPK_PIPE_STRIP);
+    if (sh.nd < 1 || sh.npb > GPK_PIPE_MAX_BLOCKS) return GPK_OK;
+    const int64_t words = pipe_ctrl_words(sh);
+    if (words * (int64_t)sizeof(unsigned) > (int64_t)GPK_DB * GPK_DB * (int64_t)sizeof(T)) return GPK_OK;
+    PipeArgs<T> pa;
+    pa.A = x.A + c0 * x.ld + c0;
+    pa.ld = x.ld;
+    pa.m = (int)m;
+    pa.w = (int)(ke - c0);
+    pa.sh = sh;
+    pa.dinv = x.dinv + (c0 / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
+    pa.ctrl = reinterpret_cast<unsigned*>(pa.dinv + (int64_t)sh.nd * (GPK_DB * GPK_DB));
+    pa.info = x.info;
+    pa.info_off = (int)c0 + x.info_base;
+    constexpr int VEC = Traits<T>::VEC;
+    const bool aligned = ((uintptr_t)pa.A % 16 == 0) && ((uintptr_t)pa.dinv % 16 == 0) && (x.ld % VEC == 0);
+    pa.vec_ok = aligned ? 1 : 0;
+    pa.off[0] = 0;
+    for (int j = 0; j < sh.nd; ++j) pa.off[j + 1] = pa.off[j] + pipe_step_tasks(sh, j);
+    for (int j = sh.nd + 1; j <= GPK_PIPE_MAX_BLOCKS; ++j) pa.off[j] = pa.off[sh.nd];
+    pa.ntasks = pa.off[sh.nd];
+    pa.prof = g_diag_prof != nullptr ? g_diag_prof + (c0 / GPK_DB) * 32 : nullptr;
+    int cus = x.max_wgs;
+    if (cus <= 0) {
+        if (g_pipe_cus == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 2)
+                return GPK_ERR_LAUNCH;
+            g_pipe_cus = v;
+        }
+        cus = g_pipe_cus;
+    }
+    // one workgroup per CU (the chain's block fills the LDS); never more workers than the first, largest step has tasks (+ a few
+    // that run ahead into the next step)
+    int64_t workers = (int64_t)pipe_step_tasks(sh, 0) + 8;
+    if (workers > cus - 1) workers = cus - 1;
+    if (workers < 1) workers = 1;
+    if (pa.ntasks == 0) workers = 0;
+    if (hipMemsetAsync(pa.ctrl, 0, (size_t)words * sizeof(unsigned), x.stream) != hipSuccess) return GPK_ERR_LAUNCH;
+    const bool edge = !aligned || (m % GPK_PIPE_STRIP) || ((ke - c0) % GPK_DB);
+    if (edge) hipLaunchKernelGGL((potrf_pipe_kernel<T, true>), dim3((unsigned)(1 + workers)), dim3(D3_THREADS), 0, x.stream, pa);
+    else hipLaunchKernelGGL((potrf_pipe_kernel<T, false>), dim3((unsigned)(1 + workers)), dim3(D3_THREADS), 0, x.stream, pa);
+    GPK_CHECK_LAUNCH();
+    if (last) {
+        DiagArgs<T> d;
+        d.A = x.A; d.ld = x.ld; d.bstride = x.bstride; d.off = c0 + (int64_t)sh.nd * GPK_DB; d.n = (int)x.n;
+        d.dinv = x.dinv; d.dinv_bstride = x.dstride; d.info = x.info; d.info_base = x.info_base;
+        d.prof = g_diag_prof;
+        d.zero_next = 0;
+        launch_diag<T>(d, 1u, x.stream);
+        GPK_CHECK_LAUNCH();
+    }
+    *done = true;
+    return GPK_OK;
+}
+
 template <typename T>
 int potrf_panel_any(const PanelCtx<T>& x, int64_t c0, int64_t w) {
+    if (g_pipe && g_diag_v2 && x.batch == 1 && x.dinv != nullptr && x.n - c0 > GPK_DB) {
+        bool done = false;
+        const int st = potrf_panel_pipe<T>(x, c0, w, &done);
+        if (st || done) return st;
+    }
     // the flag words of a step (one per strip of 32 rows below it, 1024 at most) need the dinv slot of the next block: n < 32768
     if (g_fused_step && x.batch == 1 && x.dinv != nullptr && x.n - c0 <= 32768) return potrf_panel_fused<T>(x, c0, w);
     return potrf_panel<T>(x, c0, w);
@@ -933,12 +1339,12 @@ hipEvent_t la_event(LaDevice& d, size_t i) {
 
 template <typename T>
 int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tmp, int* info, int64_t j,
-             hipStream_t s) {
+             hipStream_t s, int max_wgs = 0) {
     const int64_t k0 = j * nb;
     const int64_t w = (n - k0 < nb) ? n - k0 : nb;
     T* Ab = A + k0 * ld + k0;
     T* d128 = dinv128 + (k0 / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
-    PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0};
+    PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0, max_wgs};
     int st = potrf_panel_any<T>(sub, 0, nb);
     if (st) return st;
     return gpk_trtri_merge_launch<T>(Ab, w, ld, 1, 0, d128, nb, dinv_big + j * (int64_t)nb * nb, tmp, s);
@@ -973,6 +1379,7 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 11) g_la_strip_last = (int)value;
     if (key == 30) g_diag_v2 = (int)value;
     if (key == 32) g_fused_step = (int)value;
+    if (key == 37) g_pipe = (int)value;
 }
 
 #define GPK_LA_PAD 16
@@ -1103,7 +1510,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             }
             if (overlap) {
                 if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-                const int s2 = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux);
+                const int s2 = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux, 8);
                 if (s2) return s2;
                 if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
                     return gpk_gemm_persist_rejoin<T>(&saved, dev->aux);

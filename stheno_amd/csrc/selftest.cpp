@@ -1487,11 +1487,12 @@ static void cumask_experiment() {
 }
 
 template <typename T>
-static void diag_phase_profile(int n, int ver) {
+static void diag_phase_profile(int n, int ver, int pipe = 0) {
     const int nblk = (n + 127) / 128;
     Dev<long long> prof((size_t)nblk * 32);
     prof.zero();
     gpk_tune(30, ver);
+    gpk_tune(37, pipe);
     gpk_tune_diag_prof(prof.p);
     profile_one<T>(n, 0, 1);
     gpk_tune_diag_prof(nullptr);
@@ -1505,8 +1506,45 @@ static void diag_phase_profile(int n, int ver) {
             const long long* q = &h[(size_t)blk * 32];
             printf("DIAGPROF3 %s blk %d cycles: load %lld | panel0 %lld | steps", DT<T>::name(), blk, q[1] - q[0], q[2] - q[1]);
             for (int s = 0; s < 7; ++s) printf(" %lld", q[3 + s] - q[2 + s]);
-            printf(" | storeL %lld | inv16 %lld | merges %lld | storeW %lld | total %lld\n", q[10] - q[9], q[11] - q[10], q[12] - q[11], q[13] - q[12], q[13] - q[0]);
+            printf(" | storeL %lld | inverse: row block 6 + tile 7 %lld, row block 7 %lld | storeW %lld | total %lld\n", q[10] - q[9], q[11] - q[10], q[12] - q[11], q[13] - q[12], q[13] - q[0]);
+            if (pipe && q[20] > q[13] && blk + 1 < nblk)      // the chain workgroup of the pipelined panel: what follows the block until the next one starts
+                printf("PIPEPROF %s blk %d cycles: publish inv %lld | wait rows %lld | X = B inv^T %lld | wait block %lld | S = C - X X^T %lld | step period %lld\n",
+                       DT<T>::name(), blk, q[16] - q[13], q[17] - q[16], q[18] - q[17], q[19] - q[18], q[20] - q[19], q[32] - q[0]);
         }
+    }
+    gpk_tune(37, 1);
+}
+
+// --perf-pipe: the factorisation of small / chain-bound matrices with and without the pipelined panel kernel, at several outer
+// block widths (nbo = n: the whole matrix is ONE pipelined panel)
+template <typename T>
+static void perf_pipe() {
+    Timer tm;
+    for (int n : {1024, 2048, 4096, 8192}) {
+        const int d = 8;
+        auto hx = randv<T>((size_t)n * d);
+        Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n));
+        Dev<int> info(1);
+        X.up(hx);
+        int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+        for (int pipe = 0; pipe < 2; ++pipe) {
+            gpk_tune(37, pipe);
+            for (int nbo : {256, 512, 1024, 2048, 4096, 8192}) {
+                if (nbo > n || (!pipe && nbo > 1024)) continue;
+                float best = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    info.zero();
+                    gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+                    tm.start();
+                    gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, nbo, nullptr);
+                    const float ms = tm.stop();
+                    if (rep && ms < best) best = ms;
+                }
+                printf("PERFPIPE potrf_%s n=%d nbo=%d pipe=%d  %.3f ms  %.2f TFLOP/s info=%d\n", DT<T>::name(), n, nbo, pipe, best,
+                       (double)n * n * n / 3.0 / best * 1e-9, info.down()[0]);
+            }
+        }
+        gpk_tune(37, 1);
     }
 }
 
@@ -1573,9 +1611,9 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--mfmapeak")) { mfma_peak(); return 0; }
         if (!strcmp(argv[i], "--diagprof") && i + 1 < argc) {
             rsq_precision();
-            for (int ver = 0; ver < 2; ++ver) {
-                diag_phase_profile<double>(atoi(argv[i + 1]), ver);
-                diag_phase_profile<float>(atoi(argv[i + 1]), ver);
+            for (int ver = 0; ver < 3; ++ver) {      // old kernel, 512-thread kernel, the same inside the pipelined panel
+                diag_phase_profile<double>(atoi(argv[i + 1]), ver > 0, ver == 2);
+                diag_phase_profile<float>(atoi(argv[i + 1]), ver > 0, ver == 2);
             }
             return 0;
         }
@@ -1593,6 +1631,7 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--census")) { census(); return 0; }
         if (!strcmp(argv[i], "--perf-kmat")) { perf_kmat(); return 0; }
+        if (!strcmp(argv[i], "--perf-pipe")) { perf_pipe<double>(); perf_pipe<float>(); return 0; }
         if (!strcmp(argv[i], "--perf-trsm")) { perf_trsm<double>(16384, 2048); perf_trsm<float>(32768, 2048); return 0; }
         if (!strcmp(argv[i], "--kmat")) {                      // only the kernel-matrix checks, both kernels
             for (int band = 1; band >= 0; --band) { gpk_tune(12, band); test_kmat<double>(); test_kmat<float>(); }
