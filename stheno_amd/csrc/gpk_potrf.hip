@@ -476,6 +476,8 @@ __device__ __forceinline__ int panel_waves(int s) { return s == 0 ? 3 : (s <= 3 
 
 // micro-panel s by wave `pw` (0 .. panel_waves(s) - 1): lanes 0..15 = rows of the diagonal tile, lane group g = 1..3 = rows of tile
 // s + 3 pw + g (idle past tile 7).  Wave 0 writes the diagonal tile, the reciprocal pivots and reports a non-positive pivot.
+// (Writing the finished columns to global memory from here, out of the registers they sit in, was measured: +1.3k cycles per
+// micro-step on the critical wave.  A wave with nothing else to do stores them one step later: store_l_columns.)
 template <typename T>
 __device__ __forceinline__ void panel_chol(T* __restrict__ S, T* __restrict__ rdiag, int s, int pw, int lane, int* info, int off) {
     const int lr = lane & 15, g = lane >> 4;
@@ -512,25 +514,80 @@ __device__ __forceinline__ void panel_chol(T* __restrict__ S, T* __restrict__ rd
     }
 }
 
+// Columns 16 s .. 16 s + 15 of the finished factor (rows 16 s .. 127, lower triangle only) from LDS to global memory, by ONE wave:
+// fire-and-forget stores in the shadow of a later micro-panel instead of a write-back pass of the whole block after the
+// factorisation (4.4k cycles of the kernel).  Only for full, 16-byte-aligned blocks (the caller keeps the write-back pass for the
+// others).  A lone wave retires an instruction every ~5 cycles and a 1 KiB store costs it ~20 (scripts/dev/store_cost.hip): the
+// loop is three instructions per 8 (16) rows -- 16 / VEC lanes cover the 16 columns of a row with one 16-byte store each.
+template <typename T>
+__device__ __forceinline__ void store_l_columns(const T* __restrict__ S, T* __restrict__ Ag, int64_t ld, int s, int lane) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int LPR = 16 / VEC, RPP = 64 / LPR;
+    const int c0 = 16 * s;
+    const int sub = lane / LPR, c = c0 + (lane % LPR) * VEC;
+    // the diagonal tile: nothing above the diagonal
+#pragma unroll
+    for (int i = 0; i < 16 / RPP; ++i) {
+        const int row = c0 + sub + RPP * i;
+        T* __restrict__ dst = Ag + (int64_t)row * ld + c;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const T x = S[row * LDP + c + v];
+            if (c + v <= row) dst[v] = x;
+        }
+    }
+    // the rows below it: whole 16-byte vectors
+    const T* src = S + (c0 + 16 + sub) * LDP + c;
+    T* __restrict__ dst = Ag + (int64_t)(c0 + 16 + sub) * ld + c;
+    for (int row = c0 + 16; row < GPK_DB; row += RPP) {      // (uniform trip count)
+        vec_t w;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) w[v] = src[v];
+        *reinterpret_cast<vec_t*>(dst) = w;
+        src += RPP * LDP;
+        dst += RPP * ld;
+    }
+}
+
+// the 28 zero tiles of inv(L) above the diagonal in global memory, by one wave (a handful of instructions per tile)
+template <typename T>
+__device__ __forceinline__ void store_w_zero_tiles(T* __restrict__ Wg, int lane) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int LPR = 16 / VEC, RPP = 64 / LPR;
+    vec_t z;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) z[v] = T(0);
+    T* __restrict__ base = Wg + (int64_t)(lane / LPR) * GPK_DB + (lane % LPR) * VEC;
+    for (int tr = 0; tr < 7; ++tr)
+        for (int tc = tr + 1; tc < 8; ++tc) {
+            T* __restrict__ dst = base + (int64_t)(16 * tr) * GPK_DB + 16 * tc;
+#pragma unroll
+            for (int i = 0; i < 16 / RPP; ++i) *reinterpret_cast<vec_t*>(dst + (int64_t)(RPP * i) * GPK_DB) = z;
+        }
+}
+
 // ---- the inverse of the block, grown during its factorisation ----
 // inv(L) is built ROW BLOCK by row block (16 rows): row block r only needs the rows 0..r of L, which are final as soon as micro-panel
 // r has been factorised, and the row blocks of inv(L) above it:
 //     W_rr = inv(L_rr)                                     one 16-lane group, substitution (the reciprocal pivots are at hand)
 //     W_rc = -W_rr  sum_{k=c}^{r-1} L_rk W_kc      c < r   one wave per tile: a chain of 4 (r - c) + 4 MFMAs
 // so row block s-1 is computed in the shadow of the factorisation of micro-panel s+1, by waves that would otherwise wait at the
-// barrier (the panel chain is one wave; the rank-16 updates of the others take a fraction of its time), and only the last two row
-// blocks are left when the factorisation ends: ~9k cycles instead of the ~21k of inverting the finished block by recursive doubling
-// (three levels of two dependent products each, eight barriers) -- measured in profiles/r03_experiments.md.
+// barrier (the panel chain is one wave; the rank-16 updates of the others take a fraction of its time).  When the factorisation
+// ends, row blocks 6 and 7 are left; they are computed TOGETHER: the sums over k <= 5 of both rows at once (thirteen jobs dealt to
+// the eight waves, six MFMA groups each), then row 7 only adds its k = 6 term -- ~6k cycles instead of the ~21k of inverting the
+// finished block by recursive doubling (three levels of two dependent products each, eight barriers).
 // Storage: the strictly-lower tiles W_rc go where S has nothing -- ABOVE the diagonal, at tile position (c, r), untransposed inside
-// the tile -- and the diagonal tiles W_rr into D16 (pitch DP16: conflict-free as MFMA operand); inverse_at() reads the result back.
-// The long chains are given to waves that do not share a SIMD with the panel wave (wave w runs on SIMD w % 4; wave 0, and wave 1
-// while two waves factorise, hold the dependent scalar chain of the panel).
+// the tile -- and the diagonal tiles W_rr into D16 (pitch DP16: conflict-free as MFMA operand).  Every tile also goes straight to
+// global memory from the wave that computed it (Wg, 128 x 128 row-major; the zero tiles above the diagonal are written up front): no
+// write-back pass.  The long chains are given to waves that do not share a SIMD with the panel wave (wave w runs on SIMD w % 4).
 constexpr int DP16 = 18;
 constexpr int D3_LDS_ELEMS = GPK_DB * LDP + GPK_DB + 8 * 16 * DP16;
 
+// inv(L)[r][c] from the LDS image (the pipelined panel's chain reads its operand this way)
 template <typename T>
 __device__ __forceinline__ T inverse_at(const T* __restrict__ S, int r, int c) {
-    // one LDS read at a selected index (the tiles of a wave's lanes differ: branches here cost 4x the whole write-back)
     const int tr = r >> 4, tc = c >> 4;
     const int lower = (16 * tc + (r & 15)) * LDP + 16 * tr + (c & 15);
     const int diag = GPK_DB * LDP + GPK_DB + r * DP16 + (c & 15);       // D16 sits behind the block and the reciprocal pivots
@@ -541,8 +598,7 @@ __device__ __forceinline__ T inverse_at(const T* __restrict__ S, int r, int c) {
 // W_qq = inv(L_qq) by lanes 0..15 of the calling wave: lane lr solves for column lr of the inverse, right-looking (x_i is final once
 // the columns before it have been applied; column i + 1 of L is requested while column i is applied)
 template <typename T>
-__device__ __forceinline__ void inverse_diag_tile(const T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, int q, int lane) {
-    if (lane >= 16) return;
+__device__ __forceinline__ void inverse_diag_tile_lanes(const T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, int q, int lane) {
     const int c0 = 16 * q, lr = lane;
     T x[16], v[16], rd[16], col[2][16];
 #pragma unroll
@@ -566,10 +622,30 @@ __device__ __forceinline__ void inverse_diag_tile(const T* __restrict__ S, const
     for (int i = 0; i < 16; ++i) D16[(c0 + i) * DP16 + lr] = x[i];     // (zeros above the diagonal)
 }
 
-// W_rc (c < r) by the calling wave.  The final product takes the accumulator AS the B operand: register i of lane group g holds row
-// crow(lane, i) of the sum, so MFMA step i contracts over k = crow(lane, i) with A = -W_rr[lr][k] -- no layout change needed.
+// a finished diagonal tile of the inverse from D16 to global memory, by the whole wave (4 elements per lane)
 template <typename T>
-__device__ __forceinline__ void inverse_tile(T* __restrict__ S, const T* __restrict__ D16, int r, int c, int lane, int lr, int kq) {
+__device__ __forceinline__ void store_w_diag_tile(const T* __restrict__ D16, T* __restrict__ Wg, int q, int lane) {
+    const int r = 16 * q + (lane >> 2), c = (lane & 3) * 4;
+    T w[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w[v] = D16[r * DP16 + c + v];
+    T* __restrict__ dst = Wg + (int64_t)r * GPK_DB + 16 * q + c;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) dst[v] = w[v];
+}
+
+template <typename T>
+__device__ __forceinline__ void inverse_diag_tile(const T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16,
+                                                  T* __restrict__ Wg, int q, int lane) {
+    if (lane < 16) inverse_diag_tile_lanes<T>(S, rdiag, D16, q, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    store_w_diag_tile<T>(D16, Wg, q, lane);
+}
+
+// sum_{k=c}^{kend-1} L_rk W_kc  (c < kend <= r) by the calling wave, as an accumulator tile
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::acc_t inverse_partial(const T* __restrict__ S, const T* __restrict__ D16, int r, int c,
+                                                                     int kend, int lr, int kq) {
     typedef typename Traits<T>::acc_t acc_t;
     acc_t a0, a1;
     a0[0] = a0[1] = a0[2] = a0[3] = T(0);
@@ -582,11 +658,11 @@ __device__ __forceinline__ void inverse_tile(T* __restrict__ S, const T* __restr
         av[0][kk] = S[(16 * r + lr) * LDP + 16 * c + 4 * kk + kq];
         bv[0][kk] = D16[(16 * c + 4 * kk + kq) * DP16 + lr];
     }
-    for (int k = c; k < r; k += 2) {
+    for (int k = c; k < kend; k += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (k + h < r) {
-                if (k + h + 1 < r) {
+            if (k + h < kend) {
+                if (k + h + 1 < kend) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         av[1 - h][kk] = S[(16 * r + lr) * LDP + 16 * (k + h + 1) + 4 * kk + kq];
@@ -600,27 +676,85 @@ __device__ __forceinline__ void inverse_tile(T* __restrict__ S, const T* __restr
             }
         }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] += a1[i];
+    return a0;
+}
+
+// sum += L_rk W_kc for ONE k (c <= k < r)
+template <typename T>
+__device__ __forceinline__ typename Traits<T>::acc_t inverse_term(const T* __restrict__ S, const T* __restrict__ D16, int r, int c, int k,
+                                                                  typename Traits<T>::acc_t sum, int lr, int kq) {
+    T av[4], bv[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        av[kk] = S[(16 * r + lr) * LDP + 16 * k + 4 * kk + kq];
+        bv[kk] = (k == c) ? D16[(16 * c + 4 * kk + kq) * DP16 + lr] : S[(16 * c + 4 * kk + kq) * LDP + 16 * k + lr];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) sum = Traits<T>::mfma(av[kk], bv[kk], sum);
+    return sum;
+}
+
+// W_rc = -W_rr sum, to LDS and to global memory.  The product takes the accumulator AS the B operand: register i of lane group g
+// holds row crow(lane, i) of the sum, so MFMA step i contracts over k = crow(lane, i) with A = -W_rr[lr][k] -- no layout change.
+template <typename T>
+__device__ __forceinline__ void inverse_finish(T* __restrict__ S, const T* __restrict__ D16, T* __restrict__ Wg, int r, int c,
+                                               typename Traits<T>::acc_t sum, int lane, int lr) {
+    typedef typename Traits<T>::acc_t acc_t;
     acc_t out;
     out[0] = out[1] = out[2] = out[3] = T(0);
     T wr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) wr[i] = -D16[(16 * r + lr) * DP16 + Traits<T>::crow(lane, i)];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) out = Traits<T>::mfma(wr[i], a0[i] + a1[i], out);
+    for (int i = 0; i < 4; ++i) out = Traits<T>::mfma(wr[i], sum[i], out);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) S[(16 * c + Traits<T>::crow(lane, i)) * LDP + 16 * r + lr] = out[i];
+    for (int i = 0; i < 4; ++i) {
+        const int a = Traits<T>::crow(lane, i);
+        S[(16 * c + a) * LDP + 16 * r + lr] = out[i];
+        Wg[(int64_t)(16 * r + a) * GPK_DB + 16 * c + lr] = out[i];
+    }
 }
 
-// The calling wave's share of: the tiles (row, 0 .. row-1) of the inverse (row < 0: none) and the diagonal tiles `diag`, `diag2` (< 0:
-// none).  Jobs in order of length (tile 0 first, the diagonal tiles last) go to the waves 7, 3, 6, 2, 5, 1, 4, 0.
+// The calling wave's share of: the tiles of the row blocks row_lo .. row_hi of the inverse (none if row_hi < 1) and the diagonal tiles
+// diag_lo .. diag_hi (none if diag_hi < diag_lo).  Column c of the rows is ONE job (its tiles depend on each other downwards), the
+// jobs go in order of length -- column 0 first, the diagonal tiles last -- to the waves 7, 3, 6, 2, 5, 1, 4, 0.
 template <typename T>
-__device__ __forceinline__ void inverse_jobs(T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, int row, int diag,
-                                             int diag2, int wave, int lane, int lr, int kq) {
+__device__ __forceinline__ void inverse_jobs(T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, T* __restrict__ Wg,
+                                             int row_lo, int row_hi, int diag_lo, int diag_hi, int wave, int lane, int lr, int kq) {
     const int slot = (wave & 3) == 3 ? (wave == 7 ? 0 : 1) : ((wave & 3) == 2 ? (wave == 6 ? 2 : 3) : ((wave & 3) == 1 ? (wave == 5 ? 4 : 5) : (wave == 4 ? 6 : 7)));
-    const int ntile = row > 0 ? row : 0;
-    if (slot < ntile) inverse_tile<T>(S, D16, row, slot, lane, lr, kq);
-    else if (slot == ntile && diag >= 0) inverse_diag_tile<T>(S, rdiag, D16, diag, lane);
-    else if (slot == ntile + 1 && diag2 >= 0) inverse_diag_tile<T>(S, rdiag, D16, diag2, lane);
+    const int ncol = row_hi > 0 ? row_hi : 0;
+    if (slot < ncol) {
+        for (int r = (row_lo > slot + 1 ? row_lo : slot + 1); r <= row_hi; ++r) {
+            inverse_finish<T>(S, D16, Wg, r, slot, inverse_partial<T>(S, D16, r, slot, r, lr, kq), lane, lr);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the next row reads this tile back
+        }
+    } else if (diag_lo + (slot - ncol) <= diag_hi) {
+        inverse_diag_tile<T>(S, rdiag, D16, Wg, diag_lo + (slot - ncol), lane);
+    }
+}
+
+// Row blocks 6 and 7 together, all eight waves.  Part A: P6_c = sum_{k=c}^{5} L_6k W_kc and P7_c likewise (c = 0..5; 6 - c MFMA
+// groups each), dealt so that every wave has six groups; row 6 is finished at once (W_66 is there), P7 stays in registers.  Barrier.
+// Part B: the holder of P7_c adds L_76 W_6c and finishes W_7c; wave 0 computes W_76.
+//   wave:   0      1      2           3           4           5           6           7
+//   A:     P6_0   P7_0   P6_1 P7_5   P7_1 P6_5   P6_2 P7_4   P7_2 P6_4   P6_3 P7_3   W_77
+//   B:     W_76   W_70   W_75        W_71        W_74        W_72        W_73        -
+template <typename T>
+__device__ __forceinline__ void inverse_last_rows(T* __restrict__ S, const T* __restrict__ rdiag, T* __restrict__ D16, T* __restrict__ Wg,
+                                                  int wave, int lane, int lr, int kq) {
+    typedef typename Traits<T>::acc_t acc_t;
+    const int c6 = wave == 0 ? 0 : (wave == 2 ? 1 : (wave == 3 ? 5 : (wave == 4 ? 2 : (wave == 5 ? 4 : (wave == 6 ? 3 : -1)))));
+    const int c7 = wave == 1 ? 0 : (wave == 2 ? 5 : (wave == 3 ? 1 : (wave == 4 ? 4 : (wave == 5 ? 2 : (wave == 6 ? 3 : -1)))));
+    acc_t p7;
+    p7[0] = p7[1] = p7[2] = p7[3] = T(0);
+    if (wave == 7) inverse_diag_tile<T>(S, rdiag, D16, Wg, 7, lane);
+    if (c6 >= 0) inverse_finish<T>(S, D16, Wg, 6, c6, inverse_partial<T>(S, D16, 6, c6, 6, lr, kq), lane, lr);
+    if (c7 >= 0) p7 = inverse_partial<T>(S, D16, 7, c7, 6, lr, kq);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int cb = wave == 0 ? 6 : c7;
+    if (cb >= 0) inverse_finish<T>(S, D16, Wg, 7, cb, inverse_term<T>(S, D16, 7, cb, 6, p7, lr, kq), lane, lr);
 }
 
 // One 128x128 diagonal block by the calling workgroup (D3_THREADS threads): A = the block's first element (leading dimension ld),
@@ -634,9 +768,8 @@ __device__ __forceinline__ void diag3_block(T* __restrict__ S, T* __restrict__ r
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));        // (called from a loop: nothing derived from the thread index is worth keeping across iterations -- hoisted, it spills)
     T* __restrict__ D16 = rdiag + GPK_DB;
-    const int lane = tid & 63;
+    const int lane_fixed = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, kq = lane >> 4;
 
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
@@ -684,81 +817,71 @@ __device__ __forceinline__ void diag3_block(T* __restrict__ S, T* __restrict__ r
     if (LOAD) __syncthreads();
     if (prof) prof[1] = (long long)__builtin_readcyclecounter();
 
-    // ---- phase 1: factorise; the inverse grows row block by row block in the shadow of the panel factorisations ----
+    // ---- phase 1: factorise; every finished micro-panel leaves for global memory at once; the inverse grows row block by row
+    //      block in the shadow of the panel factorisations ----
     {
         const int np = panel_waves(0);
-        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane, info, info_off);
+        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane_fixed, info, info_off);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only, here and below: global stores are in flight and nobody waits for them)
     if (prof) prof[2] = (long long)__builtin_readcyclecounter();
     for (int s = 0; s < 7; ++s) {
         const int c0 = 16 * s;
+        // (the per-lane LDS offsets and global addresses of the jobs below are loop-invariant expressions of the lane index: hoisted
+        // out of this loop they spill -- 376 bytes of scratch per lane and a scratch reload + vmcnt(0) before every store, measured)
+        int lane = lane_fixed;
+        asm volatile("" : "+v"(lane));
+        const int lr = lane & 15, kq = lane >> 4;
         // (U1) micro-column s+1 by column s: 7 - s tiles, one per wave
         rank16_update<T>(S, c0, 0, s, 7 - s, wave, D3_WAVES, lane, lr, kq);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (prof) prof[21 + s] = (long long)__builtin_readcyclecounter();
         // panel s+1 on its waves  ||  (U2) column s applied to the remaining tiles on the others, then their share of the inverse
         const int np = panel_waves(s + 1);
         if (wave < np) {
             panel_chol<T>(S, rdiag, s + 1, wave, lane, info, info_off);
         } else {
             rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - np, D3_WAVES - np, lane, lr, kq);
-            // (step 0 is bound by its 21 trailing tiles, not by the panel: the first diagonal tile waits for step 1)
-            if (W != nullptr && s > 0) inverse_jobs<T>(S, rdiag, D16, s - 1, s, s == 1 ? 0 : -1, wave, lane, lr, kq);
-        }
-        __syncthreads();
-        if (prof) prof[3 + s] = (long long)__builtin_readcyclecounter();
-    }
-
-    // ---- phase 2: write L (lower triangle only; the upper triangle is never touched) ----
-    if (vec_io) {
-        vec_t wbuf[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + D3_THREADS * i;
-            const int r = id / CPR, c = (id % CPR) * VEC;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) wbuf[i][v] = S[r * LDP + c + v];
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + D3_THREADS * i;
-            const int r = id / CPR, c = (id % CPR) * VEC;
-            if (c + VEC - 1 <= r) {
-                *reinterpret_cast<vec_t*>(A + (int64_t)r * ld + c) = wbuf[i];
-            } else if (c <= r) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    if (c + v <= r) A[(int64_t)r * ld + c + v] = wbuf[i][v];
+            // Steps 0 and 1 are bound by their 21 / 15 trailing tiles, not by the panel: the inverse starts in step 2 (diagonal tiles
+            // 0..2), step 3 takes row blocks 1 and 2 (+ diagonal tile 3), step s >= 4 row block s - 1 (+ diagonal tile s).  The
+            // finished columns of L leave from step 3 on, through waves without a share of the inverse.
+            if (W != nullptr) {
+                if (s == 2) inverse_jobs<T>(S, rdiag, D16, W, 0, 0, 0, 2, wave, lane, lr, kq);
+                else if (s == 3) inverse_jobs<T>(S, rdiag, D16, W, 1, 2, 3, 3, wave, lane, lr, kq);
+                else if (s >= 4) inverse_jobs<T>(S, rdiag, D16, W, s - 1, s - 1, s, s, wave, lane, lr, kq);
+            }
+            if (vec_io) {
+                int col = -1;
+                if (s == 3) col = wave == 4 ? 0 : (wave == 5 ? 1 : (wave == 1 ? 2 : (wave == 2 ? 3 : -1)));
+                else if (s >= 4 && wave == 4) col = s;
+                if (col >= 0) store_l_columns<T>(S, A, ld, col, lane);
+            }
+            if (W != nullptr && s == 4 && wave == 1) {     // the zero tiles of inv(L) above the diagonal (the diagonal tiles bring their own zeros)
+                store_w_zero_tiles<T>(W, lane);
             }
         }
-    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (prof) prof[3 + s] = (long long)__builtin_readcyclecounter();
+    }
+    int lane = lane_fixed;
+    asm volatile("" : "+v"(lane));
+    if (!vec_io) {
+        // ragged or unaligned block: the write-back pass (lower triangle only; the upper triangle is never touched)
         for (int idx = tid; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
             const int r = idx >> 7, c = idx & 127;
             if (r < nv && c <= r) A[(int64_t)r * ld + c] = S[r * LDP + c];
         }
     }
-    if (W == nullptr) return;
+    if (W == nullptr) {
+        if (vec_io && wave == 4) store_l_columns<T>(S, A, ld, 7, lane);
+        return;
+    }
     if (prof) prof[10] = (long long)__builtin_readcyclecounter();
 
-    // ---- phase 3: the last two row blocks of the inverse (the write-back above only reads the lower triangle of S, the jobs
-    //      below only write above it and into D16: no barrier in between, and none that would wait for the stores to retire) ----
-    inverse_jobs<T>(S, rdiag, D16, 6, 7, -1, wave, lane, lr, kq);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (prof) prof[11] = (long long)__builtin_readcyclecounter();
-    inverse_jobs<T>(S, rdiag, D16, 7, -1, -1, wave, lane, lr, kq);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- phase 2: the last two row blocks of the inverse; the last diagonal tile of L ----
+    inverse_last_rows<T>(S, rdiag, D16, W, wave, lane, lane & 15, lane >> 4);
+    if (vec_io && wave == 7) store_l_columns<T>(S, A, ld, 7, lane);
     if (prof) prof[12] = (long long)__builtin_readcyclecounter();
-
-    // ---- phase 4: write inv(L) (identity-padded, zeros above the diagonal) ----
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int id = tid + D3_THREADS * i;
-        const int r = id / CPR, c = (id % CPR) * VEC;
-        vec_t w;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) w[v] = inverse_at<T>(S, r, c + v);
-        *reinterpret_cast<vec_t*>(W + (int64_t)r * GPK_DB + c) = w;
-    }
     if (zero_next && tid < 256) {
         uint4* z = reinterpret_cast<uint4*>(W + (int64_t)GPK_DB * GPK_DB);
         z[tid] = make_uint4(0u, 0u, 0u, 0u);

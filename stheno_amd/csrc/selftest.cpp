@@ -1506,13 +1506,16 @@ static void diag_phase_profile(int n, int ver, int pipe = 0) {
             const long long* q = &h[(size_t)blk * 32];
             printf("DIAGPROF3 %s blk %d cycles: load %lld | panel0 %lld | steps", DT<T>::name(), blk, q[1] - q[0], q[2] - q[1]);
             for (int s = 0; s < 7; ++s) printf(" %lld", q[3 + s] - q[2 + s]);
-            printf(" | storeL %lld | inverse: row block 6 + tile 7 %lld, row block 7 %lld | storeW %lld | total %lld\n", q[10] - q[9], q[11] - q[10], q[12] - q[11], q[13] - q[12], q[13] - q[0]);
+            printf(" | last two row blocks of the inverse %lld | total %lld\n", q[12] - q[10], q[13] - q[0]);
+            printf("DIAGPROF3 %s blk %d   of which column update before the panel (U1):", DT<T>::name(), blk);
+            for (int s = 0; s < 7; ++s) printf(" %lld", q[21 + s] - q[2 + s]);
+            printf("\n");
             if (pipe && q[20] > q[13] && blk + 1 < nblk)      // the chain workgroup of the pipelined panel: what follows the block until the next one starts
                 printf("PIPEPROF %s blk %d cycles: publish inv %lld | wait rows %lld | X = B inv^T %lld | wait block %lld | S = C - X X^T %lld | step period %lld\n",
                        DT<T>::name(), blk, q[16] - q[13], q[17] - q[16], q[18] - q[17], q[19] - q[18], q[20] - q[19], q[32] - q[0]);
         }
     }
-    gpk_tune(37, 1);
+    gpk_tune(37, 0);
 }
 
 // --perf-pipe: the factorisation of small / chain-bound matrices with and without the pipelined panel kernel, at several outer
@@ -1544,7 +1547,7 @@ static void perf_pipe() {
                        (double)n * n * n / 3.0 / best * 1e-9, info.down()[0]);
             }
         }
-        gpk_tune(37, 1);
+        gpk_tune(37, 0);
     }
 }
 
