@@ -143,9 +143,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
     constexpr int NT = 64 * NW;          // threads
-    constexpr int NV = TS * 8 / NT;      // 16-byte vectors a thread moves per operand tile and k-chunk
+    // HALFW: eight waves on a 32-row tile (the latency-critical strips of the pipelined panel).  An operand tile is 256 vectors: the
+    // two halves of the workgroup (waves 0-3 / 4-7) each stage and multiply HALF of the NCT column tiles, the lower half also
+    // stages A; inside a half the four waves form the usual 2 x 2 grid of 16 x 16 fragments.
+    constexpr bool HALFW = (NW == 8 && TS == 32);
+    static_assert(!HALFW || NCT % 2 == 0, "two halves share the column tiles");
+    constexpr int NTL = HALFW ? 256 : NT;   // threads that move ONE operand tile
+    constexpr int NCW = HALFW ? NCT / 2 : NCT;   // column tiles a wave works on
+    constexpr int NV = TS * 8 / NTL;     // 16-byte vectors a thread moves per operand tile and k-chunk
     constexpr int FR = TS / 32;          // 16x16 fragments per wave along the columns
-    constexpr int FRM = TS / (8 * NW);   // ... along the rows
+    constexpr int FRM = HALFW ? 1 : TS / (8 * NW);   // ... along the rows
     constexpr int WT = TS / 2;           // wave sub-tile width
     constexpr int WTM = 16 * FRM;        // ... height
     constexpr int OPB = op_bytes(TS), STAGE = (1 + NCT) * OPB;
@@ -153,7 +160,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int half = HALFW ? (wave >> 2) : 0;            // which half of the column tiles (HALFW)
+    const int ltid = HALFW ? (tid & 255) : tid;          // thread index inside the group that moves one operand tile
+    const int wgrid = HALFW ? (wave & 3) : wave;
+    const int wm = wgrid >> 1, wn = wgrid & 1;
+    const int cfirst = half * NCW;                       // first column tile of this wave
     const int lr = lane & 15, kq = lane >> 4;
     const int swz = (lr >> 1) & 7;
 
@@ -164,9 +175,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 
     const int m0 = ti * TS, n0 = tj * TS * NCT;
 
-    acc_t acc[NCT][FRM][FR];
+    acc_t acc[NCW][FRM][FR];
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) {
+    for (int c = 0; c < NCW; ++c) {
         if (p.has_beta) {
 #pragma unroll
             for (int fi = 0; fi < FRM; ++fi)
@@ -175,7 +186,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
-                        const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
+                        const int col = n0 + (cfirst + c) * TS + wn * WT + fj * 16 + lr;
                         T v = T(0);
                         if (!EDGE || (row < p.M && col < p.N)) v = Cin[(int64_t)row * p.ldcin + col];
                         acc[c][fi][fj][i] = v * p.beta_over_alpha;
@@ -199,23 +210,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // (panel / merge / solve), where a workgroup is often alone on its CU: they keep TWO k-chunks of
     // global loads in flight (PF2); the 128-tile kernel hides the latency with its second workgroup.
     constexpr bool PF2 = (TS <= 64);
-    vec_t ra[PF2 ? 2 : 1][NV], rb[PF2 ? 2 : 1][NCT][NV];
+    vec_t ra[PF2 ? 2 : 1][NV], rb[PF2 ? 2 : 1][NCW][NV];
 
     const bool a_in = EDGE && p.vec_ok && (m0 + TS <= p.M), b_in = EDGE && p.vec_ok && (n0 + TS * NCT <= p.N);
     auto issue = [&](auto set_c, int kc) {           // global -> register set `set`
         constexpr int set = decltype(set_c)::value;
         const bool k_in = (kc + 1) * BK <= p.K;
-        gload<T, TS, A_KMAJ, EDGE, NT>(ra[set], A, p.lda, m0, kc * BK, p.M, p.K, tid, a_in && k_in);
+        if (!HALFW || half == 0) gload<T, TS, A_KMAJ, EDGE, NTL>(ra[set], A, p.lda, m0, kc * BK, p.M, p.K, ltid, a_in && k_in);
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-            gload<T, TS, B_KMAJ, EDGE, NT>(rb[set][c], B, p.ldb, n0 + c * TS, kc * BK, p.N, p.K, tid, b_in && k_in);
+        for (int c = 0; c < NCW; ++c)
+            gload<T, TS, B_KMAJ, EDGE, NTL>(rb[set][c], B, p.ldb, n0 + (cfirst + c) * TS, kc * BK, p.N, p.K, ltid, b_in && k_in);
     };
     auto commit = [&](auto set_c, int stage) {       // register set -> LDS stage
         constexpr int set = decltype(set_c)::value;
         char* dA = smem + stage * STAGE;
-        sstore<T, TS, A_KMAJ, NT>(dA, ra[set], tid);
+        if (!HALFW || half == 0) sstore<T, TS, A_KMAJ, NTL>(dA, ra[set], ltid);
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) sstore<T, TS, B_KMAJ, NT>(dA + (1 + c) * OPB, rb[set][c], tid);
+        for (int c = 0; c < NCW; ++c) sstore<T, TS, B_KMAJ, NTL>(dA + (1 + cfirst + c) * OPB, rb[set][c], ltid);
     };
     auto mma = [&](int stage, int kc) {
         // scheduler hint: interleave the LDS reads with the MFMAs of this k-chunk (measured +2 % for fp64,
@@ -233,7 +244,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int pp = 0; pp < BK / 8; ++pp) {
-                f2 a2[FRM], b2[NCT][FR];
+                f2 a2[FRM], b2[NCW][FR];
                 const int u = pp * 4 + kq;           // 8-byte unit of the 128-byte row
                 const int uo = (((u >> 1) ^ swz) << 4) + (u & 1) * 8;
 #pragma unroll
@@ -241,17 +252,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
                 for (int f = 0; f < FR; ++f) {
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-                        b2[c][f] = *reinterpret_cast<const f2*>(sB + c * OPB + (wn * WT + f * 16 + lr) * 128 + uo);
+                    for (int c = 0; c < NCW; ++c)
+                        b2[c][f] = *reinterpret_cast<const f2*>(sB + (cfirst + c) * OPB + (wn * WT + f * 16 + lr) * 128 + uo);
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c)
+                    for (int c = 0; c < NCW; ++c)
 #pragma unroll
                         for (int fj = 0; fj < FR; ++fj) {
                             if constexpr (TRIB) {        // (wave-uniform) the 8 k values of this group all lie right of the fragment's columns
-                                if (kc * BK + pp * 8 >= c * TS + wn * WT + fj * 16 + 16) continue;
+                                if (kc * BK + pp * 8 >= (cfirst + c) * TS + wn * WT + fj * 16 + 16) continue;
                             }
 #pragma unroll
                             for (int fi = 0; fi < FRM; ++fi)
@@ -262,22 +273,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            T a[FRM], bb[NCT][FR];
+            T a[FRM], bb[NCW][FR];
             const int k = kk * 4 + kq;
 #pragma unroll
             for (int f = 0; f < FRM; ++f) a[f] = fragread<T, TS, A_KMAJ>(sA, wm * WTM + f * 16, lr, k, swz);
 #pragma unroll
             for (int f = 0; f < FR; ++f) {
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    bb[c][f] = fragread<T, TS, B_KMAJ>(sB + c * OPB, wn * WT + f * 16, lr, k, swz);
+                for (int c = 0; c < NCW; ++c)
+                    bb[c][f] = fragread<T, TS, B_KMAJ>(sB + (cfirst + c) * OPB, wn * WT + f * 16, lr, k, swz);
             }
 #pragma unroll
-            for (int c = 0; c < NCT; ++c)
+            for (int c = 0; c < NCW; ++c)
 #pragma unroll
                 for (int fj = 0; fj < FR; ++fj) {
                     if constexpr (TRIB) {
-                        if (kc * BK + kk * 4 >= c * TS + wn * WT + fj * 16 + 16) continue;
+                        if (kc * BK + kk * 4 >= (cfirst + c) * TS + wn * WT + fj * 16 + 16) continue;
                     }
 #pragma unroll
                     for (int fi = 0; fi < FRM; ++fi) acc[c][fi][fj] = Traits<T>::mfma(a[fi], bb[c][fj], acc[c][fi][fj]);
@@ -328,7 +339,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     }
     // (in-place use: every global read of this workgroup's rows of A happened above)
 #pragma unroll
-    for (int c = 0; c < NCT; ++c)
+    for (int c = 0; c < NCW; ++c)
 #pragma unroll
         for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
@@ -336,7 +347,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
-                    const int col = n0 + c * TS + wn * WT + fj * 16 + lr;
+                    const int col = n0 + (cfirst + c) * TS + wn * WT + fj * 16 + lr;
                     if (!EDGE || (row < p.M && col < p.N))
                         C[(int64_t)row * p.ldc + col] = p.alpha * acc[c][fi][fj][i];
                 }

@@ -906,19 +906,21 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> 
 // inside the panel) in ONE launch, as a pipeline between workgroups (task list and dependency rules: gpk_potrf_pipe.hpp).
 //
 // Against one diagonal-block launch + one panel-step launch per 128 columns the chain loses, per step: two kernel boundaries
-// (drain, dispatch, ramp: ~3 us each between dependent launches), the global round trip of the next diagonal block (its last
-// update lands in LDS, where the factorisation wants it), and everything of the step that the next diagonal block does not
-// depend on -- the solves of the rows further down and their updates run on the worker workgroups WHILE the chain factorises.
+// (drain, dispatch, ramp: ~3 us each between dependent launches) and everything of the step that the next diagonal block does not
+// depend on -- the solves of the rows further down and their updates run on the worker workgroups WHILE the chain workgroup
+// factorises; what the next diagonal block does depend on (the 128 rows below the block, and their update of it) is cut into ten
+// tasks of 32 rows that as many workers run side by side, eight waves each.
 //
-//   workgroup 0 (the chain), per block j:   factorise + invert block j in LDS (diag3_block), publish inv(L_jj);
-//       X = A[block j+1, j] inv(L_jj)^T     the 128 rows the next diagonal block depends on: inv(L_jj) read from LDS, the rows
-//                                           straight from global memory into MFMA operand registers; X to global + LDS, published;
-//       S = A[j+1, j+1] - X X^T             lower tiles only, X from LDS, result to LDS = the input of the next factorisation.
-//   workgroups 1.. (workers):               solve / update tasks of 64 rows x 128 columns on the GEMM tile (eight waves), taken from
-//                                           an atomic counter in list order; progress words say when a piece is ready.
-// Flag protocol as in panel_step_kernel: data stores -> barrier (vmcnt drained) -> agent-scope release -> flag; consumers poll
-// with relaxed agent-scope loads, then agent-scope acquire -> barrier.  A poll that exceeds PIPE_SPIN_LIMIT iterations (seconds;
-// never seen) raises the abort word: every workgroup leaves and `info` reports -1 instead of hanging the device.
+//   workgroup 0 (the chain):      for every block j: wait for the tiles of block j (counter), factorise + invert it in LDS
+//                                 (diag3_block), publish inv(L_jj).
+//   workgroups 1.. (workers):     tasks from an atomic counter in list order, on the GEMM tile (eight waves; 64 x 128 per task,
+//                                 32 x 128 / 32 x 64 for the critical ones); progress words / counters say when a piece is ready.
+// A first version let the chain workgroup do the critical solve and update itself, operands in LDS and registers (no flags, no
+// round trip of the next block through global memory): 2304 MFMAs on one CU between two factorisations, 28 us -- slower than the
+// two launches it replaced (profiles/r03_experiments.md).
+// Flag protocol as in panel_step_kernel: data stores -> barrier (vmcnt drained) -> agent-scope release -> flag / counter; consumers
+// poll with relaxed agent-scope loads, then agent-scope acquire -> barrier.  A poll that exceeds PIPE_SPIN_LIMIT iterations
+// (seconds; never seen) raises the abort word: every workgroup leaves and `info` reports -1 instead of hanging the device.
 // ---------------------------------------------------------------------------
 constexpr unsigned PIPE_SPIN_LIMIT = 1u << 22;
 
@@ -934,8 +936,8 @@ struct PipeArgs {
     int* info;
     int info_off;      // added to the pivot orders (columns left of the panel)
     int vec_ok;
-    int ntasks;
-    int off[GPK_PIPE_MAX_BLOCKS + 1];   // first task of step j
+    int ntasks, nseg;
+    int segoff[GPK_PIPE_MAX_SEGS + 1];   // first task of segment k (gpk_potrf_pipe.hpp)
     long long* prof;   // 32 stamps per diagonal block (nullable)
 };
 
@@ -974,162 +976,46 @@ __device__ __forceinline__ bool pipe_wait(unsigned* w0, unsigned* w1, unsigned* 
     return s_ctl[1] != 0;
 }
 
-// all threads: this workgroup's global stores are visible agent-wide before the words change
-__device__ __forceinline__ void pipe_publish(unsigned* w0, unsigned* w1, unsigned v) {
+// all threads: this workgroup's global stores are visible agent-wide before the word changes.  counter == nullptr: *word = v.
+// Otherwise *counter += 1 and, if that made it `full`, *word = v (word may be nullptr: the counter is what consumers poll).
+__device__ __forceinline__ void pipe_publish(unsigned* word, unsigned v, unsigned* counter = nullptr, unsigned full = 0u) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(w0, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w1 != nullptr) __hip_atomic_store(w1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (counter == nullptr) {
+            __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (word != nullptr && before + 1u == full) __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
 template <typename T>
 __device__ __forceinline__ void pipe_chain(const PipeArgs<T>& p, T* __restrict__ S, int* s_ctl) {
-    typedef typename Traits<T>::acc_t acc_t;
     T* rdiag = S + GPK_DB * LDP;
-    int tid_ = threadIdx.x;
-    int lane_ = tid_ & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
-    const int npb = p.sh.npb, nd = p.sh.nd, R = p.sh.R;
+    const int tid = threadIdx.x;
+    const int npb = p.sh.npb, nd = p.sh.nd;
     unsigned* abort_word = p.ctrl + 1;
-    unsigned* prog = p.ctrl + GPK_PIPE_CTRL_HEAD;
+    unsigned* cnt = p.ctrl + GPK_PIPE_CTRL_HEAD + (int64_t)p.sh.R * npb;
     int64_t ld = p.ld;
-
-    {   // block 0 from global memory (the later ones are built in LDS)
-        const int nv = p.m < GPK_DB ? p.m : GPK_DB;
-        for (int idx = tid_; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
-            const int r = idx >> 7, c = idx & 127;
-            S[r * LDP + c] = (r < nv && c <= r) ? p.A[(int64_t)r * ld + c] : ((r == c) ? T(1) : T(0));
-        }
-        __syncthreads();
-    }
     for (int j = 0; j < nd; ++j) {
-        // per-thread offsets (row * ld for every row a thread touches in a dozen phases) are loop-invariant: left alone, the compiler
-        // hoists them all out of this loop and spills most of them (640 bytes of scratch per lane, measured)
-        asm volatile("" : "+s"(ld));
-        asm volatile("" : "+v"(lane_), "+v"(tid_));
-        const int tid = tid_, lane = lane_;
-        const int lr = lane & 15, kq = lane >> 4;
+        asm volatile("" : "+s"(ld));       // (per-thread offsets are loop-invariant: hoisted out of this loop they spill)
         T* Ab = p.A + (int64_t)GPK_DB * j * ld + GPK_DB * j;
         const int rem = p.m - GPK_DB * j;
         T* W = p.dinv + (int64_t)j * (GPK_DB * GPK_DB);
         long long* prof = (p.prof != nullptr && tid == 0) ? p.prof + j * 32 : nullptr;
-        diag3_block<T, false>(S, rdiag, Ab, ld, rem < GPK_DB ? rem : GPK_DB, W, p.info, p.info_off + GPK_DB * j, 0, prof);
-        pipe_publish(p.ctrl + 16 + j, nullptr, 1u);
-        if (prof) prof[16] = (long long)__builtin_readcyclecounter();
-        if (j + 1 >= npb) break;
-
-        // ---- the rows of block j+1:  X = B inv(L_jj)^T ----
-        const int s1 = 2 * (j + 1);
-        const int nstr = (s1 + 1 < R) ? 2 : 1;
-        const int nr = (rem - GPK_DB < GPK_DB) ? rem - GPK_DB : GPK_DB;
-        unsigned* f0 = prog + (int64_t)s1 * npb + j;
-        unsigned* f1 = f0 + npb;
-        if (!pipe_wait(f0, f1, f0, f0, (unsigned)j, (unsigned)j, 0u, 0u, nstr, abort_word, s_ctl)) break;
-        if (prof) prof[17] = (long long)__builtin_readcyclecounter();
-        T* Bp = Ab + (int64_t)GPK_DB * ld;
-        {
-            const int row = 16 * wave + lr;
-            T areg[32];
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) areg[kk] = (row < nr) ? Bp[(int64_t)row * ld + 4 * kk + kq] : T(0);
-            acc_t xa[8];
-#pragma unroll
-            for (int cj = 0; cj < 8; ++cj) xa[cj][0] = xa[cj][1] = xa[cj][2] = xa[cj][3] = T(0);
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                // inv(L_jj) is lower triangular: column fragment cj only has k < 16 cj + 16, so k-block kb goes to the fragments kb..7
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int kk = 4 * kb + k4;
-                    T wv[8];
-#pragma unroll
-                    for (int cj = kb; cj < 8; ++cj)       // inv(L_jj)[16 cj + lr][4 kk + kq] (layout: inverse_at)
-                        wv[cj] = (cj == kb) ? rdiag[GPK_DB + (16 * cj + lr) * DP16 + 4 * k4 + kq] : S[(16 * kb + lr) * LDP + 16 * cj + 4 * k4 + kq];
-#pragma unroll
-                    for (int cj = kb; cj < 8; ++cj) xa[cj] = Traits<T>::mfma(areg[kk], wv[cj], xa[cj]);
-                }
-                __builtin_amdgcn_sched_barrier(0);     // (keeps the scheduler from hoisting all 144 operand reads: that spilled)
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with inv(L_jj)
-#pragma unroll
-            for (int cj = 0; cj < 8; ++cj)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 16 * wave + Traits<T>::crow(lane, i), c = 16 * cj + lr;
-                    S[r * LDP + c] = xa[cj][i];
-                    if (r < nr) Bp[(int64_t)r * ld + c] = xa[cj][i];
-                }
+        if (prof) prof[14] = (long long)__builtin_readcyclecounter();
+        if (j > 0) {                       // every tile of the block has received the update of step j - 1
+            unsigned* c = cnt + (int64_t)(2 * j) * npb + j;
+            if (!pipe_wait(c, c, c, c, (unsigned)pipe_xupdates(pipe_fine_strips(p.sh, j - 1)), 0u, 0u, 0u, 1, abort_word, s_ctl)) break;
         }
-        pipe_publish(f0, nstr == 2 ? f1 : nullptr, (unsigned)(j + 1));
-        if (prof) prof[18] = (long long)__builtin_readcyclecounter();
-
-        // ---- diagonal block j+1:  S = C - X X^T  (lower tiles), built in LDS ----
-        if (!pipe_wait(f0 + 1, f1 + 1, f0, f0, (unsigned)j, (unsigned)j, 0u, 0u, nstr, abort_word, s_ctl)) break;
-        if (prof) prof[19] = (long long)__builtin_readcyclecounter();
-        T* Cp = Bp + GPK_DB;
-        {
-            constexpr int PER = 5;          // 36 lower tiles over 8 waves
-            int bi[PER], bj[PER];
-            acc_t ca[PER];
-#pragma unroll
-            for (int q = 0; q < PER; ++q) {
-                const int t = (wave + 8 * q < 36) ? wave + 8 * q : 0;
-                int i = 0;
-                while ((i + 1) * (i + 2) / 2 <= t) ++i;
-                bi[q] = i;
-                bj[q] = t - i * (i + 1) / 2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 16 * bi[q] + Traits<T>::crow(lane, e), c = 16 * bj[q] + lr;
-                    ca[q][e] = (r < nr && c < nr) ? Cp[(int64_t)r * ld + c] : ((r == c) ? T(1) : T(0));
-                }
-            }
-            const bool five = wave < 4;
-#pragma unroll 4
-            for (int kk = 0; kk < 32; ++kk) {
-                T av[PER], bv[PER];
-#pragma unroll
-                for (int q = 0; q < PER; ++q) {
-                    av[q] = -S[(16 * bi[q] + lr) * LDP + 4 * kk + kq];
-                    bv[q] = S[(16 * bj[q] + lr) * LDP + 4 * kk + kq];
-                }
-#pragma unroll
-                for (int q = 0; q < PER; ++q)
-                    if (q < 4 || five) ca[q] = Traits<T>::mfma(av[q], bv[q], ca[q]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with X
-#pragma unroll
-            for (int q = 0; q < PER; ++q)
-                if (q < 4 || five) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 16 * bi[q] + Traits<T>::crow(lane, e), c = 16 * bj[q] + lr;
-                        S[r * LDP + c] = (c <= r) ? ca[q][e] : T(0);
-                    }
-                }
-            // zeros in the 28 tiles above the diagonal (they held X)
-            for (int t = wave; t < 28; t += D3_WAVES) {
-                int i = 1;
-                while (i * (i + 1) / 2 <= t) ++i;
-                const int jj = t - i * (i - 1) / 2;         // strictly lower (i, jj) -> upper tile (jj, i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) S[(16 * jj + Traits<T>::crow(lane, e)) * LDP + 16 * i + lr] = T(0);
-            }
-        }
-        __syncthreads();
-        if (prof) prof[20] = (long long)__builtin_readcyclecounter();
-        if (j + 1 >= nd) {       // the last block of the matrix is factorised by a launch of its own: hand it over updated
-            for (int idx = tid; idx < GPK_DB * GPK_DB; idx += D3_THREADS) {
-                const int r = idx >> 7, c = idx & 127;
-                if (r < nr && c <= r) Cp[(int64_t)r * ld + c] = S[r * LDP + c];
-            }
-            break;
-        }
+        diag3_block<T, true>(S, rdiag, Ab, ld, rem < GPK_DB ? rem : GPK_DB, W, p.info, p.info_off + GPK_DB * j, 0, prof);
+        pipe_publish(p.ctrl + 16 + j, 1u);
+        if (prof) prof[15] = (long long)__builtin_readcyclecounter();
     }
-    if (tid_ == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(p.info, -1);
+    if (tid == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(p.info, -1);
 }
 
 template <typename T, bool EDGE>
@@ -1138,6 +1024,7 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     const int npb = p.sh.npb, R = p.sh.R;
     unsigned* abort_word = p.ctrl + 1;
     unsigned* prog = p.ctrl + GPK_PIPE_CTRL_HEAD;
+    unsigned* cnt = prog + (int64_t)R * npb;
     GemmArgs<T> g;
     g.lda = p.ld; g.ldc = p.ld; g.ldcin = p.ld;
     g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
@@ -1146,41 +1033,64 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
     g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
     g.vec_ok = p.vec_ok;
-    int j = 0;
+    int k = 0;
     for (;;) {
         if (tid == 0) s_ctl[0] = (int)__hip_atomic_fetch_add(p.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int t = s_ctl[0];
         if (t >= p.ntasks) return;
-        while (t >= p.off[j + 1]) ++j;
-        const PipeTask tk = pipe_decode(p.sh, j, t - p.off[j]);
+        while (t >= p.segoff[k + 1]) ++k;
+        const PipeTask tk = pipe_decode(p.sh, k, t - p.segoff[k]);
+        const int j = tk.j;
         const T* Pj = p.A + GPK_DB * j;                        // column block j, rows from the top of the panel
-        unsigned* own = prog + (int64_t)tk.s * npb + j;
-        if (tk.cb < 0) {
-            // solve(j, s): the inverse of block j is out, every earlier update of the piece applied
-            if (!pipe_wait(p.ctrl + 16 + j, own, own, own, 1u, (unsigned)j, 0u, 0u, 2, abort_word, s_ctl)) return;
+        const bool solve = tk.kind == PIPE_SOLVE || tk.kind == PIPE_XSOLVE;
+        if (solve) {
             g.A = Pj; g.B = p.dinv + (int64_t)j * (GPK_DB * GPK_DB); g.C = const_cast<T*>(Pj); g.Cin = Pj;
             g.ldb = GPK_DB;
             g.N = GPK_DB;
             g.alpha = T(1); g.beta_over_alpha = T(0); g.has_beta = 0;
             g.tiles_n = 1;
-            gemm_tile<T, GPK_PIPE_STRIP, true, true, EDGE, 2, D3_WAVES, true>(g, tk.s, 0, 0, 0, smem);
-            pipe_publish(own, nullptr, (unsigned)(j + 1));
         } else {
-            // update(j, s, cb): own strip and the rows of column block cb solved, the previous update of the piece applied
+            g.A = Pj; g.B = Pj; g.C = p.A; g.Cin = p.A;
+            g.ldb = p.ld;
+            g.N = p.w;
+            g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
+            g.tiles_n = npb;
+        }
+        const int s1 = 2 * (j + 1);
+        if (tk.kind == PIPE_SOLVE) {
+            // the inverse of block j is out, every earlier update of the piece applied
+            unsigned* own = prog + (int64_t)tk.s * npb + j;
+            if (!pipe_wait(p.ctrl + 16 + j, own, own, own, 1u, (unsigned)j, 0u, 0u, 2, abort_word, s_ctl)) return;
+            gemm_tile<T, GPK_PIPE_STRIP, true, true, EDGE, 2, D3_WAVES, true>(g, tk.s, 0, 0, 0, smem);
+            pipe_publish(own, (unsigned)(j + 1));
+        } else if (tk.kind == PIPE_UPDATE) {
+            // own strip and the rows of column block cb solved, the previous update of the piece applied
+            unsigned* own = prog + (int64_t)tk.s * npb + j;
             unsigned* b0 = prog + (int64_t)(2 * tk.cb) * npb + j;
             const bool two = 2 * tk.cb + 1 < R;
             unsigned* piece = prog + (int64_t)tk.s * npb + tk.cb;
             if (!pipe_wait(own, b0, piece, two ? b0 + npb : own, (unsigned)(j + 1), (unsigned)(j + 1), (unsigned)j, (unsigned)(j + 1),
                            4, abort_word, s_ctl))
                 return;
-            g.A = Pj; g.B = Pj; g.C = p.A; g.Cin = p.A;
-            g.ldb = p.ld;
-            g.N = p.w;
-            g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
-            g.tiles_n = npb;
             gemm_tile<T, GPK_PIPE_STRIP, true, true, EDGE, 2, D3_WAVES, false>(g, tk.s, tk.cb, 0, 0, smem);
-            pipe_publish(piece, nullptr, (unsigned)(j + 1));
+            pipe_publish(piece, (unsigned)(j + 1));
+        } else if (tk.kind == PIPE_XSOLVE) {
+            // fine strip q of block j+1: as a solve; the strip of 64 rows is solved when its fine strips are
+            const int s = s1 + (tk.s >> 1);
+            unsigned* own = prog + (int64_t)s * npb + j;
+            if (!pipe_wait(p.ctrl + 16 + j, own, own, own, 1u, (unsigned)j, 0u, 0u, 2, abort_word, s_ctl)) return;
+            gemm_tile<T, GPK_PIPE_FINE, true, true, EDGE, 4, D3_WAVES, true>(g, 4 * (j + 1) + tk.s, 0, 0, 0, smem);
+            pipe_publish(own, (unsigned)(j + 1), cnt + (int64_t)s * npb + j,
+                         (unsigned)pipe_xsolves_in_strip(pipe_fine_strips(p.sh, j), tk.s >> 1));
+        } else {
+            // tile (fine strip q, column half h) of diagonal block j+1: all rows of the block solved, the earlier updates applied
+            unsigned* b0 = prog + (int64_t)s1 * npb + j;
+            const bool two = s1 + 1 < R;
+            unsigned* piece = prog + (int64_t)(s1 + (tk.s >> 1)) * npb + j + 1;
+            if (!pipe_wait(b0, two ? b0 + npb : b0, piece, piece, (unsigned)(j + 1), (unsigned)(j + 1), (unsigned)j, 0u, 3, abort_word, s_ctl)) return;
+            gemm_tile<T, GPK_PIPE_FINE, true, true, EDGE, 2, D3_WAVES, false>(g, 4 * (j + 1) + tk.s, 2 * (j + 1) + tk.cb, 0, 0, smem);
+            pipe_publish(nullptr, 0u, cnt + (int64_t)s1 * npb + j + 1, 0u);
         }
     }
 }
@@ -1189,7 +1099,8 @@ template <typename T, bool EDGE>
 __global__ __launch_bounds__(D3_THREADS, 2) void potrf_pipe_kernel(PipeArgs<T> p) {
     __shared__ __attribute__((aligned(16))) T S[D3_LDS_ELEMS];
     __shared__ int s_ctl[4];
-    static_assert(sizeof(T) * D3_LDS_ELEMS >= 2 * 3 * op_bytes(GPK_PIPE_STRIP), "the worker's operand tiles live in the chain's block");
+    static_assert(sizeof(T) * D3_LDS_ELEMS >= 2 * 5 * op_bytes(GPK_PIPE_FINE) && sizeof(T) * D3_LDS_ELEMS >= 2 * 3 * op_bytes(GPK_PIPE_STRIP),
+                  "the worker's operand tiles live in the chain's block");
     if (blockIdx.x == 0) pipe_chain<T>(p, S, s_ctl);
     else pipe_worker<T, EDGE>(p, reinterpret_cast<char*>(S), s_ctl);
 }
@@ -1281,7 +1192,7 @@ int potrf_panel_fused(const PanelCtx<T>& x, int64_t c0, int64_t w) {
 }
 int g_fused_step = 1;              // tuning knob (gpk_tune(32, v)): single matrices take potrf_panel_fused
 
-int g_pipe = 0;                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
+int g_pipe = 1;                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
 int g_pipe_cus = 0;                // CUs of the current device (queried once)
 
 // The same panel in ONE launch (potrf_pipe_kernel) -- plus a memset of its control words and, when the panel reaches the last row of
@@ -1298,6 +1209,7 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done) {
     sh.npb = (int)gpk_cdiv(ke - c0, GPK_DB);
     sh.nd = last ? sh.npb - 1 : sh.npb;
     sh.R = (int)gpk_cdiv(m, GPK_PIPE_STRIP);
+    sh.R32 = (int)gpk_cdiv(m, GPK_PIPE_FINE);
     if (sh.nd < 1 || sh.npb > GPK_PIPE_MAX_BLOCKS) return GPK_OK;
     const int64_t words = pipe_ctrl_words(sh);
     if (words * (int64_t)sizeof(unsigned) > (int64_t)GPK_DB * GPK_DB * (int64_t)sizeof(T)) return GPK_OK;
@@ -1314,10 +1226,11 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done) {
     constexpr int VEC = Traits<T>::VEC;
     const bool aligned = ((uintptr_t)pa.A % 16 == 0) && ((uintptr_t)pa.dinv % 16 == 0) && (x.ld % VEC == 0);
     pa.vec_ok = aligned ? 1 : 0;
-    pa.off[0] = 0;
-    for (int j = 0; j < sh.nd; ++j) pa.off[j + 1] = pa.off[j] + pipe_step_tasks(sh, j);
-    for (int j = sh.nd + 1; j <= GPK_PIPE_MAX_BLOCKS; ++j) pa.off[j] = pa.off[sh.nd];
-    pa.ntasks = pa.off[sh.nd];
+    pa.nseg = pipe_num_segments(sh);
+    pa.segoff[0] = 0;
+    for (int k = 0; k < pa.nseg; ++k) pa.segoff[k + 1] = pa.segoff[k] + pipe_segment_tasks(sh, k);
+    for (int k = pa.nseg + 1; k <= GPK_PIPE_MAX_SEGS; ++k) pa.segoff[k] = pa.segoff[pa.nseg];
+    pa.ntasks = pa.segoff[pa.nseg];
     pa.prof = g_diag_prof != nullptr ? g_diag_prof + (c0 / GPK_DB) * 32 : nullptr;
     int cus = x.max_wgs;
     if (cus <= 0) {
@@ -1329,9 +1242,9 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done) {
         }
         cus = g_pipe_cus;
     }
-    // one workgroup per CU (the chain's block fills the LDS); never more workers than the first, largest step has tasks (+ a few
-    // that run ahead into the next step)
-    int64_t workers = (int64_t)pipe_step_tasks(sh, 0) + 8;
+    // one workgroup per CU (the chain's block fills the LDS); never more workers than the first, largest step has tasks (+ the
+    // critical tasks of the next step, which are taken early and wait)
+    int64_t workers = (int64_t)(pa.nseg > 4 ? pa.segoff[5] : pa.ntasks) + 4;
     if (workers > cus - 1) workers = cus - 1;
     if (workers < 1) workers = 1;
     if (pa.ntasks == 0) workers = 0;

@@ -1497,7 +1497,7 @@ static void diag_phase_profile(int n, int ver, int pipe = 0) {
     profile_one<T>(n, 0, 1);
     gpk_tune_diag_prof(nullptr);
     auto h = prof.down();
-    for (int blk : {0, nblk / 2, nblk - 1}) {
+    for (int blk : {0, nblk / 2 + 1, nblk - 1}) {
         if (ver == 0) {
             const long long* q = &h[(size_t)blk * 16];
             printf("DIAGPROF %s blk %d cycles: load %lld  factor %lld [trsm %lld  c1 %lld  chol(wave0) %lld]  storeL %lld  invert %lld [16x16 %lld]  storeW %lld  total %lld\n",
@@ -1510,12 +1510,12 @@ static void diag_phase_profile(int n, int ver, int pipe = 0) {
             printf("DIAGPROF3 %s blk %d   of which column update before the panel (U1):", DT<T>::name(), blk);
             for (int s = 0; s < 7; ++s) printf(" %lld", q[21 + s] - q[2 + s]);
             printf("\n");
-            if (pipe && q[20] > q[13] && blk + 1 < nblk)      // the chain workgroup of the pipelined panel: what follows the block until the next one starts
-                printf("PIPEPROF %s blk %d cycles: publish inv %lld | wait rows %lld | X = B inv^T %lld | wait block %lld | S = C - X X^T %lld | step period %lld\n",
-                       DT<T>::name(), blk, q[16] - q[13], q[17] - q[16], q[18] - q[17], q[19] - q[18], q[20] - q[19], q[32] - q[0]);
+            if (pipe && q[15] > q[13] && blk + 1 < nblk)      // the chain workgroup of the pipelined panel
+                printf("PIPEPROF %s blk %d cycles: wait for the block's tiles %lld | publish the inverse %lld | step period %lld\n",
+                       DT<T>::name(), blk, q[0] - q[14], q[15] - q[13], q[32 + 14] - q[14]);
         }
     }
-    gpk_tune(37, 0);
+    gpk_tune(37, 1);
 }
 
 // --perf-pipe: the factorisation of small / chain-bound matrices with and without the pipelined panel kernel, at several outer
@@ -1547,7 +1547,7 @@ static void perf_pipe() {
                        (double)n * n * n / 3.0 / best * 1e-9, info.down()[0]);
             }
         }
-        gpk_tune(37, 0);
+        gpk_tune(37, 1);
     }
 }
 
