@@ -1290,7 +1290,9 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     if (n <= 0 || batch <= 0) return GPK_OK;
     if (n > INT32_MAX) return GPK_ERR_ARG(2);
     if (ld < n) return GPK_ERR_ARG(3);
-    if (nbo <= 0) nbo = (n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256);
+    // one matrix: the pipelined panel (potrf_panel_pipe) takes whole matrices up to 4096 as ONE panel; above, the trailing matrix is
+    // big enough for the rank-nbo update GEMM to be worth its launch (measured: N = 8192 5.76 ms at 1024, 5.97 at 2048, 6.07 at 512)
+    if (nbo <= 0) nbo = (batch == 1 && dinv != nullptr) ? (n <= 4096 ? 4096 : 1024) : ((n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256));
     if (nbo < GPK_DB || (nbo & (nbo - 1))) return GPK_ERR_ARG(9);   // 128 * 2^k
     if (info == nullptr) return GPK_ERR_ARG(7);
     if (dinv == nullptr && n > GPK_DB) return GPK_ERR_ARG(6);

@@ -942,6 +942,47 @@ static void perf_la(int nmax) {
 }
 
 
+// --perf-la-tail: plain (pipelined panels) against look-ahead at several orders, outer blocks and plain-tail lengths
+template <typename T>
+static void perf_la_tail(std::initializer_list<int> ns) {
+    Timer tm;
+    for (int n : ns) {
+        const int d = 8;
+        auto hx = randv<T>((size_t)n * d);
+        Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n));
+        Dev<int> info(1);
+        X.up(hx);
+        int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+        auto run = [&](auto&& call) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                info.zero();
+                gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+                tm.start();
+                call();
+                const float ms = tm.stop();
+                if (rep) best = std::min(best, ms);
+            }
+            return best;
+        };
+        for (int nbo : {512, 1024, 2048}) {
+            const float ms = run([&] { gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, nbo, nullptr); });
+            printf("PERFTAIL potrf_%s n=%d plain nbo=%d  %.3f ms  %.2f TFLOP/s\n", DT<T>::name(), n, nbo, ms, (double)n * n * n / 3.0 / ms * 1e-9);
+        }
+        for (int nb : {512, 1024}) {
+            Dev<T> dbig((size_t)((n + nb - 1) / nb) * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+            for (int tail : {4096, 6144, 8192, 10240}) {
+                if (tail >= n) continue;
+                gpk_tune(9, tail);
+                const float ms = run([&] { gpk_potrf_la(DT<T>::v, K.p, n, n, dinv.p, dbig.p, nb, ws.p, info.p, nullptr); });
+                printf("PERFTAIL potrf_%s n=%d look-ahead nb=%d tail=%d  %.3f ms  %.2f TFLOP/s info=%d\n", DT<T>::name(), n, nb, tail, ms,
+                       (double)n * n * n / 3.0 / ms * 1e-9, info.down()[0]);
+            }
+            gpk_tune(9, 0);
+        }
+    }
+}
+
 // one look-ahead factorisation on an explicit stream, for rocprofv3 traces:  --la-one f64|f32 N NB MODE MINROWS
 template <typename T>
 static void la_one(int n, int nb, int mode, int64_t minrows, int reps, int ldpad = 0) {
@@ -1634,6 +1675,7 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--census")) { census(); return 0; }
         if (!strcmp(argv[i], "--perf-kmat")) { perf_kmat(); return 0; }
+        if (!strcmp(argv[i], "--perf-la-tail")) { perf_la_tail<double>({6144, 8192, 10240, 12288, 16384}); perf_la_tail<float>({8192, 12288, 16384, 32768}); return 0; }
         if (!strcmp(argv[i], "--perf-pipe")) { perf_pipe<double>(); perf_pipe<float>(); return 0; }
         if (!strcmp(argv[i], "--perf-trsm")) { perf_trsm<double>(16384, 2048); perf_trsm<float>(32768, 2048); return 0; }
         if (!strcmp(argv[i], "--kmat")) {                      // only the kernel-matrix checks, both kernels
