@@ -1011,9 +1011,13 @@ __device__ __forceinline__ void pipe_chain(const PipeArgs<T>& p, T* __restrict__
             unsigned* c = cnt + (int64_t)(2 * j) * npb + j;
             if (!pipe_wait(c, c, c, c, (unsigned)pipe_xupdates(pipe_fine_strips(p.sh, j - 1)), 0u, 0u, 0u, 1, abort_word, s_ctl)) break;
         }
+        if (prof && j > 0) prof[30 - 32] = wall_clock64();          // (development stamps, 100 MHz: the critical path of step j - 1 ends here)
         diag3_block<T, true>(S, rdiag, Ab, ld, rem < GPK_DB ? rem : GPK_DB, W, p.info, p.info_off + GPK_DB * j, 0, prof);
         pipe_publish(p.ctrl + 16 + j, 1u);
-        if (prof) prof[15] = (long long)__builtin_readcyclecounter();
+        if (prof) {
+            prof[15] = (long long)__builtin_readcyclecounter();
+            prof[16] = wall_clock64();
+        }
     }
     if (tid == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(p.info, -1);
 }
@@ -1080,17 +1084,25 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
             const int s = s1 + (tk.s >> 1);
             unsigned* own = prog + (int64_t)s * npb + j;
             if (!pipe_wait(p.ctrl + 16 + j, own, own, own, 1u, (unsigned)j, 0u, 0u, 2, abort_word, s_ctl)) return;
+            long long* pf = (p.prof != nullptr && tid == 0 && tk.s == 0) ? p.prof + j * 32 : nullptr;
+            if (pf) pf[17] = wall_clock64();
             gemm_tile<T, GPK_PIPE_FINE, true, true, EDGE, 4, D3_WAVES, true>(g, 4 * (j + 1) + tk.s, 0, 0, 0, smem);
+            if (pf) pf[18] = wall_clock64();
             pipe_publish(own, (unsigned)(j + 1), cnt + (int64_t)s * npb + j,
                          (unsigned)pipe_xsolves_in_strip(pipe_fine_strips(p.sh, j), tk.s >> 1));
+            if (pf) pf[19] = wall_clock64();
         } else {
             // tile (fine strip q, column half h) of diagonal block j+1: all rows of the block solved, the earlier updates applied
             unsigned* b0 = prog + (int64_t)s1 * npb + j;
             const bool two = s1 + 1 < R;
             unsigned* piece = prog + (int64_t)(s1 + (tk.s >> 1)) * npb + j + 1;
             if (!pipe_wait(b0, two ? b0 + npb : b0, piece, piece, (unsigned)(j + 1), (unsigned)(j + 1), (unsigned)j, 0u, 3, abort_word, s_ctl)) return;
+            long long* pf = (p.prof != nullptr && tid == 0 && tk.s == 3 && tk.cb == 1) ? p.prof + j * 32 : nullptr;
+            if (pf) pf[20] = wall_clock64();
             gemm_tile<T, GPK_PIPE_FINE, true, true, EDGE, 2, D3_WAVES, false>(g, 4 * (j + 1) + tk.s, 2 * (j + 1) + tk.cb, 0, 0, smem);
+            if (pf) pf[28] = wall_clock64();
             pipe_publish(nullptr, 0u, cnt + (int64_t)s1 * npb + j + 1, 0u);
+            if (pf) pf[29] = wall_clock64();
         }
     }
 }

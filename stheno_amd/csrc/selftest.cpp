@@ -1551,6 +1551,10 @@ static void diag_phase_profile(int n, int ver, int pipe = 0) {
             printf("DIAGPROF3 %s blk %d   of which column update before the panel (U1):", DT<T>::name(), blk);
             for (int s = 0; s < 7; ++s) printf(" %lld", q[21 + s] - q[2 + s]);
             printf("\n");
+            if (pipe && q[29] > q[16] && q[30] > q[16])
+                printf("PIPEPROF %s blk %d critical path after the inverse is out (us): strip solve starts %.2f, computed %.2f, published %.2f | last tile update starts %.2f, computed %.2f, published %.2f | chain sees the block %.2f\n",
+                       DT<T>::name(), blk, (q[17] - q[16]) * 0.01, (q[18] - q[16]) * 0.01, (q[19] - q[16]) * 0.01, (q[20] - q[16]) * 0.01, (q[28] - q[16]) * 0.01,
+                       (q[29] - q[16]) * 0.01, (q[30] - q[16]) * 0.01);
             if (pipe && q[15] > q[13] && blk + 1 < nblk)      // the chain workgroup of the pipelined panel
                 printf("PIPEPROF %s blk %d cycles: wait for the block's tiles %lld | publish the inverse %lld | step period %lld\n",
                        DT<T>::name(), blk, q[0] - q[14], q[15] - q[13], q[32 + 14] - q[14]);
