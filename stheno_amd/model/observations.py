@@ -150,7 +150,7 @@ class Observations(AbstractObservations):
             return measure.kernels[p_i, p_j]
         return _k.PosteriorKernel(
             measure.kernels[p_i, p_j], measure.kernels[self.fdd.p, p_i], measure.kernels[self.fdd.p, p_j],
-            self.fdd._xr, self.K_x(measure),
+            self.fdd._xr, self.K_x(measure), own_cross=True,
         )
 
     def posterior_mean(self, measure, p):
@@ -158,7 +158,7 @@ class Observations(AbstractObservations):
             return measure.means[p]
         return _k.PosteriorMean(
             measure.means[p], measure.means[self.fdd.p], measure.kernels[self.fdd.p, p], self.fdd._xr,
-            self.K_x(measure), self.y,
+            self.K_x(measure), self.y, own_cross=True,
         )
 
 
