@@ -58,12 +58,36 @@ def _is_zero(x):
     return isinstance(x, (int, float)) and not isinstance(x, bool) and x == 0
 
 
+class _Deferred:
+    """One quantity of a distribution that may not exist yet: given up front, or made on first use by a zero-argument callable
+    (the reference's ``Normal`` takes such constructors so that a prior's ``f(x)`` costs nothing until something is asked of it,
+    ``random.py:56-117``)."""
+
+    __slots__ = ("value", "make")
+
+    def __init__(self, value=None, make=None):
+        self.value, self.make = value, make
+
+    @property
+    def known(self):
+        return self.value is not None
+
+    def get(self):
+        if self.value is None and self.make is not None:
+            self.value = self.make()
+        return self.value
+
+
 class Normal(RandomVector):
     """Normal random variable.
 
     ``Normal(var)``, ``Normal(mean, var)`` with tensors / structured matrices, or
     ``Normal(mean_fn, var_fn, var_diag=..., mean_var=..., mean_var_diag=...)`` with
     zero-argument constructors that are called lazily (``random.py:56-94``).
+
+    State: three deferred quantities (mean, variance, marginal variances) and two optional JOINT constructors that produce the mean
+    together with the variance / the marginal variances in one go (a posterior shares the whitened cross-kernel between them).  A
+    joint constructor is only worth calling while neither of its two quantities exists; after that the single ones are used.
     """
 
     def __init__(self, *args, var_diag=None, mean_var=None, mean_var_diag=None):
@@ -73,53 +97,41 @@ class Normal(RandomVector):
             mean, var = args
         else:
             raise TypeError("Normal(var) or Normal(mean, var)")
-        self._mean_is_zero = None
-        self._var_diag = None
-        if isinstance(var, types.FunctionType):
-            if not isinstance(mean, types.FunctionType):
-                raise TypeError("mean and var must both be constructors or both be values")
-            self._mean = None
-            self._construct_mean = mean
-            self._var = None
-            self._construct_var = var
-            self._construct_var_diag = var_diag
-            self._construct_mean_var = mean_var
-            self._construct_mean_var_diag = mean_var_diag
-        else:
-            self._mean = mean
-            self._var = var
-            self._construct_mean = None
-            self._construct_var = None
-            self._construct_var_diag = None
-            self._construct_mean_var = None
-            self._construct_mean_var_diag = None
+        lazy = isinstance(var, types.FunctionType)
+        if lazy and not isinstance(mean, types.FunctionType):
+            raise TypeError("mean and var must both be constructors or both be values")
+        self._m = _Deferred(make=mean) if lazy else _Deferred(mean)
+        self._v = _Deferred(make=var) if lazy else _Deferred(var)
+        self._d = _Deferred(make=var_diag if lazy else None)
+        self._joint_var = mean_var if lazy else None
+        self._joint_diag = mean_var_diag if lazy else None
+        self._mean_vanishes = None       # whether the mean is identically zero, decided when the mean first exists
 
-    # -- lazy resolution (random.py:96-117) ------------------------------------
-    def _resolve_mean(self, construct_zeros):
-        if self._mean is None:
-            self._mean = self._construct_mean()
-        if self._mean_is_zero is None:
-            self._mean_is_zero = _is_zero(self._mean) or isinstance(self._mean, Zero)
-        if _is_zero(self._mean) and construct_zeros:
+    def computed(self, what):
+        """Whether ``"mean"``, ``"var"`` or ``"var_diag"`` has been given or computed already (nothing is computed by asking)."""
+        return {"mean": self._m, "var": self._v, "var_diag": self._d}[what].known
+
+    # -- the deferred quantities (random.py:96-202) ----------------------------
+    def _settle_mean(self, as_tensor):
+        """The mean exists after this; a scalar zero stays a scalar unless ``as_tensor`` (then it becomes a zero column of the
+        variance's shape and type, which makes the variance exist too)."""
+        m = self._m.get()
+        if self._mean_vanishes is None:
+            self._mean_vanishes = _is_zero(m) or isinstance(m, Zero)
+        if as_tensor and _is_zero(m):
             var = self.var
             shape = tuple(var.shape)
-            self._mean = torch.zeros(shape[:-2] + (shape[-1], 1), dtype=var.dtype, device=var.device)
+            self._m.value = torch.zeros(shape[:-2] + (shape[-1], 1), dtype=var.dtype, device=var.device)
 
-    def _resolve_var(self):
-        if self._var is None:
-            self._var = self._construct_var()
-        self._var = to_matrix(self._var)
-
-    def _resolve_var_diag(self):
-        if self._var_diag is None:
-            if self._construct_var_diag is not None:
-                self._var_diag = self._construct_var_diag()
-            else:
-                self._var_diag = self.var.diag()
+    def _settle_jointly(self, other, joint):
+        """``other`` is the variance or the marginal-variance slot: while neither it nor the mean exists, one call of ``joint``
+        (if there is one) makes both."""
+        if joint is not None and not self._m.known and not other.known:
+            self._m.value, other.value = joint()
 
     def __repr__(self):
-        m = "unresolved" if self._mean is None else repr(self._mean)
-        v = "unresolved" if self._var is None else repr(self._var)
+        m = repr(self._m.value) if self._m.known else "unresolved"
+        v = repr(self._v.value) if self._v.known else "unresolved"
         return f"<Normal:\n mean={m},\n var={v}>"
 
     __str__ = __repr__
@@ -127,40 +139,31 @@ class Normal(RandomVector):
     @property
     def mean(self):
         """Column vector: mean."""
-        self._resolve_mean(construct_zeros=True)
-        m = self._mean
+        self._settle_mean(as_tensor=True)
+        m = self._m.value
         return m.dense() if isinstance(m, AbstractMatrix) else m
 
     @property
     def mean_is_zero(self):
-        self._resolve_mean(construct_zeros=False)
-        return self._mean_is_zero
+        self._settle_mean(as_tensor=False)
+        return self._mean_vanishes
 
     @property
     def var(self):
         """Variance as a structured matrix (``B.dense(d.var)`` for the plain tensor)."""
-        self._resolve_var()
-        return self._var
+        self._v.value = to_matrix(self._v.get())
+        return self._v.value
 
     @property
     def var_diag(self):
-        self._resolve_var_diag()
-        return self._var_diag
+        if not self._d.known and self._d.make is None:
+            self._d.value = self.var.diag()
+        return self._d.get()
 
     @property
     def mean_var(self):
-        if self._mean is not None and self._var is not None:
-            return self.mean, self.var
-        elif self._mean is not None:
-            return self.mean, self.var
-        elif self._var is not None:
-            return self.mean, self.var
-        else:
-            if self._construct_mean_var is not None:
-                self._mean, self._var = self._construct_mean_var()
-                self._resolve_mean(construct_zeros=True)
-                self._resolve_var()
-            return self.mean, self.var
+        self._settle_jointly(self._v, self._joint_var)
+        return self.mean, self.var
 
     @property
     def dtype(self):
@@ -174,17 +177,8 @@ class Normal(RandomVector):
     def marginals(self):
         """Marginal means and variances (the covariance is not formed when a
         ``mean_var_diag`` constructor is available)."""
-        if self._mean is not None and self._var_diag is not None:
-            mean, var_diag = self.mean, self._var_diag
-        elif self._mean is not None:
-            mean, var_diag = self.mean, self.var_diag
-        elif self._var_diag is not None:
-            mean, var_diag = self.mean, self._var_diag
-        else:
-            if self._construct_mean_var_diag is not None:
-                self._mean, self._var_diag = self._construct_mean_var_diag()
-                self._resolve_mean(construct_zeros=True)
-            mean, var_diag = self.mean, self.var_diag
+        self._settle_jointly(self._d, self._joint_diag)
+        mean, var_diag = self.mean, self.var_diag
         if isinstance(var_diag, AbstractMatrix):
             var_diag = var_diag.dense()
         # Variances can come out slightly negative through round-off (random.py:221-227).

@@ -64,26 +64,26 @@ def approx(a, b, atol=1e-8, rtol=1e-8):
 def test_normal_lazy_zero_mean():          # test_random.py:68-83
     dist = st.Normal(lambda: torch.eye(3, dtype=f64))
     assert dist.mean_is_zero
-    assert dist._mean == 0 and dist._var is None
+    assert dist.computed("mean") and not dist.computed("var")
     approx(dist.mean, np.zeros((3, 1)))
-    assert dist._var is not None
+    assert dist.computed("var")
     approx(dist.var, np.eye(3))
 
 
 def test_normal_lazy_nonzero_mean():       # test_random.py:86-96
     dist = st.Normal(lambda: torch.ones(3, 1, dtype=f64), lambda: torch.eye(3, dtype=f64))
-    assert dist._mean is None and dist._var is None
+    assert not dist.computed("mean") and not dist.computed("var")
     approx(dist.mean, np.ones((3, 1)))
-    assert dist._var is None
+    assert not dist.computed("var")
     approx(dist.var, np.eye(3))
 
 
 def test_normal_lazy_var_diag():           # test_random.py:99-108
     dist = st.Normal(lambda: torch.eye(3, dtype=f64))
     approx(dist.var_diag, np.ones(3))
-    assert dist._var is not None
+    assert dist.computed("var")
     dist = st.Normal(lambda: torch.eye(3, dtype=f64), var_diag=lambda: 9)
-    assert dist.var_diag == 9 and dist._var is None
+    assert dist.var_diag == 9 and not dist.computed("var")
 
 
 def test_normal_lazy_mean_var_called_only_when_both_missing():    # test_random.py:111-133
@@ -159,7 +159,7 @@ def test_fdd_noise_typing_and_var():       # test_fdd.py:15-82, test_gp.py:57-92
     assert isinstance(p(x, t(np.full(5, 0.2))).noise, Diagonal)
     assert isinstance(p(x, 0.3 * torch.eye(5, dtype=f64)).noise, Dense)
     d = p(x, 1.0)
-    assert d._var is None and d._mean is None            # nothing computed at construction
+    assert not d.computed("var") and not d.computed("mean")            # nothing computed at construction
     approx(d.var, O.kernel_matrix([("eq", 1, 1)], np.linspace(0, 5, 5)) + np.eye(5))
     approx(d.mean, np.zeros((5, 1)))
     assert isinstance(d.var, KernelDense)
