@@ -9,7 +9,7 @@ from .kernels import (  # noqa: F401
     PosteriorMean, SubspaceKernel, ZeroKernel, ZeroMean,
 )
 from .lazy import LazyMatrix, LazyVector  # noqa: F401
-from .matrix import Dense, Diagonal, Zero  # noqa: F401
+from .matrix import Dense, Diagonal, Zero, deferred_checks  # noqa: F401
 from .model import *  # noqa: F401,F403
 from .random import Normal, Random, RandomProcess, RandomVector  # noqa: F401
 

@@ -43,6 +43,48 @@ class _Config:
 
 config = _Config()
 
+_missing_seen = []      # [(key, tensor, answer)]: the last observation vector scanned for NaN
+
+
+def any_missing(y):
+    """Whether column 0 of the (N, 1) tensor ``y`` holds a NaN (a missing observation) -- a device reduction plus ONE host read,
+    remembered for the tensor it was asked about: the log-density and the conditioning on the same observations both ask
+    (``random.py:262-264``, ``observations.py:73-74``), and so does every further evaluation on the same data (hyper-parameter
+    loops).  The key is the storage, shape and VERSION of the tensor (an in-place write invalidates it); the entry keeps the tensor
+    alive, so its address cannot be recycled under the key."""
+    key = (y.data_ptr(), y._version, tuple(y.shape), tuple(y.stride()), y.dtype, y.device)
+    if _missing_seen and _missing_seen[0][0] == key:
+        return _missing_seen[0][2]
+    ans = bool(torch.isnan(y[:, 0]).any())
+    _missing_seen[:] = [(key, y, ans)]
+    return ans
+
+
+_deferred = None       # factors waiting for their check inside a `deferred_checks()` block
+
+
+class deferred_checks:
+    """``with deferred_checks(): ...`` -- factorisations inside the block do not wait for their ``info`` word; all of them are checked
+    when the block ends.  Reading ``info`` is a host read behind the factorisation: done right away, the device runs dry while the
+    host comes back and enqueues what follows (0.3-0.6 ms of idle device per cfg2 eval, from the kernel trace); done at the end of the
+    block, the work that depends on the factor (log-determinant, solves) is already queued behind it.  A failed factorisation still
+    raises before anything computed from it is handed out.  Nested blocks check at the end of the outermost one."""
+
+    def __enter__(self):
+        global _deferred
+        self._outer = _deferred
+        if _deferred is None:
+            _deferred = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _deferred
+        pending, _deferred = _deferred, self._outer
+        if self._outer is None and exc_type is None:
+            for c in pending:
+                c.check()
+        return False
+
 
 def _solve_block(n, nrhs, fp64=True):
     """Size of the merged (explicitly inverted) diagonal blocks used by the triangular solves --
@@ -106,7 +148,10 @@ class Chol:
             dinv, info = be.potrf_(a, config.potrf_nbo)
             c = cls(a, dinv, info)
         if config.check_info:
-            c.check()
+            if _deferred is not None:
+                _deferred.append(c)       # checked when the enclosing `deferred_checks()` block ends
+            else:
+                c.check()
         return c
 
     def check(self):

@@ -15,6 +15,8 @@ def _noise_as_matrix(noise, x, n):
         return Zero(x.dtype, n, n, device=x.device, batch=tuple(x.shape[:-2]))
     if isinstance(noise, AbstractMatrix):
         return noise
+    if isinstance(noise, (int, float)) and not isinstance(noise, bool):
+        noise = torch.full((), float(noise), dtype=x.dtype, device=x.device)      # (a fill on the device: no host-to-device copy to wait for)
     if not torch.is_tensor(noise):
         noise = torch.as_tensor(noise, dtype=x.dtype, device=x.device)
     noise = noise.to(dtype=x.dtype, device=x.device)

@@ -7,7 +7,7 @@ import torch
 
 from .. import kernels as _k
 from .. import ops
-from ..matrix import AbstractMatrix, ChainChol, Chol, Dense, Diagonal, FactoredDense, KernelDense, Zero, config
+from ..matrix import AbstractMatrix, ChainChol, Chol, Dense, Diagonal, FactoredDense, KernelDense, Zero, any_missing, config
 from .fdd import FDD, take
 from .gp import cross
 
@@ -105,8 +105,8 @@ class AbstractObservations:
             raise ValueError(f"Invalid shape of observed values {y_shape}.")
         # Missing data (host sync, as in the reference: observations.py:73-76; opt out with `config.check_nan = False`).
         if config.check_nan and y.dim() == 2:
-            available = ~torch.isnan(y[:, 0])
-            if not bool(available.all()):
+            if any_missing(y):
+                available = ~torch.isnan(y[:, 0])
                 fdd = take(fdd, available)
                 y = y[torch.nonzero(available)[:, 0]]
         self.fdd = fdd

@@ -12,7 +12,7 @@ import types
 import torch
 
 from . import ops
-from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, config, to_matrix
+from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, any_missing, config, deferred_checks, to_matrix
 
 __all__ = ["Random", "RandomProcess", "RandomVector", "Normal"]
 
@@ -210,8 +210,8 @@ class Normal(RandomVector):
 
         # Missing data (not for batched computation): random.py:261-270.
         if config.check_nan and x.dim() == 2 and x.shape[1] == 1:
-            available = ~torch.isnan(x[:, 0])
-            if not bool(available.all()):
+            if any_missing(x):
+                available = ~torch.isnan(x[:, 0])
                 idx = torch.nonzero(available)[:, 0]
                 mean = self.mean[idx]
                 var = self.var
@@ -284,11 +284,12 @@ class Normal(RandomVector):
                 )
         if isinstance(var, Zero):
             raise torch.linalg.LinAlgError("the variance is identically zero")
-        logdet = var.logdet()
-        # (a zero prior mean: `r` IS `x`; naming it lets the factor hand the same L^{-1} y to the posterior mean later)
-        src = x if (getattr(self, "_zero_mean", False) and isinstance(var, Dense)) else None
-        iqf = var.iqf_diag(r, src) if src is not None else var.iqf_diag(r)
-        logpdfs = -(logdet[..., None] + n * LOG_2_PI + iqf) / 2
+        with deferred_checks():      # the factor's `info` is read after the log-determinant and the solve are queued behind it
+            logdet = var.logdet()
+            # (a zero prior mean: `r` IS `x`; naming it lets the factor hand the same L^{-1} y to the posterior mean later)
+            src = x if (getattr(self, "_zero_mean", False) and isinstance(var, Dense)) else None
+            iqf = var.iqf_diag(r, src) if src is not None else var.iqf_diag(r)
+            logpdfs = -(logdet[..., None] + n * LOG_2_PI + iqf) / 2
         return (logpdfs[..., 0] if logpdfs.shape[-1] == 1 else logpdfs), False
 
     def entropy(self):
