@@ -94,7 +94,13 @@ int64_t gpk_dinv_elems(int64_t n);
  * diagonal block ([batch][ceil(n/128)][128][128], identity-padded); `info`
  * (int per batch entry, MUST be zeroed by the caller) receives the LAPACK-style
  * order of the first non-positive pivot, 0 if none.  nbo: outer block of the right-looking
- * sweep (128 * 2^k; <= 0 selects the default: 1024 for n >= 8192, 512 for n >= 2048, else 256).
+ * sweep (128 * 2^k; <= 0 selects the default -- one matrix: the whole matrix up to n = 4096, else 1024; batches: 1024 for
+ * n >= 8192, 512 for n >= 2048, else 256).
+ * ONE matrix (batch == 1) is factorised panel by panel with ONE launch per panel of nbo columns (+ a memset of its control words,
+ * which live in a `dinv` slot the panel does not write): a chain workgroup factorises and inverts the diagonal blocks, the other
+ * workgroups take the solves and updates of the panel as tasks and wait for each other through flag words in device memory
+ * (gpk_potrf.hip, potrf_pipe_kernel; the task list is deadlock-free whatever part of the grid is resident).  A workgroup that
+ * waited for seconds gives up and makes all others leave: `info` = -1 then (never observed; the factor is unusable).
  * Replaces `B.cholesky(B.reg(K))` (LAPACK potrf): implicit under B.logdet / B.iqf_diag at
  * stheno/random.py:274-276, explicit at stheno/model/observations.py:300. */
 int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,

@@ -12,6 +12,9 @@ timeout 600 ./gpk_selftest --only-perf > $O/r03_native_perf.log 2>&1
 timeout 300 ./gpk_selftest --perf-la > $O/r03_native_perf_lookahead.log 2>&1
 timeout 200 ./gpk_selftest --perf-kmat > $O/r03_native_perf_kmat.log 2>&1
 timeout 300 ./gpk_selftest --perf-trsm > $O/r03_native_perf_trsm.log 2>&1
+timeout 200 ./gpk_selftest --perf-pipe > $O/r03_native_perf_pipelined_panel.log 2>&1
+timeout 300 ./gpk_selftest --perf-la-tail > $O/r03_native_perf_plain_vs_lookahead.log 2>&1
+( cd $R/scripts/dev && timeout 60 ./store_cost ) > $O/r03_store_cost.log 2>&1
 timeout 200 ./gpk_selftest --diagprof 2048 > $O/r03_diag_kernel_phases.log 2>&1
 ( cd $R/scripts/dev && timeout 60 ./mfma_latency ) > $O/r03_mfma_latency.log 2>&1
 cd /tmp

@@ -156,8 +156,14 @@ class Chol:
 
     def check(self):
         if not self._checked:
-            bad = int(self.info.max().item()) if self.info.numel() else 0
+            bad = 0
+            if self.info.numel():
+                lo, hi = torch.stack(tuple(torch.aminmax(self.info))).tolist()       # (one host read)
+                bad = lo if lo < 0 else hi
             self._checked = True
+            if bad < 0:
+                raise RuntimeError("cholesky: the workgroups of the pipelined panel kernel stopped waiting for each other (gpk.h: info = -1); "
+                                   "the factor is unusable -- please report this")
             if bad != 0:
                 raise torch.linalg.LinAlgError(
                     f"cholesky: the leading minor of order {bad} is not positive-definite "
