@@ -28,5 +28,5 @@ for w in dense_f64 sum_f32 batched_f32 sparse_f32; do
   rm -rf $O/stats_$w
   timeout 600 python $R/scripts/collect_pmc.py $w $O/r03_pmc_$w.json > $O/r03_pmc_$w.log 2>&1
 done
-GPK_BENCH_FORCE_DIST=1 NCCL_DEBUG=WARN MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python $R/bench.py --workload batched_f32 --no-cpu-baseline 2>/dev/null | grep "^{" | tail -1 > $O/r03_bench_batched_f32_rccl_1rank.json
+GPK_BENCH_FORCE_DIST=1 NCCL_DEBUG=WARN NCCL_DEBUG_FILE=$O/r03_bench_batched_f32_rccl_1rank_nccl.log MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python $R/bench.py --workload batched_f32 --no-cpu-baseline 2>/dev/null | grep "^{" | tail -1 > $O/r03_bench_batched_f32_rccl_1rank.json
 ls -la $O | head -50
