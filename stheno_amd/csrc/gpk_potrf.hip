@@ -939,6 +939,11 @@ struct PipeArgs {
     int ntasks, nseg;
     int segoff[GPK_PIPE_MAX_SEGS + 1];   // first task of segment k (gpk_potrf_pipe.hpp)
     long long* prof;   // 32 stamps per diagonal block (nullable)
+    // FILL: the part of the PREVIOUS panel's rank-K update that this panel does not touch (the lower triangle right of it), as
+    // 128 x 128 tiles from a second counter (ctrl[2]) for the workers the chain-bound panel leaves idle; fill_tiles == 0: none
+    GemmArgs<T> fill;
+    int fill_tiles;
+    int panel_wgs;     // workgroups 1 .. panel_wgs take panel tasks first and fill tiles afterwards, the others the other way round
 };
 
 // wave 0 of the workgroup: lane i < count waits for *w_i == want.  false = aborted.
@@ -1038,11 +1043,33 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
     g.vec_ok = p.vec_ok;
     int k = 0;
+    const bool fill_first = (int)blockIdx.x > p.panel_wgs;
+    bool fill_left = p.fill_tiles > 0, panel_left = true;
     for (;;) {
+        if (fill_left && (fill_first || !panel_left)) {
+            // a tile of the previous panel's trailing update: nothing in this launch depends on it or feeds it
+            if (tid == 0) s_ctl[0] = (int)__hip_atomic_fetch_add(p.ctrl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int ft = s_ctl[0];
+            __syncthreads();
+            if (ft >= p.fill_tiles) {
+                fill_left = false;
+                continue;
+            }
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= ft) ++ti;
+            gemm_tile<T, 128, true, true, EDGE, 1, D3_WAVES>(p.fill, ti, ft - ti * (ti + 1) / 2, 0, 0, smem);
+            continue;
+        }
+        if (!panel_left) return;
         if (tid == 0) s_ctl[0] = (int)__hip_atomic_fetch_add(p.ctrl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int t = s_ctl[0];
-        if (t >= p.ntasks) return;
+        __syncthreads();
+        if (t >= p.ntasks) {
+            panel_left = false;
+            continue;
+        }
         while (t >= p.segoff[k + 1]) ++k;
         const PipeTask tk = pipe_decode(p.sh, k, t - p.segoff[k]);
         const int j = tk.j;
@@ -1111,7 +1138,8 @@ template <typename T, bool EDGE>
 __global__ __launch_bounds__(D3_THREADS, 2) void potrf_pipe_kernel(PipeArgs<T> p) {
     __shared__ __attribute__((aligned(16))) T S[D3_LDS_ELEMS];
     __shared__ int s_ctl[4];
-    static_assert(sizeof(T) * D3_LDS_ELEMS >= 2 * 5 * op_bytes(GPK_PIPE_FINE) && sizeof(T) * D3_LDS_ELEMS >= 2 * 3 * op_bytes(GPK_PIPE_STRIP),
+    static_assert(sizeof(T) * D3_LDS_ELEMS >= 2 * 5 * op_bytes(GPK_PIPE_FINE) && sizeof(T) * D3_LDS_ELEMS >= 2 * 3 * op_bytes(GPK_PIPE_STRIP) &&
+                      sizeof(T) * D3_LDS_ELEMS >= 2 * 2 * op_bytes(128),
                   "the worker's operand tiles live in the chain's block");
     if (blockIdx.x == 0) pipe_chain<T>(p, S, s_ctl);
     else pipe_worker<T, EDGE>(p, reinterpret_cast<char*>(S), s_ctl);
@@ -1206,13 +1234,17 @@ int g_fused_step = 1;              // tuning knob (gpk_tune(32, v)): single matr
 
 int g_pipe = 1;                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
 int g_pipe_cus = 0;                // CUs of the current device (queried once)
+int g_pipe_fill = 1;               // tuning knob (gpk_tune(38, v)): the trailing update right of the NEXT panel rides along in that panel's launch
+int g_pipe_panel_wgs = 0;          // tuning knob (gpk_tune(39, v)): workgroups that take panel tasks first when a launch carries fill tiles (0: a third of the CUs)
 
 // The same panel in ONE launch (potrf_pipe_kernel) -- plus a memset of its control words and, when the panel reaches the last row of
 // the matrix, the diagonal-block kernel for the last block (the control words live in the `dinv` slot of the first diagonal block
 // the kernel does NOT factorise: the block behind the panel, or that last block).  GPK_OK + *done = false: the shape does not fit
 // (more than GPK_PIPE_MAX_BLOCKS blocks, control words beyond one slot), nothing was enqueued.
+// fill_k > 0: the columns [c0 - fill_k, c0) are a finished panel whose rank-fill_k update has been applied up to column c0 + w only;
+// the rest of it -- the lower triangle from row / column c0 + w on -- rides along in this launch (PipeArgs::fill).
 template <typename T>
-int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done) {
+int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, int64_t fill_k = 0) {
     *done = false;
     const int64_t ke = (c0 + w < x.n) ? c0 + w : x.n;
     const int64_t m = x.n - c0;
@@ -1260,8 +1292,31 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done) {
     if (workers > cus - 1) workers = cus - 1;
     if (workers < 1) workers = 1;
     if (pa.ntasks == 0) workers = 0;
+    pa.fill_tiles = 0;
+    pa.panel_wgs = (int)workers;
+    bool fill_edge = false;
+    if (fill_k > 0 && ke < x.n) {
+        const int64_t mf = x.n - ke;
+        GemmArgs<T>& g = pa.fill;
+        const T* P = x.A + ke * x.ld + (c0 - fill_k);
+        g.A = P; g.B = P; g.C = x.A + ke * x.ld + ke; g.Cin = g.C;
+        g.lda = x.ld; g.ldb = x.ld; g.ldc = x.ld; g.ldcin = x.ld;
+        g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
+        g.M = (int)mf; g.N = (int)mf; g.K = (int)fill_k;
+        g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
+        g.tiles_m = (int)gpk_cdiv(mf, 128); g.tiles_n = g.tiles_m;
+        g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
+        g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
+        g.vec_ok = aligned ? 1 : 0;
+        fill_edge = !aligned || (mf % 128) || (fill_k % Traits<T>::BK);
+        pa.fill_tiles = g.tiles_m * (g.tiles_m + 1) / 2;
+        // the panel is chain-bound: a third of the chip keeps its task list moving, the rest starts with the fill tiles
+        workers = cus - 1;
+        pa.panel_wgs = g_pipe_panel_wgs > 0 ? g_pipe_panel_wgs : (cus - 1) / 3;
+        if (pa.panel_wgs > workers) pa.panel_wgs = (int)workers;
+    }
     if (hipMemsetAsync(pa.ctrl, 0, (size_t)words * sizeof(unsigned), x.stream) != hipSuccess) return GPK_ERR_LAUNCH;
-    const bool edge = !aligned || (m % GPK_PIPE_STRIP) || ((ke - c0) % GPK_DB);
+    const bool edge = !aligned || (m % GPK_PIPE_STRIP) || ((ke - c0) % GPK_DB) || fill_edge;
     if (edge) hipLaunchKernelGGL((potrf_pipe_kernel<T, true>), dim3((unsigned)(1 + workers)), dim3(D3_THREADS), 0, x.stream, pa);
     else hipLaunchKernelGGL((potrf_pipe_kernel<T, false>), dim3((unsigned)(1 + workers)), dim3(D3_THREADS), 0, x.stream, pa);
     GPK_CHECK_LAUNCH();
@@ -1312,15 +1367,46 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     const int64_t dstride = nblk * GPK_DB * GPK_DB;
 
     PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream, info_base};
+    // One matrix, pipelined panels: a panel's launch is chain-bound and leaves most of the chip idle, and all it needs of the
+    // previous panel's rank-nbo update are its own columns.  So that update is split: the strip of the next panel's columns is a
+    // GEMM launch of its own, the rest (the lower triangle right of the next panel) rides along in the next panel's launch as fill
+    // tiles for its idle workers (N = 8192: 5.76 -> 5.4 ms; the last 6144 columns of N = 16384: 3.4 -> 2.9 ms).
+    const bool ride = g_pipe && g_pipe_fill && g_diag_v2 && batch == 1 && dinv != nullptr;
+    int64_t owed = 0;      // width of the previous panel whose update is still owed to the columns from k0 on (0: nothing owed)
     for (int64_t k0 = 0; k0 < n; k0 += nbo) {
         const int64_t k1 = (k0 + nbo < n) ? k0 + nbo : n;
-        int pst = potrf_panel_any<T>(ctx, k0, nbo);
-        if (pst) return pst;
-        if (k1 < n) {
-            const T* P = A + k1 * ld + k0;
-            int st = gpk_gemm_launch<T>(true, true, n - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, P, ld,
-                                        bstride, T(1), A + k1 * ld + k1, ld, bstride, batch, true, stream);
+        bool done = false;
+        if (owed > 0) {
+            // the strip: columns [k0, k1), rows k0 .. n-1
+            const T* P = A + k0 * ld + (k0 - owed);
+            int st = gpk_gemm_launch<T>(true, true, n - k0, k1 - k0, owed, T(-1), P, ld, bstride, P, ld, bstride, T(1), A + k0 * ld + k0, ld,
+                                        bstride, batch, true, stream);
             if (st) return st;
+            if (k1 < n && n - k0 > GPK_DB) {
+                st = potrf_panel_pipe<T>(ctx, k0, nbo, &done, owed);
+                if (st) return st;
+            }
+            if (!done && k1 < n) {      // the panel did not take it along: the rest of the update as a launch of its own
+                const T* P2 = A + k1 * ld + (k0 - owed);
+                st = gpk_gemm_launch<T>(true, true, n - k1, n - k1, owed, T(-1), P2, ld, bstride, P2, ld, bstride, T(1), A + k1 * ld + k1, ld,
+                                        bstride, batch, true, stream);
+                if (st) return st;
+            }
+            owed = 0;
+        }
+        if (!done) {
+            int pst = potrf_panel_any<T>(ctx, k0, nbo);
+            if (pst) return pst;
+        }
+        if (k1 < n) {
+            if (ride && n - k1 > GPK_DB) {
+                owed = k1 - k0;
+            } else {
+                const T* P = A + k1 * ld + k0;
+                int st = gpk_gemm_launch<T>(true, true, n - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, P, ld,
+                                            bstride, T(1), A + k1 * ld + k1, ld, bstride, batch, true, stream);
+                if (st) return st;
+            }
         }
     }
     return GPK_OK;
@@ -1360,7 +1446,7 @@ std::mutex g_la_mutex;
 LaDevice g_la_dev[64];
 int64_t g_la_min_rows = 2048;     // tuning knob (gpk_tune(6, v)): overlap while the trailing matrix has >= this many rows
 int64_t g_la_tail_rows = 0;       // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path;
-                                  // 0 = by block width: 4096 with nb <= 512, 6144 above (N = 8192, nb = 512: 6.69 vs 7.04 ms)
+                                  // 0 = 6144 (with the pipelined plain panels: fp64 N = 16384 26.6 ms at 6144, 27.6 at 4096, 27.0 at 8192; fp32 nb = 512 N = 16384 15.5 / 15.7)
 int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
 int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
 int g_la_rejoin = 1;              // tuning knob (gpk_tune(18, v)): reserved CUs rejoin the trailing update after the chain
@@ -1430,6 +1516,8 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 30) g_diag_v2 = (int)value;
     if (key == 32) g_fused_step = (int)value;
     if (key == 37) g_pipe = (int)value;
+    if (key == 38) g_pipe_fill = (int)value;
+    if (key == 39) g_pipe_panel_wgs = (int)value;
 }
 
 #define GPK_LA_PAD 16
@@ -1495,7 +1583,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         return gpk_trtri_merge_launch<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB),
                                          nb, dinv_big + (k / nb) * per, Tp, stream);   // the panel workspace is free by now
     };
-    const int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : (nb <= 512 ? 4096 : 6144);
+    const int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : 6144;
     if (n <= tail_rows) return finish_plain(0);
 
     int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, 0, stream);

@@ -1679,6 +1679,18 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--census")) { census(); return 0; }
         if (!strcmp(argv[i], "--perf-kmat")) { perf_kmat(); return 0; }
+        if (!strcmp(argv[i], "--perf-fill") && i + 1 < argc) {      // --perf-fill N: plain POTRF at N for several splits of the workers between panel tasks and fill tiles
+            const int n = atoi(argv[i + 1]);
+            for (int wg : {-1, 16, 32, 48, 64, 85, 128, 170}) {
+                gpk_tune(38, wg < 0 ? 0 : 1);
+                gpk_tune(39, wg < 0 ? 0 : wg);
+                printf("FILL panel workgroups %d (fill %s):\n", wg, wg < 0 ? "off" : "on");
+                perf_la_tail<double>({n});
+                perf_la_tail<float>({n});
+            }
+            gpk_tune(38, 1); gpk_tune(39, 0);
+            return 0;
+        }
         if (!strcmp(argv[i], "--perf-la-tail")) { perf_la_tail<double>({6144, 8192, 10240, 12288, 16384}); perf_la_tail<float>({8192, 12288, 16384, 32768}); return 0; }
         if (!strcmp(argv[i], "--perf-pipe")) { perf_pipe<double>(); perf_pipe<float>(); return 0; }
         if (!strcmp(argv[i], "--perf-trsm")) { perf_trsm<double>(16384, 2048); perf_trsm<float>(32768, 2048); return 0; }

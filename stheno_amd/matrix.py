@@ -28,17 +28,20 @@ class _Config:
     check_nan = True
     #: outer block of the blocked Cholesky (0 = library default)
     potrf_nbo = 0
-    #: single matrices of at least this order take the look-ahead factorisation (``gpk_potrf_la``); 0 disables it
-    potrf_lookahead_from = 7168
-    #: its outer block = the order of the explicitly inverted diagonal blocks: 512 below `potrf_lookahead_wide_from`, else the
-    #: per-dtype value (measured on MI355X, fp64 / fp32 alike: N = 8192: 6.95 ms at 512, 7.42 at 1024, 7.33 plain;
-    #: N = 12288: 15.1 / 15.6 / 16.8; N = 14336: 21.5 / 21.2 / 23.7; N = 16384: 29.8 / 28.7 / 32.6)
+    #: single matrices of at least this order take the look-ahead factorisation (``gpk_potrf_la``); 0 disables it.  Below, the plain
+    #: path (one pipelined launch per 1024-column panel, the rest of each trailing update riding along in the next panel's launch) is
+    #: as fast or faster -- measured on MI355X at the end of round 3 (`profiles/r03_native_perf_plain_vs_lookahead.log`), plain / best
+    #: look-ahead: fp64 N = 8192 5.21 / 5.48 ms, 10240 8.71 / 8.79, 12288 13.79 / 13.32, 16384 29.5 / 26.6; fp32 N = 8192 3.27 / 3.49,
+    #: 12288 7.82 / 7.76, 16384 16.1 / 15.0 (15.5 with the 512-blocks fp32 uses)
+    potrf_lookahead_from = 11264
+    #: its outer block = the order of the explicitly inverted diagonal blocks: the per-dtype value from `potrf_lookahead_wide_from` on,
+    #: 512 below (no such order is left with the defaults: at N = 12288 fp64, 1024-blocks 13.32 ms, 512-blocks 13.47)
     #: fp32 stays at 512-blocks at every order: the rows below a diagonal block are multiplied by its EXPLICIT inverse, and in fp32 the
     #: posterior mean pays for the width of that inverse -- cfg3 at its full N = 32768 against fp64 on the device: mean error
     #: 1.00e-3 with 1024-blocks, 7.3e-4 with 512-blocks (6.2e-4 with 256-block solves on top), 1.6e-3 with 2048; 3 % slower
     #: (scripts/dev_fp32_fullsize_accuracy.py).  north_star's fp32 bar is 1e-3.
     potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 512}
-    potrf_lookahead_wide_from = 14336
+    potrf_lookahead_wide_from = 11264
 
 
 config = _Config()

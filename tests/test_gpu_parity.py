@@ -323,14 +323,19 @@ def test_normal_arithmetic_and_kl_on_device():
 
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 8192 + 37), (torch.float32, 8192 + 128)])
 def test_lookahead_factorisation_through_the_api(dtype, n):
-    """Orders from 7168 take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
+    """Large orders (``matrix.config.potrf_lookahead_from``) take ``gpk_potrf_la`` (look-ahead, helper stream, persistent trailing update, plain tail): the factor
     against LAPACK, the merged block inverses it returns against what the solves then compute, ragged order included."""
     from stheno_amd import matrix
 
     rng = np.random.default_rng(n)
     x = rng.standard_normal((n, 4))
     k = O.kernel_matrix([("eq", 1.0, 1.0)], x) + 0.5 * np.eye(n)
-    c = Chol.factor_(dev(k, dtype).clone())
+    first = matrix.config.potrf_lookahead_from
+    matrix.config.potrf_lookahead_from = min(first, n)                # (the default threshold is above this order: measured crossover)
+    try:
+        c = Chol.factor_(dev(k, dtype).clone())
+    finally:
+        matrix.config.potrf_lookahead_from = first
     nb = 512 if n < matrix.config.potrf_lookahead_wide_from else matrix.config.potrf_lookahead_nb[dtype]
     assert c.lookahead_nb == nb                                       # the look-ahead path ran
     # the block inverses it leaves behind are what the merge of the 128-block inverses computes (they are kept with the factor
