@@ -121,11 +121,13 @@ struct GpkSeg {
     T* C; int64_t ldc;
     int lower_only;
     int tri_b;      // B (N x K) is lower triangular: k stops at the column tile's last column (2: pair column tiles c, n-1-c)
+    int signal;     // every finished tile of this segment is announced: ctrl[2] += 1 behind an agent-scope release (somebody polls it)
 };
-// Cin == nullptr: C = alpha * A B^T (nothing is read from C)
+// Cin == nullptr: C = alpha * A B^T (nothing is read from C).  Up to three segments per launch, handed out in order.
 struct GpkPersistSaved {       // what a reserving launch was made of, for gpk_gemm_persist_rejoin
-    alignas(16) char bytes[768];
+    alignas(16) char bytes[1024];
     int ts, edge, per_cu, valid;
+    int signal_tiles;          // tiles of the segments with `signal` set: what ctrl[2] counts up to (set whenever `saved` is given)
 };
 template <typename T>
 int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,

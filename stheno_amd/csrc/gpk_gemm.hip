@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_trib_kernel(GemmArgs<T> p) {
 // ctrl[0] = tile counter, ctrl[1] = leavers; zeroed by the launcher (memset node) per launch.
 template <typename T>
 struct PersistArgs {
-    GemmArgs<T> seg[2];
-    int ntiles0, ntiles;      // tiles of segment 0, of both
+    GemmArgs<T> seg[3];
+    int first[4];             // first tile of segment i (first[nseg] = all tiles; unused segments are empty)
+    int sig[3];               // GpkSeg::signal
+    int ntiles;               // all tiles
     int ntasks, split_from;   // tasks = tiles, except that the tiles from split_from on are handed out as four quarter tiles each
     unsigned* ctrl;
     int reserve;
@@ -207,10 +209,10 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
         const bool quarter = (TS == 128) && t >= p.split_from;
         const int quad = quarter ? ((t - p.split_from) & 3) : 0;
         const int tt = quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
-        const int sgi = (tt >= p.ntiles0) ? 1 : 0;
+        const int sgi = (tt >= p.first[2]) ? 2 : ((tt >= p.first[1]) ? 1 : 0);
         const GemmArgs<T>& g = p.seg[sgi];
         int ti, tj;
-        const int tl = tt - (sgi ? p.ntiles0 : 0);
+        const int tl = tt - p.first[sgi];
         int reps = 1;
         bool ok = true;
         if (g.tri_k_lo_b && g.pair_cols) {
@@ -237,6 +239,14 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
 #pragma unroll 1
             for (int r = 0; r < reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
                 gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem, pr);
+            if (p.sig[sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
+                __syncthreads();               // every wave's stores of the tile are out (vmcnt drained before the barrier)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(&p.ctrl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
         if (tid == 0) s_tile = nxt;
         __syncthreads();
@@ -601,8 +611,8 @@ void gpk_helper_shutdown() {
 template <typename T>
 int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,
                             hipStream_t stream, GpkPersistSaved* saved, bool ctrl_zeroed) {
-    if (saved != nullptr) saved->valid = 0;
-    if (nseg < 1 || nseg > 2) return GPK_ERR_ARG(2);
+    if (saved != nullptr) { saved->valid = 0; saved->signal_tiles = 0; }
+    if (nseg < 1 || nseg > 3) return GPK_ERR_ARG(2);
     if (ctrl == nullptr) return GPK_ERR_ARG(4);
     if (alpha == T(0)) return GPK_ERR_ARG(3);
     constexpr int VEC = Traits<T>::VEC;
@@ -647,13 +657,16 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         int64_t nt = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
         g.pair_cols = (q.tri_b == 2 && !g.lower_only && g.tiles_n >= 2 && g.tiles_n % 2 == 0) ? 1 : 0;
         if (g.pair_cols) nt = (int64_t)g.tiles_m * (g.tiles_n / 2);
-        if (live == 0) pa.ntiles0 = (int)nt;
+        pa.first[live] = (int)total;
+        pa.sig[live] = q.signal ? 1 : 0;
+        if (q.signal && saved != nullptr) saved->signal_tiles += (int)nt;
         total += nt;
         flops += (q.lower_only || q.tri_b ? 1.0 : 2.0) * (double)q.M * (double)q.N * (double)q.K;
         ++live;
     }
-    if (live == 1) { pa.seg[1] = pa.seg[0]; }
     if (total > INT32_MAX / 2) return GPK_ERR_ARG(1);
+    for (int i = live; i < 3; ++i) { pa.seg[i] = pa.seg[0]; pa.sig[i] = 0; }
+    for (int i = live; i <= 3; ++i) pa.first[i] = (int)total;      // (empty segments: never selected)
     pa.ntiles = (int)total;
     pa.ntasks = (int)total;
     pa.split_from = INT32_MAX;

@@ -941,6 +941,8 @@ struct PipeArgs {
     long long* prof;   // 32 stamps per diagonal block (nullable)
     // FILL: the part of the PREVIOUS panel's rank-K update that this panel does not touch (the lower triangle right of it), as
     // 128 x 128 tiles from a second counter (ctrl[2]) for the workers the chain-bound panel leaves idle; fill_tiles == 0: none
+    unsigned* wait_word;   // see PanelCtx (nullable)
+    unsigned wait_value;
     GemmArgs<T> fill;
     int fill_tiles;
     int panel_wgs;     // workgroups 1 .. panel_wgs take panel tasks first and fill tiles afterwards, the others the other way round
@@ -1015,6 +1017,8 @@ __device__ __forceinline__ void pipe_chain(const PipeArgs<T>& p, T* __restrict__
         if (j > 0) {                       // every tile of the block has received the update of step j - 1
             unsigned* c = cnt + (int64_t)(2 * j) * npb + j;
             if (!pipe_wait(c, c, c, c, (unsigned)pipe_xupdates(pipe_fine_strips(p.sh, j - 1)), 0u, 0u, 0u, 1, abort_word, s_ctl)) break;
+        } else if (p.wait_word != nullptr) {   // the launch that updates this panel's first block is still running beside this one
+            if (!pipe_wait(p.wait_word, p.wait_word, p.wait_word, p.wait_word, p.wait_value, 0u, 0u, 0u, 1, abort_word, s_ctl)) break;
         }
         if (prof && j > 0) prof[30 - 32] = wall_clock64();          // (development stamps, 100 MHz: the critical path of step j - 1 ends here)
         diag3_block<T, true>(S, rdiag, Ab, ld, rem < GPK_DB ? rem : GPK_DB, W, p.info, p.info_off + GPK_DB * j, 0, prof);
@@ -1166,6 +1170,8 @@ struct PanelCtx {
     hipStream_t stream;
     int info_base;
     int max_wgs = 0;   // workgroups a persistent launch on `stream` may count on at once (0: every CU of the device; a CU-masked stream: its CUs)
+    unsigned* wait_word = nullptr;   // the first diagonal block of the next panel is ready when *wait_word == wait_value (another
+    unsigned wait_value = 0;         // kernel, on another stream, is still writing it when the panel's launch starts); nullptr: it is ready
 };
 
 // Factor the panel columns [c0, c0 + w) (rows c0..n), all updates from columns
@@ -1292,6 +1298,8 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
     if (workers > cus - 1) workers = cus - 1;
     if (workers < 1) workers = 1;
     if (pa.ntasks == 0) workers = 0;
+    pa.wait_word = x.wait_word;
+    pa.wait_value = x.wait_value;
     pa.fill_tiles = 0;
     pa.panel_wgs = (int)workers;
     bool fill_edge = false;
@@ -1333,12 +1341,25 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
     return GPK_OK;
 }
 
+// one wave that returns when *word == value (bounded like the polls of the pipelined panel): puts a stream behind a device-side flag
+__global__ void wait_word_kernel(unsigned* word, unsigned value) {
+    if (threadIdx.x == 0) {
+        unsigned it = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value && ++it < PIPE_SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
 template <typename T>
 int potrf_panel_any(const PanelCtx<T>& x, int64_t c0, int64_t w) {
     if (g_pipe && g_diag_v2 && x.batch == 1 && x.dinv != nullptr && x.n - c0 > GPK_DB) {
         bool done = false;
         const int st = potrf_panel_pipe<T>(x, c0, w, &done);
         if (st || done) return st;
+    }
+    if (x.wait_word != nullptr) {      // the paths below start from the diagonal block right away
+        hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, x.stream, x.wait_word, x.wait_value);
+        GPK_CHECK_LAUNCH();
     }
     // the flag words of a step (one per strip of 32 rows below it, 1024 at most) need the dinv slot of the next block: n < 32768
     if (g_fused_step && x.batch == 1 && x.dinv != nullptr && x.n - c0 <= 32768) return potrf_panel_fused<T>(x, c0, w);
@@ -1451,6 +1472,8 @@ int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM a
 int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
 int g_la_rejoin = 1;              // tuning knob (gpk_tune(18, v)): reserved CUs rejoin the trailing update after the chain
 int g_la_mode = 1;                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
+int64_t g_la_fuse_diag_rows = 9216;   // tuning knob (gpk_tune(40, v)): the update of the next diagonal block rides in the trailing update while that has >= this many rows (0: never)
+int g_la_fuse_diag_nb = 512;          // tuning knob (gpk_tune(41, v)): ... and only for outer blocks up to this width
 
 LaDevice* la_device() {
     int dev = 0;
@@ -1475,12 +1498,12 @@ hipEvent_t la_event(LaDevice& d, size_t i) {
 
 template <typename T>
 int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tmp, int* info, int64_t j,
-             hipStream_t s, int max_wgs = 0) {
+             hipStream_t s, int max_wgs = 0, unsigned* wait_word = nullptr, unsigned wait_value = 0) {
     const int64_t k0 = j * nb;
     const int64_t w = (n - k0 < nb) ? n - k0 : nb;
     T* Ab = A + k0 * ld + k0;
     T* d128 = dinv128 + (k0 / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
-    PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0, max_wgs};
+    PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0, max_wgs, wait_word, wait_value};
     int st = potrf_panel_any<T>(sub, 0, nb);
     if (st) return st;
     return gpk_trtri_merge_launch<T>(Ab, w, ld, 1, 0, d128, nb, dinv_big + j * (int64_t)nb * nb, tmp, s);
@@ -1516,6 +1539,8 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 30) g_diag_v2 = (int)value;
     if (key == 32) g_fused_step = (int)value;
     if (key == 37) g_pipe = (int)value;
+    if (key == 40) g_la_fuse_diag_rows = value;
+    if (key == 41) g_la_fuse_diag_nb = (int)value;
     if (key == 38) g_pipe_fill = (int)value;
     if (key == 39) g_pipe_panel_wgs = (int)value;
 }
@@ -1612,11 +1637,20 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             if (st) return st;
             return finish_plain(k1);
         }
-        // diag(j+1)
-        st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, nb, T(-1), P1, ld, 0, P1, ld, 0, T(1),
-                                A + k1 * ld + k1, ld, 0, 1, 1, stream);
-        if (st) return st;
         const bool overlap = g_la_mode == 1 && dev->aux != nullptr && (n - k2) >= g_la_min_rows;
+        // diag(j+1): a launch of its own -- or, while the trailing update is long enough to hide a chain that starts a tile later, the
+        // FIRST tiles of that update: the chain's kernel waits for them through a counter word instead of a kernel boundary
+        // (one dependent launch less on the main stream per step)
+        // (measured: fp32 N = 32768 with 512-blocks, 60 steps: cfg3 127.8 -> 127.0 ms; fp64 N = 16384 with 1024-blocks, 10 steps whose
+        // 36 diagonal tiles take ~300 us as 128-tiles of the persistent kernel against 46 us as a launch of 64-tiles: 26.7 -> 26.8 ms.
+        // So: blocks up to 512 only.)
+        const bool fuse_diag = overlap && nb <= g_la_fuse_diag_nb && g_la_fuse_diag_rows > 0 && (n - k2) >= g_la_fuse_diag_rows && g_pipe && g_diag_v2 &&
+                               (k2 - k1) > GPK_DB;
+        if (!fuse_diag) {
+            st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, nb, T(-1), P1, ld, 0, P1, ld, 0, T(1),
+                                    A + k1 * ld + k1, ld, 0, 1, 1, stream);
+            if (st) return st;
+        }
         hipEvent_t e_fork = nullptr, e_join = nullptr;
         if (overlap) {
             e_fork = la_event(*dev, ev++);
@@ -1639,16 +1673,19 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             // ~0.3 ms for those, which the main stream would otherwise spend idle
             if (k2 < n) {
                 const T* P2 = A + k2 * ld + k0;
-                GpkSeg<T> seg[2];
+                GpkSeg<T> seg[3];
+                const int d = fuse_diag ? 1 : 0;
+                if (fuse_diag) seg[0] = GpkSeg<T>{k2 - k1, k2 - k1, nb, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0, 1};
                 const int so = g_la_strip_last ? 1 : 0;   // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
-                seg[so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
-                seg[1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
-                const int s2 = gpk_gemm_persist_launch<T>(seg, 2, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
+                seg[d + so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
+                seg[d + 1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
+                const int s2 = gpk_gemm_persist_launch<T>(seg, 2 + d, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
                 if (s2) return s2;
             }
             if (overlap) {
                 if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-                const int s2 = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux, 8);
+                const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux, 8, ctrl + 2, (unsigned)saved.signal_tiles)
+                                         : la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux, 8);
                 if (s2) return s2;
                 if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
                     return gpk_gemm_persist_rejoin<T>(&saved, dev->aux);

@@ -574,6 +574,11 @@ static void test_lookahead() {
     test_potrf_la_case<T>(3000, 1024, 1, 1024);
     test_potrf_la_case<T>(4096, 1024, 1, 0);
     test_potrf_la_case<T>(5000, 512, 1, 2048);
+    gpk_tune(40, 256); gpk_tune(41, 4096);              // the next diagonal block's update inside the trailing update, at these small orders and every block width
+    test_potrf_la_case<T>(4096, 1024, 1, 0);
+    test_potrf_la_case<T>(5000, 512, 1, 1024);
+    test_potrf_la_case<T>(6000, 256, 1, 0, 700);
+    gpk_tune(40, 9216); gpk_tune(41, 512);
     test_potrf_la_case<T>(10, 256, 1, 0, 5120);        // all plain + merge
     test_potrf_la_case<T>(1200, 512, 1, 0, 5120);
     test_potrf_la_case<T>(1664, 256, 1, 0, 700);       // look-ahead, then a plain tail
