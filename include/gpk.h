@@ -268,13 +268,21 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * measured optima, the product path never calls these.  key 1: use 64x64 GEMM tiles below this many 128-tiles;
  * 2: XCD super-tile order from this many tiles; 4: row-pair tile order from this many tiles; 6: look-ahead overlaps while the trailing matrix has at least this many
  * rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the persistent update takes 64x64 tiles
- * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm (0 = 4096 with blocks up to 512, 6144 above);
+ * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm (0 = 6144);
  * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
  * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 13: column-major GEMM tile order from this ratio of
  * tile columns to tile rows (off by default); 17: 1 = one-workgroup-per-matrix TRSV for batches of small factors;
  * 18: 1 = the CUs reserved for the look-ahead chain rejoin the trailing update once the chain is done (default);
- * 20: gpk_tune_tile_prof stamps only the v-th persistent launch since this knob was set (-1 = every launch).
- * gpk_tune_diag_prof: device buffer (16 int64 per diagonal block, or NULL) for cycle stamps of the diagonal-block kernel. */
+ * 20: gpk_tune_tile_prof stamps only the v-th persistent launch since this knob was set (-1 = every launch);
+ * 30: 1 = 512-thread diagonal-block kernel (default), 0 = the 256-thread kernel of rounds 1-2; 31: quarter tiles for the last partial
+ * round of a 128-tile GEMM launch; 32: fused panel-step kernel (batched / fallback path); 34: compact 1-D grid for lower-triangle
+ * kernel matrices; 36: triangular-operand fragment skipping in panel solves; 37: 1 = one pipelined launch per panel for single
+ * matrices (default), 0 = diagonal-block kernel + panel-step kernel per 128 columns; 38: the rest of a panel's trailing update rides
+ * in the next panel's launch; 39: workgroups that take panel tasks first in such a launch (0 = a third of the CUs); 40 / 41: the
+ * look-ahead's update of the next diagonal block is the first segment of the trailing update while that has at least (40) rows
+ * and the outer block is at most (41) wide.
+ * gpk_tune_diag_prof: device buffer (32 int64 per diagonal block, or NULL) for cycle / wall-clock stamps of the diagonal-block
+ * kernel and of the pipelined panel's chain and critical tasks (read by `gpk_selftest --diagprof`). */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);
 /* device buffer (grid x 8 tiles x 8 int64, or NULL): stamps of the persistent update's first 8 tiles per workgroup:
