@@ -8,7 +8,9 @@
  * the native self-test binary (``stheno_amd/csrc/gpk_selftest``) must report ``fail=0``;
  * RCCL on the hardware: the sharded paths of ``stheno_amd/dist.py`` through a one-rank ``nccl`` process group
    (``scripts/rccl_1rank.py``, run with ``NCCL_DEBUG=INFO``; reference semantics ``tests/model/test_cases.py:134-155``);
- * ``gpk_potrf_la`` inside a stream capture (the claim in ``include/gpk.h``).
+ * ``gpk_potrf_la`` inside a stream capture (the claim in ``include/gpk.h``);
+ * the one-launch-per-panel factorisation of single matrices against LAPACK and against the two-launch path, ragged orders, one and
+   several panels, not-PD reporting.
 """
 import hashlib
 import json
@@ -222,3 +224,50 @@ def test_potrf_lookahead_inside_a_stream_capture():
     torch.cuda.synchronize()
     assert int(outs[1].max()) == 0
     assert rel(torch.tril(buf), torch.tril(eager)) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,nbo", [(129, 0), (300, 0), (1000, 256), (2048 + 37, 0), (4096, 0), (5000, 1024), (8192 + 64, 0)])
+def test_pipelined_panel_against_lapack_and_the_two_launch_path(dtype, n, nbo):
+    """``gpk_potrf`` of ONE matrix = one launch per panel (``potrf_pipe_kernel``: chain workgroup + task-queue workers that wait for
+    each other through flag words; with several panels the rest of each trailing update rides in the next panel's launch): the factor
+    and the inverted diagonal blocks against LAPACK on the host and against the path of two launches per 128 columns
+    (``gpk_tune(37, 0)``), at ragged orders, one and several panels; a non-positive pivot is reported with the same order."""
+    from stheno_amd import _native
+
+    lib = _native.load()
+    be = ops.get_backend()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 6, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+    a = st.EQ().pairwise(x, None)
+    a.diagonal().add_(0.2)
+    ref = np.linalg.cholesky(a.double().cpu().numpy())
+    tol = 1e-11 if dtype == torch.float64 else 3e-4
+
+    def factor(mat, pipelined):
+        lib.gpk_tune(37, 1 if pipelined else 0)
+        try:
+            m = mat.clone()
+            dinv, info = be.potrf_(m, nbo)
+            torch.cuda.synchronize()
+        finally:
+            lib.gpk_tune(37, 1)
+        return torch.tril(m), dinv, int(info.max())
+
+    l1, d1, i1 = factor(a, True)
+    l0, d0, i0 = factor(a, False)
+    assert i1 == 0 and i0 == 0
+    assert np.max(np.abs(l1.double().cpu().numpy() - ref)) / np.max(np.abs(ref)) < tol
+    assert rel(l1, l0) < tol and rel(d1, d0) < tol * 100
+    # inv(L_cc) of the second diagonal block (ragged last block: identity-padded)
+    if n > 128:
+        hi = min(256, n)
+        w = d1.reshape(-1, 128, 128)[1].double().cpu().numpy()[: hi - 128, : hi - 128]
+        assert np.max(np.abs(w @ ref[128:hi, 128:hi] - np.eye(hi - 128))) < tol * 1e3
+    # not positive definite from pivot 200 on (orders above 200): both paths name the same pivot
+    if n > 200:
+        bad = a.clone()
+        bad[200, 200] = -1.0
+        _, _, j1 = factor(bad, True)
+        _, _, j0 = factor(bad, False)
+        assert j1 == j0 == 201
