@@ -143,6 +143,20 @@ __global__ __launch_bounds__(256, 2) void gemm_trib_kernel(GemmArgs<T> p) {
     gemm_tile<T, TS, true, true, EDGE, NCT, 4, true>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
 
+// A (M x K) LOWER TRIANGULAR, few tiles (the leaves `inv(L_qq) B_q` of the recursive solve: 1024 x 1024 against 2048 columns):
+// a row tile at row m0 runs m0 + TS of k, so with one tile per workgroup the long tiles finish alone -- one wave per SIMD, which
+// issues an MFMA every ~140 cycles (profiles/r03_experiments.md, sections 1 and 11: 62 us = 35 TFLOP/s for 2.1 GFLOP).  Here a
+// workgroup takes the PAIR of 32-row tiles i and tiles_m - 1 - i of one 64-column tile: every task has the same K (M + 32), there
+// are 4x as many workgroups as 64 x 64 tiles gave (two per CU at the leaf's size: two waves per SIMD from start to end).
+template <typename T, bool B_KMAJ, bool EDGE>
+__global__ __launch_bounds__(256, 4) void gemm_trilo_pair_kernel(GemmArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * (1 + 2) * op_bytes(32)];
+    const int half = p.tiles_m >> 1;                      // tiles_m is even (launcher)
+    const int tj = (int)blockIdx.x / half, pi = (int)blockIdx.x - tj * half;
+    gemm_tile<T, 32, true, B_KMAJ, EDGE, 2>(p, p.tiles_m - 1 - pi, tj, blockIdx.y, blockIdx.z, smem);
+    gemm_tile<T, 32, true, B_KMAJ, EDGE, 2>(p, pi, tj, blockIdx.y, blockIdx.z, smem);
+}
+
 // ---- persistent variant: a resident set of workgroups pulls tiles of up to two problems ("segments")
 // from one device-side counter.  It exists for the look-ahead Cholesky (gpk_potrf.hip):
 //  * the trailing update of one outer step is two problems -- the next panel's strip (written OUT OF
@@ -312,6 +326,7 @@ Prof g_prof;
 int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
 int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
 int g_trib = 1;                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
+int g_trilo_pairs = 1;            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
 int g_split_tail = 1;               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
@@ -350,6 +365,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 13) g_colmajor_ratio = (int)value;
     if (key == 31) g_split_tail = (int)value;
     if (key == 36) g_trib = (int)value;
+    if (key == 42) g_trilo_pairs = (int)value;
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -481,6 +497,27 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         // (a triangular operand halves the multiply-adds actually needed: the TRSM / TRMM count)
         const double fl = (lower_only ? 1.0 : 2.0) * ((flags & (2 | 4 | 8)) ? 0.5 : 1.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
         slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), fl, stream);
+    }
+    // triangular A, a grid too small to keep two waves per SIMD busy to the end: pairs of 32-row tiles (gemm_trilo_pair_kernel)
+    if (g_trilo_pairs && flags == 4 && a_kmaj && ts == 64 && nct == 1 && batch == 1 && batch2 == 1 && M % 64 == 0 && M >= 256 &&
+        (const void*)A != (const void*)C && (const void*)B != (const void*)C && gpk_cdiv(M, 64) * gpk_cdiv(N, 64) <= 2 * (int64_t)device_cus()) {
+        g.tiles_m = (int)(M / 32);
+        g.tiles_n = (int)gpk_cdiv(N, 64);
+        g.colmajor = 0; g.swizzle = 0; g.tri_pairs = 0;
+        const bool e2 = !aligned || (N % 64) || (K % BK);
+        const dim3 pgrid((unsigned)((g.tiles_m / 2) * g.tiles_n), 1, 1);
+        ProfSlot* ps = nullptr;
+        if (g_prof.on) ps = g_prof.begin(96 + (sizeof(T) == 8 ? 8 : 0) + (e2 ? 1 : 0), (double)M * (double)N * (double)K, stream);
+        if (b_kmaj) {
+            if (e2) hipLaunchKernelGGL((gemm_trilo_pair_kernel<T, true, true>), pgrid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_trilo_pair_kernel<T, true, false>), pgrid, dim3(256), 0, stream, g);
+        } else {
+            if (e2) hipLaunchKernelGGL((gemm_trilo_pair_kernel<T, false, true>), pgrid, dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((gemm_trilo_pair_kernel<T, false, false>), pgrid, dim3(256), 0, stream, g);
+        }
+        if (ps) g_prof.end(ps, stream);
+        GPK_CHECK_LAUNCH();
+        return GPK_OK;
     }
     const bool trib = (flags & 16) && g_trib && a_kmaj && b_kmaj && g.tiles_n == 1 && N <= 128 && g.split_from == INT32_MAX;
     if (trib && nct == 2) {
