@@ -117,6 +117,13 @@ int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t bat
 int64_t gpk_potrf_la_ws_elems(int64_t n, int nb);
 int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_nb, int nb, void* ws, int* info,
                  void* stream);
+/* The same with explicit inverses NARROWER than the outer blocks: `sb` (256 ... nb, a power of two) wide.  The rows below an nb-block
+ * are then solved by block substitution over its nb / sb column blocks (same flops, 2 nb / sb - 1 GEMMs instead of one) and `dinv_sb` =
+ * [ceil(n/sb)][sb][sb] is what gpk_trtri_merge(sb) would produce.  For fp32: the error of everything solved against an explicit inverse
+ * grows with its width (posterior mean of configs[2] at N = 32768 against fp64: 1.0e-3 with 1024-wide inverses, 7e-4 with 512), while
+ * the factorisation is fastest with 1024-column outer blocks. */
+int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
+                       void* stream);
 
 /* Merge the 128-block inverses into inverses of sb x sb diagonal blocks
  * (sb = 128 * 2^k <= 4096); dinv_sb: [batch][ceil(n/sb)][sb][sb];

@@ -25,13 +25,18 @@ B.epsilon = 1e-12
 lp64, m64, v64 = run(torch.float64)
 rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
 B.epsilon = 1e-6
-for la_from, nb, sbmax in [(7168, 1024, 512), (7168, 512, 512), (7168, 512, 256), (0, 0, 512), (7168, 1024, 128), (7168, 2048, 512)]:
+# (look-ahead from, outer block, width of the explicit inverses, largest solve block)
+CASES = [(7168, 1024, 512, 256), (7168, 1024, 1024, 256), (7168, 512, 512, 256), (7168, 1024, 256, 256), (0, 0, 0, 256)]
+if len(sys.argv) > 1 and sys.argv[1] == "all":
+    CASES += [(7168, 1024, 1024, 512), (7168, 512, 512, 512), (7168, 1024, 512, 128), (7168, 2048, 2048, 512)]
+for la_from, nb, inv, sbmax in CASES:
     matrix.config.potrf_lookahead_from = la_from
     matrix.config.potrf_lookahead_nb[torch.float32] = nb
+    matrix.config.potrf_lookahead_inv[torch.float32] = inv
     orig = matrix._solve_block
     matrix._solve_block = lambda n, nrhs, fp64=True, _o=orig, _m=sbmax: min(_o(n, nrhs, fp64), _m) if not fp64 else _o(n, nrhs, fp64)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lp32, m32, v32 = run(torch.float32)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     matrix._solve_block = orig
-    print(f"FP32ACC look-ahead from {la_from} nb {nb} solve block <= {sbmax}: logpdf {abs(lp32 - lp64) / abs(lp64):.2e}  mean {rel(m32, m64):.3e}  var {rel(v32, v64):.2e}   {dt * 1e3:.0f} ms")
+    print(f"FP32ACC look-ahead from {la_from} outer block {nb} explicit inverses {inv} solve block <= {sbmax}: logpdf {abs(lp32 - lp64) / abs(lp64):.2e}  mean {rel(m32, m64):.3e}  var {rel(v32, v64):.2e}   {dt * 1e3:.0f} ms")

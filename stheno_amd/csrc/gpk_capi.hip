@@ -64,6 +64,11 @@ int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* di
     D1(dtype, gpk_potrf_la_launch<T>((T*)a, n, ld, (T*)dinv, (T*)dinv_nb, nb, (T*)ws, info, (hipStream_t)stream));
 }
 
+int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
+                       void* stream) {
+    D1(dtype, gpk_potrf_la_launch<T>((T*)a, n, ld, (T*)dinv, (T*)dinv_sb, nb, (T*)ws, info, (hipStream_t)stream, sb));
+}
+
 int gpk_gemm_update2(int dtype, const gpk_update_t* upd, int nupd, double alpha, void* ctrl, int reserve_cus,
                      void* stream) {
     D1(dtype, update2<T>(upd, nupd, alpha, ctrl, reserve_cus, (hipStream_t)stream));

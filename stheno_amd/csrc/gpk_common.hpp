@@ -149,7 +149,7 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
 int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb);
 template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
-                        hipStream_t stream);
+                        hipStream_t stream, int sb = 0);     // sb: width of the explicit inverses (0 = nb); dinv_big: [ceil(n/sb)][sb][sb]
 
 void gpk_tune_gemm(int key, int64_t value);
 void gpk_tune_potrf(int key, int64_t value);

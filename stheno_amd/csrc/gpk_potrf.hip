@@ -1497,7 +1497,7 @@ hipEvent_t la_event(LaDevice& d, size_t i) {
 }
 
 template <typename T>
-int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tmp, int* info, int64_t j,
+int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* tmp, int* info, int64_t j,
              hipStream_t s, int max_wgs = 0, unsigned* wait_word = nullptr, unsigned wait_value = 0) {
     const int64_t k0 = j * nb;
     const int64_t w = (n - k0 < nb) ? n - k0 : nb;
@@ -1506,7 +1506,8 @@ int la_chain(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* tm
     PanelCtx<T> sub{Ab, w, ld, 1, 0, d128, 0, info, s, (int)k0, max_wgs, wait_word, wait_value};
     int st = potrf_panel_any<T>(sub, 0, nb);
     if (st) return st;
-    return gpk_trtri_merge_launch<T>(Ab, w, ld, 1, 0, d128, nb, dinv_big + j * (int64_t)nb * nb, tmp, s);
+    // the explicit inverses of the sb x sb diagonal blocks of this nb-block (sb = nb: of the whole block)
+    return gpk_trtri_merge_launch<T>(Ab, w, ld, 1, 0, d128, sb, dinv_big + (k0 / sb) * (int64_t)sb * sb, tmp, s);
 }
 
 }  // namespace
@@ -1551,22 +1552,24 @@ int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb) {
 }
 
 template <typename T>
-static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
+static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* ws, int* info,
                          hipStream_t stream);
 
 template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
-                        hipStream_t stream) {
+                        hipStream_t stream, int sb) {
     if (n <= 0) return GPK_OK;
     if (n > INT32_MAX) return GPK_ERR_ARG(2);
     if (ld < n) return GPK_ERR_ARG(3);
     if (nb < 256 || nb > 4096 || (nb & (nb - 1))) return GPK_ERR_ARG(6);
+    if (sb <= 0) sb = nb;
+    if (sb < 256 || sb > nb || (sb & (sb - 1))) return GPK_ERR_ARG(10);
     if (dinv128 == nullptr || dinv_big == nullptr || ws == nullptr || info == nullptr) return GPK_ERR_ARG(4);
 
     std::lock_guard<std::mutex> lock(g_la_mutex);
     LaDevice* dev = la_device();
     if (dev == nullptr) return GPK_ERR_LAUNCH;
-    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, ws, info, stream);
+    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, stream);
 
     // The legacy default stream (what torch's default stream is) synchronises implicitly with every BLOCKING
     // stream -- and the CU-masked helper stream is one (hipExtStreamCreateWithCUMask takes no flags): each
@@ -1580,14 +1583,14 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     hipEvent_t e_in = la_event(*dev, 0), e_out = la_event(*dev, 1);
     if (e_in == nullptr || e_out == nullptr) return GPK_ERR_LAUNCH;
     if (hipEventRecord(e_in, nullptr) != hipSuccess || hipStreamWaitEvent(dev->priv, e_in, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, ws, info, dev->priv);
+    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, dev->priv);
     // joined whatever `st` is: what was enqueued on the private stream before a failure still uses the caller's buffers
     if (hipEventRecord(e_out, dev->priv) != hipSuccess || hipStreamWaitEvent(nullptr, e_out, 0) != hipSuccess) return st ? st : GPK_ERR_LAUNCH;
     return st;
 }
 
 template <typename T>
-static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
+static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* ws, int* info,
                          hipStream_t stream) {
     unsigned* ctrl = reinterpret_cast<unsigned*>(ws);                   // 64 elements reserved
     // n x nb, leading dimension nb + 16: with a power-of-two pitch the rows of a tile sit on a few memory channels and
@@ -1596,7 +1599,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     T* Tp = ws + 64;
     T* tmp = Tp + (n > nb ? n : nb) * ldt;
     const int64_t nblk = gpk_cdiv(n, nb);
-    const int64_t per = (int64_t)nb * nb;
+    const int64_t per = (int64_t)sb * sb;      // one explicit inverse
     size_t ev = 2;                       // (events 0 and 1 belong to the default-stream stand-in)
 
     // Small matrices, and the tail of big ones, are chain-bound: there the plain right-looking recursion
@@ -1606,12 +1609,12 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
                                0, (int)k, stream);
         if (s) return s;
         return gpk_trtri_merge_launch<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB),
-                                         nb, dinv_big + (k / nb) * per, Tp, stream);   // the panel workspace is free by now
+                                         sb, dinv_big + (k / sb) * per, Tp, stream);   // the panel workspace is free by now
     };
     const int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : 6144;
     if (n <= tail_rows) return finish_plain(0);
 
-    int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, 0, stream);
+    int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, 0, stream);
     if (st) return st;
     if (nblk > 1) {   // the first panel enters the workspace as it is
         st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, n - nb, nb, 1, stream);
@@ -1621,7 +1624,20 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         const int64_t k0 = j * nb, k1 = k0 + nb;
         const int64_t k2 = (k1 + nb < n) ? k1 + nb : n;
         // solve(j): rows k1.. of panel j  (k clipped to W's triangle)
-        if (g_la_ps_mode == 0) {
+        if (sb < nb) {
+            // the explicit inverses are sb wide (fp32: the error of the posterior mean grows with the width of an explicit inverse): block
+            // substitution over the nb / sb column blocks of the panel -- X_i = (T_i - sum_{p<i} X_p L_ip^T) W_ii^T, same flops as the
+            // single product, 2 nb / sb - 1 launches
+            for (int64_t i = 0; i * sb < nb && st == GPK_OK; ++i) {
+                const int64_t c = i * sb;
+                if (i > 0)
+                    st = gpk_gemm_launch<T>(true, true, n - k1, sb, c, T(-1), A + k1 * ld + k0, ld, 0, A + (k0 + c) * ld + k0, ld, 0, T(1),
+                                            Tp + k1 * ldt + c, ldt, 0, 1, 0, stream);
+                if (st == GPK_OK)
+                    st = gpk_gemm_launch<T>(true, true, n - k1, sb, sb, T(1), Tp + k1 * ldt + c, ldt, 0, dinv_big + (k0 / sb + i) * per, sb, 0, T(0),
+                                            A + k1 * ld + k0 + c, ld, 0, 1, 8, stream);
+            }
+        } else if (g_la_ps_mode == 0) {
             st = gpk_gemm_launch<T>(true, true, n - k1, nb, nb, T(1), Tp + k1 * ldt, ldt, 0, dinv_big + j * per, nb, 0, T(0),
                                     A + k1 * ld + k0, ld, 0, 1, 8, stream);
         } else {
@@ -1660,7 +1676,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
             if (hipEventRecord(e_fork, stream) != hipSuccess) return GPK_ERR_LAUNCH;
         } else {
-            st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, stream);
+            st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, stream);
             if (st) return st;
         }
         GpkPersistSaved saved;
@@ -1684,8 +1700,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             }
             if (overlap) {
                 if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-                const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux, 8, ctrl + 2, (unsigned)saved.signal_tiles)
-                                         : la_chain<T>(A, n, ld, dinv128, dinv_big, nb, tmp, info, j + 1, dev->aux, 8);
+                const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8, ctrl + 2, (unsigned)saved.signal_tiles)
+                                         : la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8);
                 if (s2) return s2;
                 if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
                     return gpk_gemm_persist_rejoin<T>(&saved, dev->aux);
@@ -1702,8 +1718,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     return GPK_OK;
 }
 
-template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t);
-template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t);
+template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t, int);
+template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t, int);
 
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,

@@ -501,16 +501,18 @@ static void test_update2_case(int M0, int N0, int M1, int K, int reserve, int pa
 }
 
 template <typename T>
-static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_t tail_rows = 0) {
+static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_t tail_rows = 0, int sb = 0) {
     const int64_t ld = n + (n % 2);
     auto A = make_spd<T>(n, 1, ld);
     const int64_t de = gpk_dinv_elems(n);
-    const int nblk = (n + nb - 1) / nb;
-    Dev<T> dA(A.size()), dRef(A.size()), dinv((size_t)de), dinv2((size_t)de), dbig((size_t)nblk * nb * nb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+    const int wb = sb > 0 ? sb : nb;           // width of the explicit inverses
+    const int nblk = (n + wb - 1) / wb;
+    Dev<T> dA(A.size()), dRef(A.size()), dinv((size_t)de), dinv2((size_t)de), dbig((size_t)nblk * wb * wb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
     Dev<int> info(1), info2(1);
     dA.up(A); dRef.up(A); info.zero(); info2.zero();
     gpk_tune(7, mode); gpk_tune(6, min_rows); gpk_tune(9, tail_rows);
-    const int st = gpk_potrf_la(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
+    const int st = sb > 0 ? gpk_potrf_la_split(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, sb, ws.p, info.p, nullptr)
+                          : gpk_potrf_la(DT<T>::v, dA.p, n, ld, dinv.p, dbig.p, nb, ws.p, info.p, nullptr);
     gpk_tune(7, 1); gpk_tune(6, 2048); gpk_tune(9, 0);
     const int st2 = gpk_potrf(DT<T>::v, dRef.p, n, ld, 0, 1, dinv2.p, info2.p, 0, nullptr);
     HIPCHK(hipDeviceSynchronize());
@@ -524,7 +526,7 @@ static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_
             num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
         }
     char nm[160];
-    snprintf(nm, sizeof nm, "potrf_la_%s n%d nb%d mode%d minrows%lld tail%lld st%d/%d info%d", DT<T>::name(), n, nb, mode, (long long)min_rows, (long long)tail_rows, st, st2, info.down()[0]);
+    snprintf(nm, sizeof nm, "potrf_la_%s n%d nb%d sb%d mode%d minrows%lld tail%lld st%d/%d info%d", DT<T>::name(), n, nb, wb, mode, (long long)min_rows, (long long)tail_rows, st, st2, info.down()[0]);
     report(nm, (st || st2 || !finite || info.down()[0]) ? INFINITY : num / den, DT<T>::eps * 100);
     // upper triangle untouched
     {
@@ -537,12 +539,12 @@ static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_
     {
         auto W = dbig.down();
         double worst = 0;
-        for (int blk : {0, nblk - 1}) {
-            const int o = blk * nb, nv = std::min(nb, n - o);
+        for (int blk : {0, nblk / 2, nblk - 1}) {
+            const int o = blk * wb, nv = std::min(wb, n - o);
             for (int i = 0; i < nv; i += 7)
                 for (int j = 0; j < nv; ++j) {
                     double sacc = 0;
-                    for (int k = j; k <= i; ++k) sacc += (double)W[(size_t)blk * nb * nb + (size_t)i * nb + k] * (double)R[(size_t)(o + k) * ld + o + j];
+                    for (int k = j; k <= i; ++k) sacc += (double)W[(size_t)blk * wb * wb + (size_t)i * wb + k] * (double)R[(size_t)(o + k) * ld + o + j];
                     worst = std::max(worst, std::fabs(sacc - (i == j ? 1.0 : 0.0)));
                 }
         }
@@ -574,6 +576,10 @@ static void test_lookahead() {
     test_potrf_la_case<T>(3000, 1024, 1, 1024);
     test_potrf_la_case<T>(4096, 1024, 1, 0);
     test_potrf_la_case<T>(5000, 512, 1, 2048);
+    test_potrf_la_case<T>(4096, 1024, 1, 0, 0, 512);       // explicit inverses narrower than the outer blocks (gpk_potrf_la_split)
+    test_potrf_la_case<T>(5000, 1024, 1, 1024, 1000, 256);
+    test_potrf_la_case<T>(3000, 512, 1, 0, 700, 256);
+    test_potrf_la_case<T>(2100, 1024, 0, 0, 300, 512);
     gpk_tune(40, 256); gpk_tune(41, 4096);              // the next diagonal block's update inside the trailing update, at these small orders and every block width
     test_potrf_la_case<T>(4096, 1024, 1, 0);
     test_potrf_la_case<T>(5000, 512, 1, 1024);
@@ -984,6 +990,13 @@ static void perf_la_tail(std::initializer_list<int> ns) {
                        (double)n * n * n / 3.0 / ms * 1e-9, info.down()[0]);
             }
             gpk_tune(9, 0);
+        }
+        {   // 1024-column outer blocks with 512-wide explicit inverses (what fp32 runs)
+            const int nb = 1024, sb = 512;
+            Dev<T> dbig((size_t)((n + sb - 1) / sb) * sb * sb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+            const float ms = run([&] { gpk_potrf_la_split(DT<T>::v, K.p, n, n, dinv.p, dbig.p, nb, sb, ws.p, info.p, nullptr); });
+            printf("PERFTAIL potrf_%s n=%d look-ahead nb=%d sb=%d tail=default  %.3f ms  %.2f TFLOP/s info=%d\n", DT<T>::name(), n, nb, sb, ms,
+                   (double)n * n * n / 3.0 / ms * 1e-9, info.down()[0]);
         }
     }
 }

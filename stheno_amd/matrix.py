@@ -36,11 +36,14 @@ class _Config:
     potrf_lookahead_from = 11264
     #: its outer block = the order of the explicitly inverted diagonal blocks: the per-dtype value from `potrf_lookahead_wide_from` on,
     #: 512 below (no such order is left with the defaults: at N = 12288 fp64, 1024-blocks 13.32 ms, 512-blocks 13.47)
-    #: fp32 stays at 512-blocks at every order: the rows below a diagonal block are multiplied by its EXPLICIT inverse, and in fp32 the
-    #: posterior mean pays for the width of that inverse -- cfg3 at its full N = 32768 against fp64 on the device: mean error
-    #: 1.00e-3 with 1024-blocks, 7.3e-4 with 512-blocks (6.2e-4 with 256-block solves on top), 1.6e-3 with 2048; 3 % slower
-    #: (scripts/dev_fp32_fullsize_accuracy.py).  north_star's fp32 bar is 1e-3.
-    potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 512}
+    #: fp32 keeps 512-wide EXPLICIT inverses at every order: the rows below a diagonal block are multiplied by its explicit inverse, and
+    #: in fp32 the posterior mean pays for the width of that inverse -- cfg3 at its full N = 32768 against fp64 on the device: mean error
+    #: 1.00e-3 with 1024-wide inverses, 7.3e-4 with 512 (6.2e-4 with 256-block solves on top), 1.6e-3 with 2048
+    #: (scripts/dev_fp32_fullsize_accuracy.py; north_star's fp32 bar is 1e-3).  The OUTER blocks are 1024 columns for both types
+    #: (N = 32768 fp32: 97.6 ms with 1024-blocks, 102.5 with 512): with `potrf_lookahead_inv` narrower than the block, the rows below it
+    #: are solved by block substitution over its column blocks (``gpk_potrf_la_split``).
+    potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 1024}
+    potrf_lookahead_inv = {torch.float64: 1024, torch.float32: 512}
     potrf_lookahead_wide_from = 11264
 
 
@@ -127,6 +130,7 @@ class Chol:
         self._dinv_sb = {128: dinv}
         self._clean = False
         self.lookahead_nb = 0
+        self.lookahead_sb = 0
         self._residuals = {}
 
     @classmethod
@@ -140,13 +144,14 @@ class Chol:
             if nb > 512 and n < config.potrf_lookahead_wide_from:
                 nb = 512
         if nb:
-            dinv, info, dnb = be.potrf_(a, config.potrf_nbo, lookahead_nb=nb)
+            sb = min(nb, config.potrf_lookahead_inv.get(a.dtype, nb))
+            dinv, info, dnb = be.potrf_(a, config.potrf_nbo, lookahead_nb=nb, lookahead_sb=sb)
             c = cls(a, dinv, info)
             c.lookahead_nb = nb           # (which path ran; the tests ask)
-            if nb == _solve_block(n, 1, a.dtype == torch.float64):
-                c._dinv_sb[nb] = dnb      # the merged inverses the solves want come for free
-            # (otherwise -- fp32, whose solves stay at 512-blocks for accuracy, or a 512-block look-ahead under 1024-block
-            # solves -- nobody would ever read them: n * nb elements, 134 MB at N = 32768 fp32, are released here)
+            c.lookahead_sb = sb
+            if sb == _solve_block(n, 1, a.dtype == torch.float64):
+                c._dinv_sb[sb] = dnb      # the merged inverses the solves want come for free
+            # (otherwise nobody would ever read them: n * sb elements are released here)
         else:
             dinv, info = be.potrf_(a, config.potrf_nbo)
             c = cls(a, dinv, info)

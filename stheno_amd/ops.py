@@ -214,11 +214,11 @@ class HipBackend:
 
     # -- factorisation -------------------------------------------------------
     @_on_operand_device
-    def potrf_(self, a, nbo=0, lookahead_nb=0):
+    def potrf_(self, a, nbo=0, lookahead_nb=0, lookahead_sb=0):
         """In-place lower Cholesky of ``a`` (..., n, n).  Returns ``(dinv, info)``, or
-        ``(dinv, info, dinv_nb)`` when ``lookahead_nb`` (256 ... 4096) selects the look-ahead
-        factorisation of ONE large matrix: ``dinv_nb`` are the inverses of the ``nb x nb`` diagonal
-        blocks of the factor (what ``trtri_merge(l, dinv, nb)`` would compute)."""
+        ``(dinv, info, dinv_sb)`` when ``lookahead_nb`` (256 ... 4096) selects the look-ahead
+        factorisation of ONE large matrix: ``dinv_sb`` are the inverses of the ``sb x sb`` diagonal
+        blocks of the factor (what ``trtri_merge(l, dinv, sb)`` would compute), ``sb = lookahead_sb`` or ``lookahead_nb``."""
         a3, _ = _as3(a)
         if a3.data_ptr() != a.data_ptr():
             raise ValueError("potrf_ needs a tensor with unit inner stride (it factorises in place)")
@@ -231,10 +231,15 @@ class HipBackend:
             if B != 1:
                 raise ValueError("the look-ahead factorisation takes one matrix")
             nb = int(lookahead_nb)
-            dnb = torch.empty((1, (n + nb - 1) // nb, nb, nb), dtype=a.dtype, device=a.device)
+            sb = int(lookahead_sb) or nb
+            dnb = torch.empty((1, (n + sb - 1) // sb, sb, sb), dtype=a.dtype, device=a.device)
             ws = torch.empty((int(self.lib.gpk_potrf_la_ws_elems(n, nb)),), dtype=a.dtype, device=a.device)
-            code = self.lib.gpk_potrf_la(_dtype_id(a3), self._ptr(a3), n, _ld(a3), self._ptr(dinv), self._ptr(dnb), nb,
-                                         self._ptr(ws), self._ptr(info), self._stream())
+            if sb == nb:
+                code = self.lib.gpk_potrf_la(_dtype_id(a3), self._ptr(a3), n, _ld(a3), self._ptr(dinv), self._ptr(dnb), nb,
+                                             self._ptr(ws), self._ptr(info), self._stream())
+            else:
+                code = self.lib.gpk_potrf_la_split(_dtype_id(a3), self._ptr(a3), n, _ld(a3), self._ptr(dinv), self._ptr(dnb), nb, sb,
+                                                   self._ptr(ws), self._ptr(info), self._stream())
             self._st(code, "gpk_potrf_la")
             # `ws` is freed here while the factorisation may still be running: torch's caching allocator only reuses the
             # block for work enqueued later on this same stream, and the helper stream has joined it by then

@@ -337,14 +337,15 @@ def test_lookahead_factorisation_through_the_api(dtype, n):
     finally:
         matrix.config.potrf_lookahead_from = first
     nb = 512 if n < matrix.config.potrf_lookahead_wide_from else matrix.config.potrf_lookahead_nb[dtype]
-    assert c.lookahead_nb == nb                                       # the look-ahead path ran
+    sb = min(nb, matrix.config.potrf_lookahead_inv[dtype])
+    assert c.lookahead_nb == nb and c.lookahead_sb == sb              # the look-ahead path ran
     # the block inverses it leaves behind are what the merge of the 128-block inverses computes (they are kept with the factor
     # only when the solves use that block size: matrix.Chol.factor_)
     be = ops.get_backend()
     a2 = dev(k, dtype).clone()
-    dinv2, info2, dnb = be.potrf_(a2, 0, lookahead_nb=nb)
-    assert int(info2.max()) == 0 and dnb.shape[-3] == (n + nb - 1) // nb
-    merged = be.trtri_merge(a2, dinv2, nb)
+    dinv2, info2, dnb = be.potrf_(a2, 0, lookahead_nb=nb, lookahead_sb=sb)
+    assert int(info2.max()) == 0 and dnb.shape[-3] == (n + sb - 1) // sb
+    merged = be.trtri_merge(a2, dinv2, sb)
     assert rel(dnb, merged.double().cpu().numpy()) < (1e-11 if dtype == torch.float64 else 1e-4)
     del a2, dinv2, dnb, merged
     l_ref = np.linalg.cholesky(k)

@@ -118,11 +118,12 @@ def test_config3_full_size_residuals_and_fp64_on_device():
 
 @pytest.mark.parametrize("dtype,n", [(torch.float64, 14336), (torch.float32, 14464)])
 def test_lookahead_wide_blocks_against_lapack(dtype, n):
-    """``Chol.factor_`` at an order that takes the look-ahead path with the block width the headline configurations run -- 1024 in
-    fp64 (cfg2), 512 in fp32 (cfg3: accuracy, ``matrix.config.potrf_lookahead_nb``) -- against ``np.linalg.cholesky`` (LAPACK, host)."""
+    """``Chol.factor_`` at an order that takes the look-ahead path with the widths the headline configurations run -- 1024-column
+    outer blocks; explicit inverses 1024 wide in fp64 (cfg2), 512 in fp32 (cfg3: accuracy, ``matrix.config.potrf_lookahead_inv``) --
+    against ``np.linalg.cholesky`` (LAPACK, host)."""
     assert n >= matrix.config.potrf_lookahead_wide_from
-    nb = matrix.config.potrf_lookahead_nb[dtype]
-    assert nb == (1024 if dtype == torch.float64 else 512)
+    nb, sb = matrix.config.potrf_lookahead_nb[dtype], matrix.config.potrf_lookahead_inv[dtype]
+    assert nb == 1024 and sb == (1024 if dtype == torch.float64 else 512)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(n, 8, generator=g, dtype=torch.float64).to(dtype).to(DEV)
     k = st.EQ()
@@ -130,17 +131,18 @@ def test_lookahead_wide_blocks_against_lapack(dtype, n):
     a.diagonal().add_(NOISE)
     ref = np.linalg.cholesky(a.double().cpu().numpy())
     chol = matrix.Chol.factor_(a.clone())
-    assert chol.lookahead_nb == nb              # the look-ahead path ran, with that block width
+    assert chol.lookahead_nb == nb and chol.lookahead_sb == sb        # the look-ahead path ran, with those widths
     L = chol.lower().double().cpu().numpy()
     err = np.max(np.abs(L - ref)) / np.max(np.abs(ref))
     assert err < (1e-11 if dtype == torch.float64 else 2e-4), err
     # the block inverses the look-ahead leaves behind are the inverses of L's diagonal blocks
     be = ops.get_backend()
-    _, info, dnb = be.potrf_(a.clone(), 0, lookahead_nb=nb)
+    _, info, dnb = be.potrf_(a.clone(), 0, lookahead_nb=nb, lookahead_sb=sb)
     assert int(info.max()) == 0
-    w1 = dnb[0, 1].double().cpu().numpy()
-    blk = ref[nb:2 * nb, nb:2 * nb]
-    assert np.max(np.abs(w1 @ blk - np.eye(nb))) < (1e-9 if dtype == torch.float64 else 5e-3)
+    for q in (1, 3):
+        w = dnb[0, q].double().cpu().numpy()
+        blk = ref[q * sb:(q + 1) * sb, q * sb:(q + 1) * sb]
+        assert np.max(np.abs(w @ blk - np.eye(sb))) < (1e-9 if dtype == torch.float64 else 5e-3)
 
 
 def test_native_selftest_binary_reports_no_failure():
