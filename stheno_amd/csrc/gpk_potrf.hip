@@ -5,17 +5,16 @@
 // LAPACK dpotrf/spotrf under `B.logdet` / `B.iqf_diag` (stheno/random.py:274-276)
 // and under `B.cholesky(K_z)` (stheno/model/observations.py:300).
 //
-// Structure per outer block of `nbo` columns (nbo = 1024 from n = 8192, 512 from 2048, else 256):
-//   for each 128-column inner block c:
-//     1. potrf_diag_kernel: ONE workgroup factorises the 128x128 diagonal block
-//        entirely in LDS (16-wide micro-panels: shuffle-based 16x16 Cholesky on
-//        one wave, thread-per-row micro-TRSM, MFMA rank-16 update), writes L_cc,
-//        then inverts L_cc in place in LDS (16x16 substitutions + recursive
-//        doubling with MFMA) and writes inv(L_cc) to the `dinv` workspace.
-//     2. panel TRSM as an MFMA GEMM:  A[c+128:, c:c+128] <- A[...] * inv(L_cc)^T
-//     3. strip update (rank 128) of the remaining columns of the outer block.
-//   4. trailing SYRK update (rank nbo, lower tiles only):
-//        A[k1:, k1:] -= A[k1:, k0:k1] A[k1:, k0:k1]^T        <- the MFMA-bound part
+// Structure (gpk_potrf; the look-ahead variant for one large matrix is described further down):
+//   ONE matrix -- per outer panel of `nbo` columns (the whole matrix up to n = 4096, 1024 above) ONE launch, potrf_pipe_kernel:
+//     a chain workgroup factorises AND inverts the 128x128 diagonal blocks one after the other entirely in LDS (diag3_block:
+//     16-wide micro-panels factorised as panels by shuffle-based waves, MFMA rank-16 updates, the inverse grown row block by row
+//     block in the shadow of the factorisation); every other workgroup takes the solves below the blocks (GEMMs against the
+//     inverted block) and the rank-128 updates inside the panel as tasks from a counter, synchronised through flag words
+//     (gpk_potrf_pipe.hpp).  Between panels: the trailing SYRK update (rank nbo, lower tiles only) -- its strip over the next
+//     panel's columns as a GEMM launch, the rest as fill tiles inside the next panel's launch.
+//   BATCHES (throughput-bound) -- per 128-column block: potrf_diag3_kernel (one workgroup per matrix), the panel TRSM as an MFMA
+//     GEMM  A[c+128:, c:c+128] <- A[...] * inv(L_cc)^T, strip updates by recursive halving, trailing SYRK with K = nbo.
 //
 // inv(L_cc) blocks are kept: gpk_solve.hip turns every triangular solve of the
 // path into GEMM/GEMV work with them.
