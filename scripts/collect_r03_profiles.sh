@@ -16,6 +16,7 @@ timeout 200 ./gpk_selftest --perf-pipe > $O/r03_native_perf_pipelined_panel.log 
 timeout 300 ./gpk_selftest --perf-la-tail > $O/r03_native_perf_plain_vs_lookahead.log 2>&1
 ( cd $R/scripts/dev && timeout 60 ./store_cost ) > $O/r03_store_cost.log 2>&1
 timeout 200 ./gpk_selftest --diagprof 2048 > $O/r03_diag_kernel_phases.log 2>&1
+( cd $R/scripts/dev && for b in mfma_latency store_cost; do [ -x $b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $b $b.hip; done ) > /dev/null 2>&1   # (git-ignored binaries)
 ( cd $R/scripts/dev && timeout 60 ./mfma_latency ) > $O/r03_mfma_latency.log 2>&1
 cd /tmp
 for w in dense_f64 sum_f32 batched_f32 sparse_f32; do

@@ -74,7 +74,8 @@ class deferred_checks:
     when the block ends.  Reading ``info`` is a host read behind the factorisation: done right away, the device runs dry while the
     host comes back and enqueues what follows (0.3-0.6 ms of idle device per cfg2 eval, from the kernel trace); done at the end of the
     block, the work that depends on the factor (log-determinant, solves) is already queued behind it.  A failed factorisation still
-    raises before anything computed from it is handed out.  Nested blocks check at the end of the outermost one."""
+    raises before anything computed from it is handed out.  Nested blocks check at the end of the outermost one.  (Module state,
+    like ``B.epsilon``: one block at a time per process, not per thread.)"""
 
     def __enter__(self):
         global _deferred
