@@ -7,14 +7,23 @@ One STEP = one eval of ``configs[1]``:  from ``x`` (N x D, resident in HBM) buil
 ``K + sigma^2 I`` (lower triangle, jitter fused), Cholesky-factorise it in place,
 ``f(x, noise).logpdf(y)``, condition ``f | (f(x, noise), y)`` (re-using the factor), and
 the posterior mean + marginal variance at N* = 2048 test points -- through the public
-``stheno_amd`` API, i.e. through libgpk.so.  Nothing is cached across steps.
+``stheno_amd`` API, i.e. through libgpk.so.  Nothing is carried from one step to the next: the
+kernel matrix, the factor and the solves are rebuilt, and the one thing the library remembers about
+a data tensor between calls -- the NaN scan of ``y`` (``matrix.any_missing``) -- is forgotten at the
+start of every step, so each step pays for its scan like a first call.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dense_f64|sum_f32|batched_f32|sparse_f32]
 
-For N > 1 it is launched by ``python -m torch.distributed.run --nproc-per-node N ...``:
-the dense workload does not shard (one coupled factorisation), so every rank runs an
-independent replica ("replicas only"); ``batched_f32`` shards its 512 GPs over the ranks
-and all-gathers the log-densities (stheno_amd/dist.py).
+``--gpus N`` with N > 1: one process per GPU.  Either the driver launches this file under
+``python -m torch.distributed.run --nproc-per-node N ...`` (RANK / WORLD_SIZE in the environment), or --
+when they are absent -- ``bench.py --gpus N`` re-launches ITSELF that way (127.0.0.1 rendezvous, a free
+port) and passes the one JSON line through.  The dense workload does not shard (one coupled
+factorisation), so every rank runs an independent replica ("replicas only"); the batched configuration
+(BASELINE.json configs[3]: 512 independent GPs, the one north_star scales over GPUs) shards its GPs over
+the ranks and all-gathers the log-densities (stheno_amd/dist.py): it is the headline of
+``--workload batched_f32`` and rides along as the ``batched`` sub-record of every other workload's line.
+``--dry-run-dist`` proves the launch / rendezvous / collective / reporting path on a GPU-less box (gloo,
+a stand-in step that does no GP arithmetic; the line says ``"dry_run": true``).
 
 Rank 0 prints ONE JSON line.  ``roofline`` is the dominant kernel -- the MFMA GEMM variant with the
 largest summed duration in a step; for the dense workloads that is the persistent two-segment
@@ -40,6 +49,7 @@ if ROOT not in sys.path:
 
 import stheno_amd as st  # noqa: E402
 from stheno_amd import _native  # noqa: E402
+from stheno_amd.matrix import forget_scan  # noqa: E402
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md / SURVEY 8(d)
 NOISE = 0.1
@@ -97,6 +107,7 @@ def make_step(name, w, t):
 
     if name in ("dense_f64", "sum_f32"):
         def step():
+            forget_scan(t["y"])          # (every step scans y for NaN, as a first call does)
             f = st.GP(kernel)
             fdd = f(t["x"], NOISE)
             lp = fdd.logpdf(t["y"])
@@ -107,10 +118,12 @@ def make_step(name, w, t):
         from stheno_amd.dist import sharded_logpdf
 
         def step():
+            forget_scan(t["y"])
             f = st.GP(kernel)
             return sharded_logpdf(f, t["x"], NOISE, t["y"], w["b"])
     else:
         def step():
+            forget_scan(t["y"])
             prior = st.Measure()
             f = st.GP(kernel, measure=prior)
             return st.PseudoObs(f(t["z"]), f(t["x"], NOISE), t["y"]).elbo(prior)
@@ -124,7 +137,7 @@ def pmc_traffic(name, w, kernel):
     figure is read from ``profiles/``; ``None`` if no pass exists for this workload / kernel."""
     if w["n"] != WORKLOADS[name]["n"]:
         return None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
         if os.path.exists(path):
             with open(path) as f:
@@ -134,11 +147,20 @@ def pmc_traffic(name, w, kernel):
     return None
 
 
+PROF_CODES = 256        # gpk_prof variant codes (include/gpk.h, gpk_prof_stop)
+
+
 def _variant_name(code, dtype):
     """Kernel behind a gpk_prof variant code (see gpk_prof_stop in include/gpk.h)."""
     t = "double" if dtype == "f64" else "float"
     ts = 64 if code & 16 else 128
     edge = "true" if code & 1 else "false"
+    if code >= 128:                  # the panel solve against a triangular inverse: its own kernel (and its own code since round 4)
+        return f"gemm_trib_kernel<{t}, {ts}, {edge}, {2 if ts == 64 else 1}>"
+    if code >= 96:
+        return f"gemm_trilo_pair_kernel<{t}, {'true' if code & 2 else 'false'}, {edge}>"
+    if code >= 64:
+        return f"panel_step_kernel<{t}, ..., {edge}>"
     if code & 32:
         return f"gemm_persist_kernel<{t}, {ts}, {edge}>"
     return f"gemm_kernel<{t}, {ts}, {'true' if code & 4 else 'false'}, {'true' if code & 2 else 'false'}, {edge}, 1>"
@@ -226,6 +248,114 @@ def cpu_baseline(name):
                       f"M^3 factorisations ({t_m3:.2f} s) kept, the O(N M^2) rest scaled by N/{n_s} = x{w['n'] // n_s}"}
 
 
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _relaunch_under_torchrun(n, argv):
+    """``bench.py --gpus N`` outside a launcher: start N ranks of this file (one per GPU) under ``torch.distributed.run`` and hand
+    their output through -- rank 0 prints the one JSON line."""
+    import subprocess
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GPK_BENCH_RELAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+class _StandInProcess:
+    """``--dry-run-dist``: stands where a ``GP`` stands in ``dist.sharded_logpdf`` -- ``process(x, noise).logpdf(y)`` -- and does no
+    GP arithmetic (there is no CPU path in the package to do it with): the launch, the sharding, the collective and the reporting
+    are what the dry run is about."""
+
+    def __call__(self, x, noise):
+        self._x, self._noise = x, noise
+        return self
+
+    def logpdf(self, y):
+        return -(y[..., 0] ** 2).sum(-1) / (1.0 + self._noise) - self._x.pow(2).sum((-1, -2))
+
+
+def _timed(step, steps, warmup, barrier, use_dist, device):
+    """W untimed + K timed steps between barriers; the MAX over ranks of the elapsed time."""
+    keep = None
+    for _ in range(warmup):
+        keep = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        keep = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+    del keep
+    return elapsed
+
+
+def _allgather_us(total, world, device, barrier, reps=50):
+    """Average time of the data path's ONE exchange step by itself: the all-gather of ``total / world`` fp32 log-densities per rank."""
+    import torch.distributed as dist
+
+    local = torch.zeros(total // world, dtype=torch.float32, device=device)
+    out = torch.empty(total // world * world, dtype=torch.float32, device=device)
+    for _ in range(5):
+        dist.all_gather_into_tensor(out, local)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(out, local)
+    barrier()
+    return 1e6 * (time.perf_counter() - t0) / reps
+
+
+def _batched_record(device, rank, world, steps, warmup, barrier, use_dist, dry_run=False):
+    """configs[3] (512 independent GPs x N = 2048, D = 3, EQ, fp32) sharded over the ranks: whole-job GPs/s, the step time, the
+    fraction of the fp32 MFMA peak PER GPU the factorisations reach, the all-gather alone."""
+    name = "batched_f32"
+    if dry_run:
+        from stheno_amd.dist import shard_bounds, sharded_logpdf
+
+        w = dict(WORKLOADS[name], n=8, b=16)
+        lo, hi = shard_bounds(w["b"], world, rank)
+        g = torch.Generator(device="cpu").manual_seed(0)
+        x = torch.randn(w["b"], w["n"], w["d"], generator=g)[lo:hi].to(device)
+        y = torch.randn(w["b"], w["n"], 1, generator=g)[lo:hi].to(device)
+        proc = _StandInProcess()
+
+        def step():
+            return sharded_logpdf(proc, x, NOISE, y, w["b"])
+    else:
+        w, t = make_inputs(name, device, rank, world)
+        eps0 = st.B.epsilon
+        st.B.epsilon = 1e-6
+        step = make_step(name, w, t)
+    try:
+        elapsed = _timed(step, steps, warmup, barrier, use_dist, device)
+        full = step()
+    finally:
+        if not dry_run:
+            st.B.epsilon = eps0
+    assert full.shape == (w["b"],) and bool(torch.isfinite(full).all())
+    rec = {"metric": "batched GP logpdfs/sec (512 x N=2048 D=3 fp32)" if not dry_run else "dry run of the batched path (16 stand-in GPs)",
+           "value": w["b"] * steps / elapsed, "unit": "GPs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong", "dtype": "f32",
+           "parallelism": "GPs sharded over %d ranks (contiguous blocks), all-gather of the log-densities" % world,
+           "allgather_us": (_allgather_us(w["b"], world, device, barrier) if use_dist and w["b"] % world == 0 else None)}
+    if not dry_run:
+        fl = step_flops(name, w) / world * steps / elapsed / 1e12
+        rec["per_gpu_step"] = {"unit": "TFLOP/s", "achieved": fl, "peak": PEAK_TFLOPS["f32"], "frac": fl / PEAK_TFLOPS["f32"]}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,46 +364,67 @@ def main():
     ap.add_argument("--workload", default="dense_f64", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override N (development only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched-record", action="store_true", help="skip the `batched` sub-record (configs[3] sharded over the ranks)")
+    ap.add_argument("--dry-run-dist", action="store_true",
+                    help="GPU-less proof of the N-rank path: gloo, a stand-in step, the same launch / barrier / all-gather / JSON code")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        raise SystemExit(_relaunch_under_torchrun(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU path in stheno_amd)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if launched and args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    dry = args.dry_run_dist
+    if dry:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (there is no CPU path in stheno_amd)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)          # one process per GPU
+        device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("GPK_BENCH_FORCE_DIST") == "1"   # (the env switch exercises the RCCL path on one GPU)
     if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+
+    if dry:
+        rec = _batched_record(device, rank, world, args.steps, args.warmup, barrier, use_dist, dry_run=True)
+        if rank == 0:
+            out = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": world, "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                   "vs_baseline": None, "dtype": "f32", "data": "dry run: no GP arithmetic, no GPU", "dry_run": True,
+                   "config": {"workload": "stand-in step through stheno_amd.dist.sharded_logpdf", "parallelism": rec["parallelism"]},
+                   "batched": rec, "world_size": (dist.get_world_size() if use_dist else 0), "backend": "gloo" if use_dist else None}
+            line = json.dumps(out)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(line, flush=True)
+        return
 
     name = args.workload
     w, tensors = make_inputs(name, device, rank, world, args.n or None)
     if w["dtype"] == "f32":
         st.B.epsilon = 1e-6          # the reference's own fp32 setting (README.md:887-888)
     step = make_step(name, w, tensors)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    keep = None
-    for _ in range(args.warmup):
-        keep = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        keep = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
+    elapsed = _timed(step, args.steps, args.warmup, barrier, use_dist, device)
 
     # -- live roofline of the dominant kernel: extra untimed steps under HIP-event hooks --
     roofline = None
@@ -285,9 +436,10 @@ def main():
     for _ in range(prof_steps):
         keep = step()
     torch.cuda.synchronize()
+    del keep
     ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
     best = None
-    for code in range(64):            # every GEMM kernel variant: the dominant one is the one with the most time
+    for code in range(PROF_CODES):    # every GEMM kernel variant: the dominant one is the one with the most time
         lib.gpk_prof_stop(code, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
         if nl.value > 0 and (best is None or ms.value > best[1]):
             best = (code, ms.value, nl.value, fl.value)
@@ -310,6 +462,16 @@ def main():
     per_gpu = 1.0 if name != "batched_f32" else 1.0 / world
     whole["achieved"] = whole["algorithmic_flops_per_step"] * per_gpu * args.steps / elapsed / 1e12
     whole["frac"] = whole["achieved"] / peak
+    allgather = None
+    if name == "batched_f32" and use_dist and w["b"] % world == 0:
+        allgather = _allgather_us(w["b"], world, device, barrier)
+
+    # -- north_star: "at 1 GPU and at 2/4/8 GPUs for the batched config": configs[3] sharded over these same ranks --
+    batched = None
+    if name != "batched_f32" and not args.no_batched_record and not args.n:
+        del step, tensors
+        torch.cuda.empty_cache()
+        batched = _batched_record(device, rank, world, max(2, min(args.steps, 10)), 1, barrier, use_dist)
 
     if rank == 0:
         units = args.steps * (world if name != "batched_f32" else 1)
@@ -326,13 +488,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
             "config": {"workload": w["desc"], "noise_variance": NOISE, "epsilon": st.B.epsilon,
-                       "parallelism": ("replicas only (%d independent evals in flight)" % world) if name != "batched_f32"
+                       "nan_scan": "every step (the library's per-tensor memo is cleared at the start of each step)",
+                       "parallelism": ("replicas only (%d independent evals in flight, one process per GPU)" % world) if name != "batched_f32"
                        else "GPs sharded over %d ranks, all-gather of log-densities" % world},
             "roofline": roofline,
             "whole_step": whole,
             "rccl_world_size": (dist.get_world_size() if use_dist else 0),
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.n) else cpu_baseline(name),
         }
+        if allgather is not None:
+            out["allgather_us"] = allgather
+        if batched is not None:
+            out["batched"] = batched
         line = json.dumps(out)
     if use_dist:
         dist.barrier()

@@ -6,12 +6,13 @@ kernel matrix that can be factorised without ever being materialised next to its
 All heavy lifting goes through :mod:`stheno_amd.ops` (HIP kernels).
 """
 import math
+import threading
 
 import torch
 
 from . import ops
 
-__all__ = ["AbstractMatrix", "Dense", "Diagonal", "Zero", "KernelDense", "FactoredDense", "Chol", "ChainChol", "config"]
+__all__ = ["AbstractMatrix", "Dense", "Diagonal", "Zero", "KernelDense", "FactoredDense", "Chol", "ChainChol", "config", "any_missing", "forget_scan", "deferred_checks"]
 
 
 class _Config:
@@ -49,24 +50,47 @@ class _Config:
 
 config = _Config()
 
-_missing_seen = []      # [(key, tensor, answer)]: the last observation vector scanned for NaN
+def _version_of(t):
+    """The autograd version counter of ``t``, or ``None`` when nothing can vouch for its contents between two calls: inference
+    tensors have no counter, and host memory can be aliased by NumPy / DLPack and written behind torch's back."""
+    if not t.is_cuda or t.is_inference():
+        return None
+    return t._version
 
 
 def any_missing(y):
-    """Whether column 0 of the (N, 1) tensor ``y`` holds a NaN (a missing observation) -- a device reduction plus ONE host read,
-    remembered for the tensor it was asked about: the log-density and the conditioning on the same observations both ask
-    (``random.py:262-264``, ``observations.py:73-74``), and so does every further evaluation on the same data (hyper-parameter
-    loops).  The key is the storage, shape and VERSION of the tensor (an in-place write invalidates it); the entry keeps the tensor
-    alive, so its address cannot be recycled under the key."""
-    key = (y.data_ptr(), y._version, tuple(y.shape), tuple(y.stride()), y.dtype, y.device)
-    if _missing_seen and _missing_seen[0][0] == key:
-        return _missing_seen[0][2]
+    """Whether column 0 of the (N, 1) tensor ``y`` holds a NaN (a missing observation) -- a device reduction plus ONE host read
+    (``random.py:262-264``, ``observations.py:73-74``).  The log-density and the conditioning on the same observations both ask, so
+    the answer is remembered ON THE TENSOR OBJECT (an attribute: no global table, nothing outlives ``y``) together with the version
+    counter it was computed at; any tracked in-place write invalidates it.  Not remembered at all for host tensors and inference
+    tensors (``_version_of``).  Writes that bypass the counter on a device tensor (``y.data[...] = ...``, raw-pointer kernels) are
+    the caller's to announce with :func:`forget_scan`; ``config.check_nan = False`` skips the scan altogether."""
+    ver = _version_of(y)
+    if ver is not None:
+        seen = getattr(y, "_gpk_nan_scan", None)
+        if seen is not None and seen[0] == ver:
+            return seen[1]
     ans = bool(torch.isnan(y[:, 0]).any())
-    _missing_seen[:] = [(key, y, ans)]
+    if ver is not None:
+        try:
+            y._gpk_nan_scan = (ver, ans)
+        except (AttributeError, RuntimeError):      # (a tensor subclass without a __dict__)
+            pass
     return ans
 
 
-_deferred = None       # factors waiting for their check inside a `deferred_checks()` block
+def forget_scan(y):
+    """Drop what :func:`any_missing` remembers about ``y`` (after a write torch did not see; ``bench.py`` calls it every step so that
+    each step pays for its scan as a first call does)."""
+    if getattr(y, "_gpk_nan_scan", None) is not None:
+        y._gpk_nan_scan = None
+
+
+class _DeferredState(threading.local):
+    pending = None      # factors waiting for their check inside a `deferred_checks()` block of THIS thread
+
+
+_deferred_state = _DeferredState()
 
 
 class deferred_checks:
@@ -74,22 +98,27 @@ class deferred_checks:
     when the block ends.  Reading ``info`` is a host read behind the factorisation: done right away, the device runs dry while the
     host comes back and enqueues what follows (0.3-0.6 ms of idle device per cfg2 eval, from the kernel trace); done at the end of the
     block, the work that depends on the factor (log-determinant, solves) is already queued behind it.  A failed factorisation still
-    raises before anything computed from it is handed out.  Nested blocks check at the end of the outermost one.  (Module state,
-    like ``B.epsilon``: one block at a time per process, not per thread.)"""
+    raises before anything computed from it is handed out, and the failed factor stays failed: whoever holds it in a cache
+    (``Dense.chol()``) raises again on the next use instead of handing it out (``Chol.vetted``).  Nested blocks check at the end of
+    the outermost one; a block left through an exception checks nothing, its factors are checked by their next user.  Per thread."""
 
     def __enter__(self):
-        global _deferred
-        self._outer = _deferred
-        if _deferred is None:
-            _deferred = []
+        self._outer = _deferred_state.pending
+        if self._outer is None:
+            _deferred_state.pending = []
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        global _deferred
-        pending, _deferred = _deferred, self._outer
+        pending, _deferred_state.pending = _deferred_state.pending, self._outer
         if self._outer is None and exc_type is None:
-            for c in pending:
-                c.check()
+            first = None
+            for c in pending:                 # every one of them is looked at, the first failure is the one reported
+                try:
+                    c.check()
+                except (RuntimeError, torch.linalg.LinAlgError) as e:
+                    first = first or e
+            if first is not None:
+                raise first
         return False
 
 
@@ -128,6 +157,7 @@ class Chol:
         self.dinv = dinv
         self.info = info
         self._checked = False
+        self._error = None            # what `check` raised: a failed factor stays failed
         self._dinv_sb = {128: dinv}
         self._clean = False
         self.lookahead_nb = 0
@@ -157,13 +187,15 @@ class Chol:
             dinv, info = be.potrf_(a, config.potrf_nbo)
             c = cls(a, dinv, info)
         if config.check_info:
-            if _deferred is not None:
-                _deferred.append(c)       # checked when the enclosing `deferred_checks()` block ends
+            if _deferred_state.pending is not None:
+                _deferred_state.pending.append(c)       # checked when the enclosing `deferred_checks()` block ends
             else:
                 c.check()
         return c
 
     def check(self):
+        if self._error is not None:
+            raise self._error
         if not self._checked:
             bad = 0
             if self.info.numel():
@@ -171,13 +203,26 @@ class Chol:
                 bad = lo if lo < 0 else hi
             self._checked = True
             if bad < 0:
-                raise RuntimeError("cholesky: the workgroups of the pipelined panel kernel stopped waiting for each other (gpk.h: info = -1); "
-                                   "the factor is unusable -- please report this")
-            if bad != 0:
-                raise torch.linalg.LinAlgError(
+                self._error = RuntimeError("cholesky: the workgroups of the pipelined panel kernel stopped waiting for each other (gpk.h: "
+                                           "info = -1); the factor is unusable -- please report this")
+            elif bad != 0:
+                self._error = torch.linalg.LinAlgError(
                     f"cholesky: the leading minor of order {bad} is not positive-definite "
                     "(increase B.epsilon or the noise)"
                 )
+            if self._error is not None:
+                raise self._error
+        return self
+
+    def vetted(self):
+        """This factor, for a holder that hands it out of a cache: raises what its check raised; checks it now if nobody has yet and
+        no ``deferred_checks()`` block of this thread is going to (the block it was made in was left through an exception)."""
+        if self._error is not None:
+            raise self._error
+        if not self._checked and config.check_info:
+            pending = _deferred_state.pending
+            if pending is None or not any(c is self for c in pending):
+                self.check()
         return self
 
     @property
@@ -239,18 +284,21 @@ class Chol:
         """``L^{-1} r`` for a few columns, remembered when the caller can name where ``r`` came from: ``source`` = the data
         tensor ``y`` when ``r`` is ``y`` minus a ZERO mean (``None`` otherwise).  The log-density (``random.py:276``) and the posterior
         mean (``observations.py:161-168``) of the same observations both need ``L^{-1} y`` -- the reference solves twice; here the
-        second asker gets the first one's result (0.46 ms of a cfg2 eval).  The key is the identity of ``y``'s storage at its
-        current version; the entry keeps ``y`` alive, so the address cannot be recycled under it."""
+        second asker gets the first one's result (0.46 ms of a cfg2 eval).  The key is the tensor OBJECT ``y`` (the entry holds it, so
+        its id cannot be recycled) at its version counter; no memory for tensors nothing vouches for (``_version_of``: host memory,
+        inference tensors)."""
         if source is None or not torch.is_tensor(source) or r.dim() != 2 or r.shape[-1] > 8 or torch.is_grad_enabled() and source.requires_grad:
             return self.solve(r)
-        key = (source.data_ptr(), source._version, tuple(source.shape), tuple(source.stride()), source.dtype)
-        hit = self._residuals.get(key)
-        if hit is not None:
-            return hit[1]
+        ver = _version_of(source)
+        if ver is None:
+            return self.solve(r)
+        hit = self._residuals.get(id(source))
+        if hit is not None and hit[0] is source and hit[1] == ver:
+            return hit[2]
         out = self.solve(r)
         if len(self._residuals) >= 2:
             self._residuals.clear()
-        self._residuals[key] = (source, out)
+        self._residuals[id(source)] = (source, ver, out)
         return out
 
     def inverse_lower(self):
@@ -284,6 +332,11 @@ class ChainChol:
     def check(self):
         for c in self.chols:
             c.check()
+        return self
+
+    def vetted(self):
+        for c in self.chols:
+            c.vetted()
         return self
 
     def logdet(self):
@@ -435,7 +488,8 @@ class Dense(AbstractMatrix):
             if config.epsilon:
                 be.add_diag_(a, config.epsilon)
             self._chol = Chol.factor_(a)
-        return self._chol
+            return self._chol
+        return self._chol.vetted()
 
     def logdet(self):
         return self.chol().logdet()
@@ -535,7 +589,8 @@ class KernelDense(Dense):
                 return super().chol()
             a = self._build(lower=True, jitter=config.epsilon)
             self._chol = Chol.factor_(a)
-        return self._chol
+            return self._chol
+        return self._chol.vetted()
 
 
 class FactoredDense(Dense):

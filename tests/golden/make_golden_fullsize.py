@@ -1,5 +1,12 @@
-"""Full-size golden values for BASELINE.json's headline configuration (configs[1]):
-EQ() kernel, N = 16384, D = 8, fp64, noise 0.1, epsilon 1e-12.
+"""Full-size golden values for BASELINE.json's configurations 2, 3 and 5 (configs[1], [2], [4]):
+
+  cfg2  EQ() kernel, N = 16384, D = 8, fp64, noise 0.1, epsilon 1e-12          -> cfg2_n16384.json
+  cfg3  EQ() + Linear(), N = 32768, D = 4, the fp32 inputs of the bench cast to fp64, epsilon 1e-6 (the
+        reference's own fp32 setting, README.md:887-888), N* = 16 of the 2048 test points -> cfg3_n32768.json
+  cfg5  PseudoObs (VFE), N = 200000, D = 8, M = 4096, same convention          -> cfg5_n200000_m4096.json
+
+cfg3 / cfg5 are the fp64 oracle on the fp32-ROUNDED inputs: what the fp32 HIP path must reproduce to 1e-3 and
+the fp64 HIP path (fed the same rounded numbers, same epsilon) to 1e-6.
 
 north_star: "N=16384, D=8 ... with logpdf matching CPU reference to 1e-6 rel".  This script
 regenerates EXACTLY the seeded inputs ``bench.make_inputs("dense_f64", ...)`` produces (CPU
@@ -11,7 +18,10 @@ and writes ``tests/golden/cfg2_n16384.json``: the log-density, posterior mean / 
 the first 16 test points, and checksums of the inputs (so that the GPU-side test can prove it fed the
 same numbers).  Takes a few minutes and ~6 GB on 8 cores.  Re-run:
 
-    python tests/golden/make_golden_fullsize.py
+    python tests/golden/make_golden_fullsize.py [cfg2] [cfg3] [cfg5]
+
+cfg3: ~17 GB (the kernel matrix is built in row blocks by the oracle's own ``kernel_matrix`` so that its N x N
+temporaries stay small, then ``np.linalg.cholesky``), cfg5: ~35 GB peak (``oracle.pseudo_obs`` as is).
 """
 import hashlib
 import json
@@ -38,7 +48,75 @@ def checksum(a):
             "shape": list(a.shape)}
 
 
-def main():
+def kernel_matrix_blocked(terms, x, rows=2048):
+    """``O.kernel_matrix(terms, x)`` evaluated row block by row block (element-wise identical arithmetic: every entry
+    comes out of the same ``pw_dists2`` / ``_kappa`` expressions) -- keeps the temporaries at rows x N."""
+    n = x.shape[0]
+    k = np.empty((n, n), dtype=x.dtype)
+    for i in range(0, n, rows):
+        k[i:i + rows] = O.kernel_matrix(terms, x[i:i + rows], x)
+    return k
+
+
+def cfg3():
+    w, t = make_inputs("sum_f32", torch.device("cpu"))
+    assert t["x"].dtype == torch.float32 and t["x"].shape == (32768, 4)
+    x, y, xs = (t[k].double().numpy() for k in ("x", "y", "xs"))      # the fp32-rounded numbers, in fp64
+    terms = [("eq", 1.0, 1.0), ("linear", 1.0, 1.0)]
+    eps = 1e-6
+    t0 = time.perf_counter()
+    k = kernel_matrix_blocked(terms, x)
+    d = np.diag_indices_from(k)
+    k[d] += NOISE                     # fdd.py:79
+    k[d] += eps                       # B.reg (same order of additions as oracle.reg)
+    chol = np.linalg.cholesky(k)      # = O.cholesky without the N x N identity temporary
+    del k
+    logdet = O.logdet_chol(chol)
+    quad = float(O.iqf_diag(chol, y)[0])
+    lp = -(logdet + x.shape[0] * O.LOG_2_PI + quad) / 2
+    ks = O.kernel_matrix(terms, x, xs[:N_TEST])
+    v = O.solve_lower(chol, ks)
+    mean = (v.T @ O.solve_lower(chol, y))[:, 0]
+    var = O.kernel_diag(terms, xs[:N_TEST]).reshape(-1) - np.sum(v * v, axis=0)
+    dt = time.perf_counter() - t0
+    out = {
+        "config": "BASELINE.json configs[2]: EQ()+Linear(), N=32768, D=4, fp32 inputs (cast to fp64 for the oracle), noise 0.1, epsilon 1e-6",
+        "generator": "tests/golden/make_golden_fullsize.py cfg3 (oracle/gp_oracle.py on bench.make_inputs('sum_f32'))",
+        "noise": NOISE, "epsilon": eps, "n_test": N_TEST,
+        "inputs": {"x": checksum(x), "y": checksum(y), "xs_first": checksum(xs[:N_TEST])},
+        "logpdf": float(lp), "logdet": float(logdet), "quadratic_form": quad,
+        "posterior_mean": [float(a) for a in mean], "posterior_var": [float(a) for a in var],
+        "oracle_seconds": round(dt, 1),
+    }
+    with open(os.path.join(HERE, "cfg3_n32768.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out)[:400], "...", flush=True)
+
+
+def cfg5():
+    w, t = make_inputs("sparse_f32", torch.device("cpu"))
+    assert t["x"].dtype == torch.float32 and t["x"].shape == (200000, 8) and t["z"].shape == (4096, 8)
+    x, y, z = (t[k].double().numpy() for k in ("x", "y", "z"))
+    terms = [("eq", 1.0, 1.0)]
+    eps = 1e-6
+    t0 = time.perf_counter()
+    r = O.pseudo_obs(terms, x, NOISE, y, z, method="vfe", eps=eps)
+    dt = time.perf_counter() - t0
+    out = {
+        "config": "BASELINE.json configs[4]: PseudoObs VFE, EQ(), N=200000, D=8, M=4096, fp32 inputs (cast to fp64 for the oracle), noise 0.1, epsilon 1e-6",
+        "generator": "tests/golden/make_golden_fullsize.py cfg5 (oracle/gp_oracle.py pseudo_obs on bench.make_inputs('sparse_f32'))",
+        "noise": NOISE, "epsilon": eps, "n_mu": N_TEST,
+        "inputs": {"x": checksum(x), "y": checksum(y), "z": checksum(z)},
+        "elbo": float(r["elbo"]), "mu_first": [float(a) for a in r["mu"][:N_TEST, 0]],
+        "mu_checksum": {"sum": float(r["mu"].sum()), "sum_abs": float(np.abs(r["mu"]).sum()), "max_abs": float(np.abs(r["mu"]).max())},
+        "oracle_seconds": round(dt, 1),
+    }
+    with open(os.path.join(HERE, "cfg5_n200000_m4096.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out)[:400], "...", flush=True)
+
+
+def cfg2():
     w, t = make_inputs("dense_f64", torch.device("cpu"))
     x, y, xs = (t[k].numpy() for k in ("x", "y", "xs"))
     assert x.shape == (16384, 8) and x.dtype == np.float64
@@ -72,4 +150,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    for which in (sys.argv[1:] or ["cfg2"]):
+        {"cfg2": cfg2, "cfg3": cfg3, "cfg5": cfg5}[which]()

@@ -323,7 +323,8 @@ def test_whitened_observations_are_solved_for_once(any_backend, monkeypatch):
     lp = fdd.logpdf(y)
     post = f | (fdd, y)
     mean, var = post(xs).marginals()
-    assert calls.count((300, 1)) == 1                  # one single-column solve for both
+    # one single-column solve for both on the device; host memory can change behind torch's back (NumPy aliases): solved twice there
+    assert calls.count((300, 1)) == (1 if y.is_cuda else 2)
     # the same numbers as without the shortcut
     f2 = st.GP(st.EQ())
     mean2, var2 = (f2 | (f2(x, 0.1), y))(xs).marginals()

@@ -37,10 +37,18 @@ def test_nan_scan_is_remembered_until_the_tensor_changes(monkeypatch):
     lp = fdd.logpdf(y)
     post = f | (fdd, y)
     n_first = len(calls)
-    assert n_first == 1                                  # the log-density scanned, the conditioning on the same y did not
     f2 = st.GP(st.EQ())
     f2(x, 0.1).logpdf(y)
-    assert len(calls) == n_first                         # another evaluation on the same data: no new scan
+    if y.is_cuda:
+        assert n_first == 1                              # the log-density scanned, the conditioning on the same y did not
+        assert len(calls) == n_first                     # another evaluation on the same data: no new scan
+        matrix.forget_scan(y)                            # ... until the caller says the data changed behind torch's back
+        f2(x, 0.1).logpdf(y)
+        assert len(calls) == n_first + 1
+        n_first = len(calls)
+    else:
+        assert n_first == 2 and len(calls) == 3          # host memory can be written through NumPy: nothing is remembered
+        n_first = len(calls)
     y[3, 0] = float("nan")                               # an in-place write bumps the version: scanned again, and found
     lp_nan = f2(x, 0.1).logpdf(y)
     assert len(calls) > n_first
@@ -66,7 +74,53 @@ def test_deferred_checks_report_at_the_end_of_the_block():
     with matrix.deferred_checks():
         ok = matrix.Dense(good.clone()).chol()
     assert float(ok.logdet()) == pytest.approx(np.log(np.linalg.det(good.cpu().numpy())), rel=1e-9)      # (B.epsilon on the diagonal)
-    assert matrix._deferred is None
+    assert matrix._deferred_state.pending is None
+
+
+def test_a_failed_factor_stays_failed_in_its_cache():
+    """inside ``deferred_checks()`` (``Normal.logpdf``) the factor is cached before it is checked -- the second use of the
+    same distribution must raise again, not return NaN; a block left through an exception leaves its factors to their next user."""
+    bad = T(np.array([[1.0, 2.0], [2.0, 1.0]]), f64)
+    y = T(np.array([[0.3], [-0.2]]), f64)
+    d = st.Normal(matrix.Dense(bad.clone()))
+    for _ in range(3):
+        with pytest.raises(torch.linalg.LinAlgError):
+            d.logpdf(y)
+    with pytest.raises(torch.linalg.LinAlgError):
+        d.var.chol()
+    m = matrix.Dense(bad.clone())
+    with pytest.raises(KeyError):
+        with matrix.deferred_checks():
+            m.chol()                                      # queued for the end of the block ...
+            raise KeyError("something else went wrong")   # ... which never checks it
+    assert matrix._deferred_state.pending is None
+    with pytest.raises(torch.linalg.LinAlgError):
+        m.chol()                                          # the next user does
+    # several failures in one block: every factor is looked at, the first failure is reported, the others stay failed too
+    m1, m2 = matrix.Dense(bad.clone()), matrix.Dense(bad.clone())
+    with pytest.raises(torch.linalg.LinAlgError):
+        with matrix.deferred_checks():
+            m1.chol(), m2.chol()
+    assert m1._chol._error is not None and m2._chol._error is not None
+
+
+def test_nan_scan_with_inference_tensors_and_numpy_aliases():
+    """inference tensors have no version counter (the scan must not ask for one), and host memory shared with NumPy can
+    change without torch noticing (nothing may be remembered about it)."""
+    rng = np.random.default_rng(3)
+    xh, yh = rng.standard_normal((30, 2)), rng.standard_normal((30, 1))
+    with torch.inference_mode():
+        x, y = T(xh, f64), T(yh, f64)
+        f = st.GP(st.EQ())
+        lp = f(x, 0.1).logpdf(y)
+        mean = (f | (f(x, 0.1), y))(x).mean
+    ref = O.gp_logpdf([("eq", 1.0, 1.0)], xh, 0.1, yh)
+    assert abs(float(lp) - ref) < 1e-8 * abs(ref) and torch.isfinite(mean).all()
+    shared = yh.copy()
+    y_alias = torch.from_numpy(shared)                    # host tensor aliasing a NumPy array
+    assert matrix.any_missing(y_alias) is False
+    shared[4, 0] = np.nan                                 # written through NumPy: no version bump
+    assert matrix.any_missing(y_alias) is True
 
 
 def test_dense_posterior_consumes_the_cross_matrix_and_the_pseudo_point_posterior_does_not(monkeypatch):
