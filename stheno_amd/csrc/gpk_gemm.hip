@@ -376,7 +376,8 @@ extern "C" int gpk_prof_start(void) {
     return GPK_OK;
 }
 
-// variant: 16*(64x64 tiles) + 8*(f64) + 4*(A k-major) + 2*(B k-major) + 1*(edge-checked kernel), or -1 for all
+// variant: 16*(64x64 tiles) + 8*(f64) + 4*(A k-major) + 2*(B k-major) + 1*(edge-checked kernel); + 32: the persistent update, 64 +: panel_step_kernel,
+// 96 +: gemm_trilo_pair_kernel, 128 +: gemm_trib_kernel; or -1 for all
 extern "C" int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops) {
     g_prof.on = false;
     double ms = 0, fl = 0;
@@ -491,12 +492,16 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         }
     }
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
+    const bool trib = (flags & 16) && g_trib && a_kmaj && b_kmaj && g.tiles_n == 1 && N <= 128 && g.split_from == INT32_MAX;
     ProfSlot* slot = nullptr;
     if (g_prof.on) {
         // useful (algorithmic) flops: a lower-only update counts the symmetric half
         // (a triangular operand halves the multiply-adds actually needed: the TRSM / TRMM count)
         const double fl = (lower_only ? 1.0 : 2.0) * ((flags & (2 | 4 | 8)) ? 0.5 : 1.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
-        slot = g_prof.begin((sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0), fl, stream);
+        // (gemm_trib_kernel is a kernel of its own: codes 128 + ...; round 3 filed it under gemm_kernel's code)
+        const int code = (trib && (nct == 2 || ts == 128)) ? 128 + (sizeof(T) == 8 ? 8 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0)
+                                                           : (sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0);
+        slot = g_prof.begin(code, fl, stream);
     }
     // triangular A, a grid too small to keep two waves per SIMD busy to the end: pairs of 32-row tiles (gemm_trilo_pair_kernel)
     if (g_trilo_pairs && flags == 4 && a_kmaj && ts == 64 && nct == 1 && batch == 1 && batch2 == 1 && M % 64 == 0 && M >= 256 &&
@@ -507,7 +512,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         const bool e2 = !aligned || (N % 64) || (K % BK);
         const dim3 pgrid((unsigned)((g.tiles_m / 2) * g.tiles_n), 1, 1);
         ProfSlot* ps = nullptr;
-        if (g_prof.on) ps = g_prof.begin(96 + (sizeof(T) == 8 ? 8 : 0) + (e2 ? 1 : 0), (double)M * (double)N * (double)K, stream);
+        if (g_prof.on) ps = g_prof.begin(96 + (sizeof(T) == 8 ? 8 : 0) + (b_kmaj ? 2 : 0) + (e2 ? 1 : 0), (double)M * (double)N * (double)K, stream);
         if (b_kmaj) {
             if (e2) hipLaunchKernelGGL((gemm_trilo_pair_kernel<T, true, true>), pgrid, dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((gemm_trilo_pair_kernel<T, true, false>), pgrid, dim3(256), 0, stream, g);
@@ -519,7 +524,6 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         GPK_CHECK_LAUNCH();
         return GPK_OK;
     }
-    const bool trib = (flags & 16) && g_trib && a_kmaj && b_kmaj && g.tiles_n == 1 && N <= 128 && g.split_from == INT32_MAX;
     if (trib && nct == 2) {
         if (edge) hipLaunchKernelGGL((gemm_trib_kernel<T, 64, true, 2>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((gemm_trib_kernel<T, 64, false, 2>), grid, dim3(256), 0, stream, g);

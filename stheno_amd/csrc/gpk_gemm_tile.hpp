@@ -7,6 +7,12 @@
 #include "gpk_common.hpp"
 #include <type_traits>
 
+// The k loop of the 128-tile: 0 = one chunk of global loads in flight, MFMA phase, write phase, barrier (rounds 1-3);
+// 1 = the software-pipelined loop (see gemm_tile).  A build-time switch: both loops in one kernel cost registers.
+#ifndef GPK_GEMM_PIPE
+#define GPK_GEMM_PIPE 1
+#endif
+
 namespace {
 
 // One operand tile of TS rows in LDS, either image: k-contiguous [TS][128 B] or
@@ -107,6 +113,24 @@ __device__ __forceinline__ void sstore(char* lds, const typename Traits<T>::vec_
     }
 }
 
+
+// vector i alone (the pipelined loop writes one vector per slice of MFMAs)
+template <typename T, int TS, bool KMAJ, int NT = 256>
+__device__ __forceinline__ void sstore1(char* lds, const typename Traits<T>::vec_t& r, int tid, int i) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    int off;
+    if (KMAJ) {
+        const int c = tid & 7, rr = (tid >> 3) + (NT / 8) * i;
+        off = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4);
+    } else {
+        constexpr int CPR = TS / VEC;
+        const int id = tid + NT * i;
+        off = (id / CPR) * ((TS + 16) * (int)sizeof(T)) + (id % CPR) * 16;
+    }
+    *reinterpret_cast<vec_t*>(lds + off) = r;
+}
+
 // ---- LDS -> MFMA operand -----------------------------------------------------
 // rowbase: first tile row of this 16-row fragment; lr = lane & 15; k = element index in chunk.
 template <typename T, int TS, bool KMAJ>
@@ -135,13 +159,14 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // TRIB: the B operand (N x K) is LOWER TRIANGULAR and the tile starts at column 0 of it (the panel solve P inv(L_cc)^T of the
 // Cholesky): a 16-column fragment at columns j0.. only needs k < j0 + 16, the MFMAs beyond are skipped per fragment and per group of
 // k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false>
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false, int PIPE = GPK_GEMM_PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
                                           long long* prof = nullptr) {
     if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int BK = Traits<T>::BK;
+    constexpr int VEC_ = Traits<T>::VEC;
     constexpr int NT = 64 * NW;          // threads
     // HALFW: eight waves on a 32-row tile (the latency-critical strips of the pipelined panel).  An operand tile is 256 vectors: the
     // two halves of the workgroup (waves 0-3 / 4-7) each stage and multiply HALF of the NCT column tiles, the lower half also
@@ -302,6 +327,167 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         prof[1] = wall_clock64();
         prof[4] = (long long)__builtin_readcyclecounter();   // shader-clock ticks: with the 100 MHz stamps they give the clock the k loop ran at
     }
+
+    // ---- PIPE: the software-pipelined k loop of the 128-tile (round 4) ----------------------------------------------------
+    // A lone fp64 wave issues an MFMA every ~140 cycles, two waves of a SIMD together every 64 (profiles/r03_experiments.md section 1):
+    // the matrix pipe runs at full rate only while BOTH waves of a SIMD have an MFMA to issue.  The loop below therefore never
+    // leaves the MFMA stream: a chunk is four PHASES (4 k values in fp64, 8 in fp32: one register set of fragments each);
+    // while phase p multiplies, the fragments of phase p + 1 are read from LDS into the other register set, the NEXT chunk (global
+    // loads issued one chunk earlier) is written to the other LDS stage (phase 0) and the chunk after that is requested from
+    // global memory (phase 1); the one barrier of the chunk sits in the middle of phase 3's MFMAs, and the first fragments of the
+    // next chunk are read behind it, under the rest of phase 3.  sched_group_barrier pins that interleaving.
+    if constexpr (PIPE != 0 && TS == 128 && NCT == 1 && NW == 4 && !TRIB && !EDGE) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef typename std::conditional<sizeof(T) == 8, double, f32x2>::type frag_t;
+        constexpr int KPP = (sizeof(T) == 8) ? 4 : 8;      // k values per phase
+        constexpr int NPH = BK / KPP;                       // phases per chunk
+        constexpr int MPP = FRM * FR * (KPP / 4);           // MFMAs per phase and wave
+        static_assert(NPH == 4, "four phases per chunk");
+        frag_t Fa[2][FRM], Fb[2][FR];
+        vec_t qa[NV], qb[NV];
+        const T* pa[NV];
+        const T* pb[NV];
+        // per-thread source pointers of the NV vectors of an operand tile (bumped by one chunk per issue)
+        auto init_ptrs = [&](const T* (&ptr)[NV], auto kmaj_c, const T* base, int64_t ld, int r0) {
+            constexpr bool KMAJ = decltype(kmaj_c)::value;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (KMAJ) {
+                    ptr[i] = base + (int64_t)(r0 + (tid >> 3) + (NT / 8) * i) * ld + (int64_t)kc0 * BK + (tid & 7) * VEC_;
+                } else {
+                    constexpr int CPR = TS / VEC_;
+                    const int id = tid + NT * i;
+                    ptr[i] = base + ((int64_t)kc0 * BK + id / CPR) * ld + r0 + (id % CPR) * VEC_;
+                }
+            }
+        };
+        init_ptrs(pa, std::integral_constant<bool, A_KMAJ>{}, A, p.lda, m0);
+        init_ptrs(pb, std::integral_constant<bool, B_KMAJ>{}, B, p.ldb, n0);
+        const int64_t stepA = A_KMAJ ? (int64_t)BK : (int64_t)BK * p.lda, stepB = B_KMAJ ? (int64_t)BK : (int64_t)BK * p.ldb;
+        // one vector of the next-but-one chunk: global -> registers (and the pointer moves on by a chunk)
+        // (the pointers stop at the tile's last chunk: past the end of the k range the loop re-reads that chunk and nobody uses it --
+        // one loop body for every chunk instead of three tail variants, which cost 800 bytes of scratch)
+        int64_t curA = 0, curB = 0;
+        auto g_issue1 = [&](int j) {
+            if (j < NV) { qa[j] = *reinterpret_cast<const vec_t*>(pa[j]); pa[j] += curA; }
+            else { qb[j - NV] = *reinterpret_cast<const vec_t*>(pb[j - NV]); pb[j - NV] += curB; }
+        };
+        int adv = nk - kc0 - 1;                 // how many more times the pointers may move on
+        auto g_arm = [&]() { curA = adv > 0 ? stepA : 0; curB = adv > 0 ? stepB : 0; --adv; };
+        // one vector of the next chunk: registers -> LDS stage
+        auto g_commit1 = [&](int stage, int j) {
+            char* dA = smem + stage * STAGE;
+            if (j < NV) sstore1<T, TS, A_KMAJ, NT>(dA, qa[j], tid, j);
+            else sstore1<T, TS, B_KMAJ, NT>(dA + OPB, qb[j - NV], tid, j - NV);
+        };
+        auto frag = [&](auto kmaj_c, const char* lds, int rowbase, int ph) -> frag_t {
+            constexpr bool KMAJ = decltype(kmaj_c)::value;
+            if constexpr (sizeof(T) == 8) {
+                return fragread<T, TS, KMAJ>(lds, rowbase, lr, ph * 4 + kq, swz);
+            } else {
+                // two consecutive k values per lane: step 2 * ph' + e of the chunk <-> k = 8 ph + 2 kq + e, the same permutation
+                // of the contraction order for both operands
+                if constexpr (KMAJ) {
+                    const int u = ph * 4 + kq;
+                    return *reinterpret_cast<const f32x2*>(lds + (rowbase + lr) * 128 + ((((u >> 1) ^ swz) << 4) + (u & 1) * 8));
+                } else {
+                    const int k = ph * 8 + 2 * kq;
+                    f32x2 v;
+                    v[0] = fragread<T, TS, false>(lds, rowbase, lr, k, swz);
+                    v[1] = fragread<T, TS, false>(lds, rowbase, lr, k + 1, swz);
+                    return v;
+                }
+            }
+        };
+        // fragment j of a phase (0 .. FRM - 1: A, FRM .. FRM + FR - 1: B): LDS -> register set
+        auto f_read1 = [&](auto set_c, int stage, int ph, int j) {
+            constexpr int set = decltype(set_c)::value;
+            const char* sA = smem + stage * STAGE;
+            if (j < FRM) Fa[set][j] = frag(std::integral_constant<bool, A_KMAJ>{}, sA, wm * WTM + j * 16, ph);
+            else Fb[set][j - FRM] = frag(std::integral_constant<bool, B_KMAJ>{}, sA + OPB, wn * WT + (j - FRM) * 16, ph);
+        };
+        // slice q of the NSL slices of a phase's MFMAs: fragment column q / 2, fragment rows 2 (q % 2), 2 (q % 2) + 1
+        constexpr int NSL = FRM * FR / 2;
+        static_assert(NSL == 8 && FRM + FR == 8 && 2 * NV == 8, "eight slices, eight fragments, eight vectors per phase");
+        auto f_mma1 = [&](auto set_c, int q) {
+            constexpr int set = decltype(set_c)::value;
+            const int fj = q >> 1, f0 = (q & 1) * 2;
+            if constexpr (sizeof(T) == 8) {
+                acc[0][f0][fj] = Traits<T>::mfma(Fa[set][f0], Fb[set][fj], acc[0][f0][fj]);
+                acc[0][f0 + 1][fj] = Traits<T>::mfma(Fa[set][f0 + 1], Fb[set][fj], acc[0][f0 + 1][fj]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc[0][f0][fj] = Traits<T>::mfma((T)Fa[set][f0][e], (T)Fb[set][fj][e], acc[0][f0][fj]);
+                    acc[0][f0 + 1][fj] = Traits<T>::mfma((T)Fa[set][f0 + 1][e], (T)Fb[set][fj][e], acc[0][f0 + 1][fj]);
+                }
+            }
+        };
+        typedef std::integral_constant<int, 0> F0;
+        typedef std::integral_constant<int, 1> F1;
+        // One chunk.  On entry: LDS stage `stage` holds the chunk, fragment set 0 its phase 0, qa / qb the next chunk; it writes that
+        // one to the other stage, requests the one after it and reads the next chunk's phase 0 at the end.
+        // The source order IS the schedule: sched_barrier(0) after every slice keeps the compiler from regrouping it.
+        auto chunk = [&](int stage) {
+            constexpr bool W = true, G = true;
+            g_arm();
+#pragma unroll
+            for (int q = 0; q < NSL; ++q) {          // phase 0: multiply set 0, read phase 1 into set 1, write the next chunk
+                f_mma1(F0{}, q);
+                f_read1(F1{}, stage, 1, q);
+                if constexpr (W) g_commit1(stage ^ 1, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NSL; ++q) {          // phase 1: multiply set 1, read phase 2 into set 0, request the chunk after next
+                f_mma1(F1{}, q);
+                f_read1(F0{}, stage, 2, q);
+                if constexpr (G) g_issue1(q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NSL; ++q) {          // phase 2: multiply set 0, read phase 3 into set 1
+                f_mma1(F0{}, q);
+                f_read1(F1{}, stage, 3, q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NSL / 2; ++q) f_mma1(F1{}, q);     // phase 3, first half
+            __builtin_amdgcn_sched_barrier(0);
+            // every wave has read this stage and written the other one
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = NSL / 2; q < NSL; ++q) {    // phase 3, second half: read phase 0 of the next chunk into set 0
+                f_mma1(F1{}, q);
+                if constexpr (W) {
+                    f_read1(F0{}, stage ^ 1, 0, 2 * (q - NSL / 2));
+                    f_read1(F0{}, stage ^ 1, 0, 2 * (q - NSL / 2) + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto g_issue = [&]() {
+#pragma unroll
+            for (int j = 0; j < 2 * NV; ++j) g_issue1(j);
+        };
+        int left = nk - kc0;                    // chunks of this tile (>= 1)
+        g_arm();
+        g_issue();
+#pragma unroll
+        for (int j = 0; j < 2 * NV; ++j) g_commit1(0, j);
+        __syncthreads();
+        g_arm();
+        g_issue();
+#pragma unroll
+        for (int j = 0; j < FRM + FR; ++j) f_read1(F0{}, 0, 0, j);
+        while (true) {
+            chunk(0);
+            if (--left == 0) break;
+            chunk(1);
+            if (--left == 0) break;
+        }
+    } else
     if (PF2) {
         issue(S0{}, kc0);
         if (kc0 + 1 < nk) issue(S1{}, kc0 + 1);
