@@ -34,6 +34,7 @@
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
 #include "gpk_gemm_tile.hpp"
+#include "gpk_gemm_stream.hpp"
 #include <type_traits>
 #include <cstring>
 #include <mutex>
@@ -143,6 +144,63 @@ __global__ __launch_bounds__(256, 2) void gemm_trib_kernel(GemmArgs<T> p) {
     gemm_tile<T, TS, true, true, EDGE, NCT, 4, true>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
 
+// The plain launch as a STREAM (gpk_gemm_stream.hpp): a resident grid, workgroup w takes the tasks w, w + G, w + 2G, ... of the
+// (tile, batch, batch2) index space the one-tile-per-workgroup launch would have had as its grid -- a static deal, every task the
+// same size (or, for triangular operands, dealt longest-first) -- so that it knows its next tile while it works on one.
+template <typename T, bool EDGE>
+struct StaticSched {
+    const GemmArgs<T>& p;
+    int gridx, batch, total;      // tasks = gridx (tiles incl. the quarter tiles of the last round) * batch * batch2
+    int t, stride;
+    __device__ __forceinline__ const GemmArgs<T>& args(int) const { return p; }
+    __device__ __forceinline__ void prefetch() {}
+    __device__ __forceinline__ TileRef decode(int task) const {
+        TileRef r;
+        r.seg = 0; r.ti = r.tj = 0; r.b = r.b2 = 0; r.task = task; r.kind = 0;
+        if (task >= total) return r;
+        const int bx = task % gridx, rest = task / gridx;
+        r.b = rest % batch; r.b2 = rest / batch;
+        r.kind = 2;
+        if (bx < p.split_from && decode_tile(p, bx, r.ti, r.tj) && tile_streamable<T, EDGE>(p, r.ti, r.tj)) r.kind = 1;
+        r.uniform();
+        return r;
+    }
+    __device__ __forceinline__ TileRef resolve(char*) {
+        t += stride;
+        return decode(t);
+    }
+};
+
+template <typename T, bool A_KMAJ, bool B_KMAJ, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs<T> p, int gridx, int batch, int total) {
+    __shared__ __attribute__((aligned(16))) char smem[STREAM_SMEM];
+    StaticSched<T, EDGE> sched{p, gridx, batch, total, (int)blockIdx.x + (int)gridDim.x, (int)gridDim.x};
+    TileRef cur = sched.decode((int)blockIdx.x);
+    TileRef nxt = sched.decode((int)blockIdx.x + (int)gridDim.x);
+    while (cur.kind != 0) {
+        if (cur.kind == 1) {
+            gemm_stream<T, A_KMAJ, B_KMAJ, EDGE>(cur, nxt, sched, smem);
+            continue;
+        }
+        // a tile that cannot ride in the stream (ragged edge, odd number of k-chunks, a quarter tile of the last round) -- or nothing
+        const int bx = cur.task % gridx;
+        int ti, tj;
+        if (bx >= p.split_from) {
+            const int qd = bx - p.split_from;
+            if (decode_tile(p, p.split_from + (qd >> 2), ti, tj)) {
+                const int ti2 = 2 * ti + ((qd >> 1) & 1), tj2 = 2 * tj + (qd & 1);
+                if (!((p.lower_only && tj2 > ti2) || ti2 * 64 >= p.M || tj2 * 64 >= p.N))
+                    gemm_tile<T, 64, A_KMAJ, B_KMAJ, EDGE, 1>(p, ti2, tj2, cur.b, cur.b2, smem);
+            }
+        } else if (decode_tile(p, bx, ti, tj)) {
+            gemm_tile<T, 128, A_KMAJ, B_KMAJ, EDGE, 1, 4, false, 0>(p, ti, tj, cur.b, cur.b2, smem);
+        }
+        __syncthreads();
+        cur = nxt;
+        nxt = sched.resolve(smem);
+    }
+}
+
 // A (M x K) LOWER TRIANGULAR, few tiles (the leaves `inv(L_qq) B_q` of the recursive solve: 1024 x 1024 against 2048 columns):
 // a row tile at row m0 runs m0 + TS of k, so with one tile per workgroup the long tiles finish alone -- one wave per SIMD, which
 // issues an MFMA every ~140 cycles (profiles/r03_experiments.md, sections 1 and 11: 62 us = 35 TFLOP/s for 2.1 GFLOP).  Here a
@@ -185,16 +243,87 @@ struct PersistArgs {
     int max_leave;
     unsigned rkeys[8];
     long long* prof;          // development aid: 8 slots (6 stamps) for each of the first 8 tiles of every workgroup (nullable)
+    int stream;               // tiles ride in gemm_stream (tuning knob 43)
+};
+
+// What a task index of the persistent launch stands for.
+template <typename T>
+struct PersistTask {
+    int sgi, ti, tj, quad, reps;
+    bool ok, quarter;
+};
+template <typename T, int TS>
+__device__ __forceinline__ PersistTask<T> persist_decode(const PersistArgs<T>& p, int t) {
+    PersistTask<T> k;
+    k.quarter = (TS == 128) && t >= p.split_from;
+    k.quad = k.quarter ? ((t - p.split_from) & 3) : 0;
+    const int tt = k.quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
+    k.sgi = (tt >= p.first[2]) ? 2 : ((tt >= p.first[1]) ? 1 : 0);
+    const GemmArgs<T>& g = p.seg[k.sgi];
+    const int tl = tt - p.first[k.sgi];
+    k.reps = 1;
+    k.ok = true;
+    if (g.tri_k_lo_b && g.pair_cols) {
+        // B lower triangular in k: column tile c runs c + 1 blocks of k.  One task = the tiles c and
+        // tiles_n - 1 - c of one tile row, tiles_n + 1 blocks together whatever c is: equal tasks.
+        const int half = g.tiles_n >> 1;
+        k.ti = tl / half;
+        k.tj = tl - k.ti * half;
+        k.reps = 2;
+    } else {
+        k.ok = decode_tile(g, tl, k.ti, k.tj);
+    }
+    return k;
+}
+
+// The tile scheduler of the persistent launch as gemm_stream wants it: tasks come from the device-side counter; the claim for the
+// task after next is started at the beginning of a tile (its latency hides under the k loop) and read at its end.
+template <typename T, int TS, bool EDGE>
+struct PersistSched {
+    const PersistArgs<T>& p;
+    int tid;
+    int pending;
+    __device__ __forceinline__ void prefetch() {
+        if (tid == 0) pending = (int)atomicAdd(&p.ctrl[0], 1u);
+    }
+    __device__ __forceinline__ const GemmArgs<T>& args(int seg) const { return p.seg[seg]; }
+    __device__ __forceinline__ TileRef decode(int t) const {
+        TileRef r;
+        r.seg = 0; r.ti = r.tj = 0; r.b = r.b2 = 0; r.task = t; r.kind = 0;
+        if (t >= p.ntasks) return r;
+        const PersistTask<T> k = persist_decode<T, TS>(p, t);
+        r.seg = k.sgi; r.ti = k.ti; r.tj = k.tj;
+        r.kind = 2;
+        if constexpr (TS == 128 && GPK_GEMM_PIPE != 0) {
+            if (p.stream && k.ok && !k.quarter && k.reps == 1 && !p.sig[k.sgi] && p.prof == nullptr && tile_streamable<T, EDGE>(p.seg[k.sgi], k.ti, k.tj))
+                r.kind = 1;
+        }
+        r.uniform();
+        return r;
+    }
+    // all threads: the claim started by prefetch(), broadcast through the scheduler's LDS word
+    __device__ __forceinline__ TileRef resolve(char* smem) {
+        // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast word lives in the
+        // unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel its fourth workgroup per CU)
+        volatile int* w = reinterpret_cast<volatile int*>(smem + TS * 128);
+        if (tid == 0) *w = pending;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int t = __builtin_amdgcn_readfirstlane(*w);     // uniform by construction; tell the compiler (scalar loads of the segment)
+        return decode(t);
+    }
+    __device__ __forceinline__ TileRef claim_sync(char* smem) {
+        prefetch();
+        TileRef r = resolve(smem);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the word when the next claim writes it
+        return r;
+    }
 };
 
 template <typename T, int TS, bool EDGE, int NW = 4>
 __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem) {
-    // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast
-    // word lives in the unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel
-    // its fourth workgroup per CU)
-    volatile int& s_tile = *reinterpret_cast<volatile int*>(smem + TS * 128);
     const int tid = threadIdx.x;
     if (p.reserve) {
+        volatile int& s_leave = *reinterpret_cast<volatile int*>(smem + TS * 128);
         if (tid == 0) {
             unsigned xcc, hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -205,43 +334,30 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             // the chip blocked by somebody else's kernel, the whole grid could otherwise drain through the
             // reserved CUs and leave the update undone
             if (leave && atomicAdd(&p.ctrl[1], 1u) >= (unsigned)p.max_leave) leave = false;
-            s_tile = leave ? -1 : 0;
+            s_leave = leave ? -1 : 0;
         }
         __syncthreads();
-        if (s_tile < 0) return;
+        if (s_leave < 0) return;
         __syncthreads();
     }
-    int t = 0, nlocal = 0;
-    if (tid == 0) s_tile = (int)atomicAdd(&p.ctrl[0], 1u);
-    __syncthreads();
-    t = __builtin_amdgcn_readfirstlane(s_tile);     // uniform by construction; tell the compiler (scalar loads of the segment)
-    __syncthreads();
-    while (t < p.ntasks) {
-        // the next tile index is requested now and read after this tile: its latency hides under the k-loop
-        int nxt = 0;
-        if (tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);
-        const bool quarter = (TS == 128) && t >= p.split_from;
-        const int quad = quarter ? ((t - p.split_from) & 3) : 0;
-        const int tt = quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
-        const int sgi = (tt >= p.first[2]) ? 2 : ((tt >= p.first[1]) ? 1 : 0);
-        const GemmArgs<T>& g = p.seg[sgi];
-        int ti, tj;
-        const int tl = tt - p.first[sgi];
-        int reps = 1;
-        bool ok = true;
-        if (g.tri_k_lo_b && g.pair_cols) {
-            // B lower triangular in k: column tile c runs c + 1 blocks of k.  One task = the tiles c and
-            // tiles_n - 1 - c of one tile row, tiles_n + 1 blocks together whatever c is: equal tasks.
-            const int half = g.tiles_n >> 1;
-            ti = tl / half;
-            tj = tl - ti * half;
-            reps = 2;
-        } else {
-            ok = decode_tile(g, tl, ti, tj);
+    PersistSched<T, TS, EDGE> sched{p, tid, 0};
+    int nlocal = 0;
+    // two tasks are held at any time: the one being worked on and its successor (what gemm_stream pre-loads)
+    TileRef cur = sched.claim_sync(smem);
+    TileRef nxt = sched.claim_sync(smem);
+    while (cur.kind != 0) {
+        if constexpr (TS == 128 && GPK_GEMM_PIPE != 0) {
+            if (cur.kind == 1) {
+                gemm_stream<T, true, true, EDGE>(cur, nxt, sched, smem);
+                continue;
+            }
         }
+        const PersistTask<T> k = persist_decode<T, TS>(p, cur.task);
+        const GemmArgs<T>& g = p.seg[k.sgi];
+        bool ok = k.ok;
         if constexpr (TS == 128) {
-            if (ok && quarter) {              // the last, partial round of the launch: 64 x 64 quarters of a 128-tile
-                const int ti2 = 2 * ti + (quad >> 1), tj2 = 2 * tj + (quad & 1);
+            if (ok && k.quarter) {              // the last, partial round of the launch: 64 x 64 quarters of a 128-tile
+                const int ti2 = 2 * k.ti + (k.quad >> 1), tj2 = 2 * k.tj + (k.quad & 1);
                 if (!((g.lower_only && tj2 > ti2) || ti2 * 64 >= g.M || tj2 * 64 >= g.N))
                     gemm_tile<T, 64, true, true, EDGE, 1, NW>(g, ti2, tj2, 0, 0, smem, nullptr);
                 ok = false;
@@ -251,9 +367,9 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             long long* pr = (p.prof != nullptr && nlocal < 8) ? p.prof + ((int64_t)blockIdx.x * 8 + nlocal) * 8 : nullptr;
             ++nlocal;
 #pragma unroll 1
-            for (int r = 0; r < reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
-                gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, ti, (reps == 2 && r == 0) ? g.tiles_n - 1 - tj : tj, 0, 0, smem, pr);
-            if (p.sig[sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
+            for (int r = 0; r < k.reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
+                gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr);
+            if (p.sig[k.sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
                 __syncthreads();               // every wave's stores of the tile are out (vmcnt drained before the barrier)
                 if (tid == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -262,10 +378,9 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
                 }
             }
         }
-        if (tid == 0) s_tile = nxt;
-        __syncthreads();
-        t = __builtin_amdgcn_readfirstlane(s_tile);
-        __syncthreads();
+        __syncthreads();          // (gemm_tile's operand stages are free again)
+        cur = nxt;
+        nxt = sched.claim_sync(smem);
     }
 }
 
@@ -294,6 +409,18 @@ void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, cons
         hipLaunchKernelGGL((gemm_kernel<T, TS, false, true, EDGE>), grid, dim3(256), 0, stream, args);
     else
         hipLaunchKernelGGL((gemm_kernel<T, TS, false, false, EDGE>), grid, dim3(256), 0, stream, args);
+}
+
+template <typename T, bool EDGE>
+void launch_stream(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, const GemmArgs<T>& args, int gridx, int batch, int total) {
+    if (a_kmaj && b_kmaj)
+        hipLaunchKernelGGL((gemm_stream_kernel<T, true, true, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
+    else if (a_kmaj && !b_kmaj)
+        hipLaunchKernelGGL((gemm_stream_kernel<T, true, false, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
+    else if (!a_kmaj && b_kmaj)
+        hipLaunchKernelGGL((gemm_stream_kernel<T, false, true, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
+    else
+        hipLaunchKernelGGL((gemm_stream_kernel<T, false, false, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
 }
 
 // ---- measurement hook: HIP events around every GEMM launch (opt-in, see gpk.h) ----
@@ -327,6 +454,7 @@ int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 
 int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
 int g_trib = 1;                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
 int g_trilo_pairs = 1;            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
+int g_stream = 1;                   // tuning knob (gpk_tune(43, v)): 128-tile launches run as tile streams (gpk_gemm_stream.hpp)
 int g_split_tail = 1;               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
@@ -366,6 +494,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 31) g_split_tail = (int)value;
     if (key == 36) g_trib = (int)value;
     if (key == 42) g_trilo_pairs = (int)value;
+    if (key == 43) g_stream = (int)value;
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -535,6 +664,13 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, true, 2>), grid, dim3(256), 0, stream, g);
         else
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, false, 2>), grid, dim3(256), 0, stream, g);
+    } else if (ts == 128 && g_stream && GPK_GEMM_PIPE != 0 && gridx * batch * batch2 <= INT32_MAX / 2) {
+        const int64_t tasks = gridx * batch * batch2, slots = (int64_t)device_cus() * 2;
+        const dim3 sgrid((unsigned)(tasks < slots ? tasks : slots));
+        if (edge)
+            launch_stream<T, true>(a_kmaj, b_kmaj, sgrid, stream, g, (int)gridx, (int)batch, (int)tasks);
+        else
+            launch_stream<T, false>(a_kmaj, b_kmaj, sgrid, stream, g, (int)gridx, (int)batch, (int)tasks);
     } else if (ts == 128) {
         if (edge)
             launch_layout<T, 128, true>(a_kmaj, b_kmaj, grid, stream, g);
@@ -713,6 +849,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     pa.split_from = INT32_MAX;
     pa.ctrl = ctrl;
     pa.prof = nullptr;
+    pa.stream = g_stream;
     if (g_tile_prof != nullptr) {
         if (g_tile_prof_only < 0 || g_tile_prof_count == g_tile_prof_only) pa.prof = g_tile_prof;
         ++g_tile_prof_count;
