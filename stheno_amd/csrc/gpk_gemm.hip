@@ -34,7 +34,6 @@
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
 #include "gpk_gemm_tile.hpp"
-#include "gpk_gemm_stream.hpp"
 #include <type_traits>
 #include <cstring>
 #include <mutex>
@@ -144,63 +143,6 @@ __global__ __launch_bounds__(256, 2) void gemm_trib_kernel(GemmArgs<T> p) {
     gemm_tile<T, TS, true, true, EDGE, NCT, 4, true>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
 
-// The plain launch as a STREAM (gpk_gemm_stream.hpp): a resident grid, workgroup w takes the tasks w, w + G, w + 2G, ... of the
-// (tile, batch, batch2) index space the one-tile-per-workgroup launch would have had as its grid -- a static deal, every task the
-// same size (or, for triangular operands, dealt longest-first) -- so that it knows its next tile while it works on one.
-template <typename T, bool EDGE>
-struct StaticSched {
-    const GemmArgs<T>& p;
-    int gridx, batch, total;      // tasks = gridx (tiles incl. the quarter tiles of the last round) * batch * batch2
-    int t, stride;
-    __device__ __forceinline__ const GemmArgs<T>& args(int) const { return p; }
-    __device__ __forceinline__ void prefetch() {}
-    __device__ __forceinline__ TileRef decode(int task) const {
-        TileRef r;
-        r.seg = 0; r.ti = r.tj = 0; r.b = r.b2 = 0; r.task = task; r.kind = 0;
-        if (task >= total) return r;
-        const int bx = task % gridx, rest = task / gridx;
-        r.b = rest % batch; r.b2 = rest / batch;
-        r.kind = 2;
-        if (bx < p.split_from && decode_tile(p, bx, r.ti, r.tj) && tile_streamable<T, EDGE>(p, r.ti, r.tj)) r.kind = 1;
-        r.uniform();
-        return r;
-    }
-    __device__ __forceinline__ TileRef resolve(char*) {
-        t += stride;
-        return decode(t);
-    }
-};
-
-template <typename T, bool A_KMAJ, bool B_KMAJ, bool EDGE>
-__global__ __launch_bounds__(256, 2) void gemm_stream_kernel(GemmArgs<T> p, int gridx, int batch, int total) {
-    __shared__ __attribute__((aligned(16))) char smem[STREAM_SMEM];
-    StaticSched<T, EDGE> sched{p, gridx, batch, total, (int)blockIdx.x + (int)gridDim.x, (int)gridDim.x};
-    TileRef cur = sched.decode((int)blockIdx.x);
-    TileRef nxt = sched.decode((int)blockIdx.x + (int)gridDim.x);
-    while (cur.kind != 0) {
-        if (cur.kind == 1) {
-            gemm_stream<T, A_KMAJ, B_KMAJ, EDGE>(cur, nxt, sched, smem);
-            continue;
-        }
-        // a tile that cannot ride in the stream (ragged edge, odd number of k-chunks, a quarter tile of the last round) -- or nothing
-        const int bx = cur.task % gridx;
-        int ti, tj;
-        if (bx >= p.split_from) {
-            const int qd = bx - p.split_from;
-            if (decode_tile(p, p.split_from + (qd >> 2), ti, tj)) {
-                const int ti2 = 2 * ti + ((qd >> 1) & 1), tj2 = 2 * tj + (qd & 1);
-                if (!((p.lower_only && tj2 > ti2) || ti2 * 64 >= p.M || tj2 * 64 >= p.N))
-                    gemm_tile<T, 64, A_KMAJ, B_KMAJ, EDGE, 1>(p, ti2, tj2, cur.b, cur.b2, smem);
-            }
-        } else if (decode_tile(p, bx, ti, tj)) {
-            gemm_tile<T, 128, A_KMAJ, B_KMAJ, EDGE, 1, 4, false, 0>(p, ti, tj, cur.b, cur.b2, smem);
-        }
-        __syncthreads();
-        cur = nxt;
-        nxt = sched.resolve(smem);
-    }
-}
-
 // A (M x K) LOWER TRIANGULAR, few tiles (the leaves `inv(L_qq) B_q` of the recursive solve: 1024 x 1024 against 2048 columns):
 // a row tile at row m0 runs m0 + TS of k, so with one tile per workgroup the long tiles finish alone -- one wave per SIMD, which
 // issues an MFMA every ~140 cycles (profiles/r03_experiments.md, sections 1 and 11: 62 us = 35 TFLOP/s for 2.1 GFLOP).  Here a
@@ -243,87 +185,16 @@ struct PersistArgs {
     int max_leave;
     unsigned rkeys[8];
     long long* prof;          // development aid: 8 slots (6 stamps) for each of the first 8 tiles of every workgroup (nullable)
-    int stream;               // tiles ride in gemm_stream (tuning knob 43)
-};
-
-// What a task index of the persistent launch stands for.
-template <typename T>
-struct PersistTask {
-    int sgi, ti, tj, quad, reps;
-    bool ok, quarter;
-};
-template <typename T, int TS>
-__device__ __forceinline__ PersistTask<T> persist_decode(const PersistArgs<T>& p, int t) {
-    PersistTask<T> k;
-    k.quarter = (TS == 128) && t >= p.split_from;
-    k.quad = k.quarter ? ((t - p.split_from) & 3) : 0;
-    const int tt = k.quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
-    k.sgi = (tt >= p.first[2]) ? 2 : ((tt >= p.first[1]) ? 1 : 0);
-    const GemmArgs<T>& g = p.seg[k.sgi];
-    const int tl = tt - p.first[k.sgi];
-    k.reps = 1;
-    k.ok = true;
-    if (g.tri_k_lo_b && g.pair_cols) {
-        // B lower triangular in k: column tile c runs c + 1 blocks of k.  One task = the tiles c and
-        // tiles_n - 1 - c of one tile row, tiles_n + 1 blocks together whatever c is: equal tasks.
-        const int half = g.tiles_n >> 1;
-        k.ti = tl / half;
-        k.tj = tl - k.ti * half;
-        k.reps = 2;
-    } else {
-        k.ok = decode_tile(g, tl, k.ti, k.tj);
-    }
-    return k;
-}
-
-// The tile scheduler of the persistent launch as gemm_stream wants it: tasks come from the device-side counter; the claim for the
-// task after next is started at the beginning of a tile (its latency hides under the k loop) and read at its end.
-template <typename T, int TS, bool EDGE>
-struct PersistSched {
-    const PersistArgs<T>& p;
-    int tid;
-    int pending;
-    __device__ __forceinline__ void prefetch() {
-        if (tid == 0) pending = (int)atomicAdd(&p.ctrl[0], 1u);
-    }
-    __device__ __forceinline__ const GemmArgs<T>& args(int seg) const { return p.seg[seg]; }
-    __device__ __forceinline__ TileRef decode(int t) const {
-        TileRef r;
-        r.seg = 0; r.ti = r.tj = 0; r.b = r.b2 = 0; r.task = t; r.kind = 0;
-        if (t >= p.ntasks) return r;
-        const PersistTask<T> k = persist_decode<T, TS>(p, t);
-        r.seg = k.sgi; r.ti = k.ti; r.tj = k.tj;
-        r.kind = 2;
-        if constexpr (TS == 128 && GPK_GEMM_PIPE != 0) {
-            if (p.stream && k.ok && !k.quarter && k.reps == 1 && !p.sig[k.sgi] && p.prof == nullptr && tile_streamable<T, EDGE>(p.seg[k.sgi], k.ti, k.tj))
-                r.kind = 1;
-        }
-        r.uniform();
-        return r;
-    }
-    // all threads: the claim started by prefetch(), broadcast through the scheduler's LDS word
-    __device__ __forceinline__ TileRef resolve(char* smem) {
-        // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast word lives in the
-        // unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel its fourth workgroup per CU)
-        volatile int* w = reinterpret_cast<volatile int*>(smem + TS * 128);
-        if (tid == 0) *w = pending;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int t = __builtin_amdgcn_readfirstlane(*w);     // uniform by construction; tell the compiler (scalar loads of the segment)
-        return decode(t);
-    }
-    __device__ __forceinline__ TileRef claim_sync(char* smem) {
-        prefetch();
-        TileRef r = resolve(smem);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // nobody still reads the word when the next claim writes it
-        return r;
-    }
 };
 
 template <typename T, int TS, bool EDGE, int NW = 4>
 __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem) {
+    // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast
+    // word lives in the unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel
+    // its fourth workgroup per CU)
+    volatile int& s_tile = *reinterpret_cast<volatile int*>(smem + TS * 128);
     const int tid = threadIdx.x;
     if (p.reserve) {
-        volatile int& s_leave = *reinterpret_cast<volatile int*>(smem + TS * 128);
         if (tid == 0) {
             unsigned xcc, hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -334,25 +205,57 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             // the chip blocked by somebody else's kernel, the whole grid could otherwise drain through the
             // reserved CUs and leave the update undone
             if (leave && atomicAdd(&p.ctrl[1], 1u) >= (unsigned)p.max_leave) leave = false;
-            s_leave = leave ? -1 : 0;
+            s_tile = leave ? -1 : 0;
         }
         __syncthreads();
-        if (s_leave < 0) return;
+        if (s_tile < 0) return;
         __syncthreads();
     }
-    PersistSched<T, TS, EDGE> sched{p, tid, 0};
-    int nlocal = 0;
-    // two tasks are held at any time: the one being worked on and its successor (what gemm_stream pre-loads)
-    TileRef cur = sched.claim_sync(smem);
-    TileRef nxt = sched.claim_sync(smem);
-    while (cur.kind != 0) {
-        if constexpr (TS == 128 && GPK_GEMM_PIPE != 0) {
-            if (cur.kind == 1) {
-                gemm_stream<T, true, true, EDGE>(cur, nxt, sched, smem);
-                continue;
-            }
+    // Two tasks are held at any time: the one being worked on and its successor, whose C tile the current tile's k loop pulls into
+    // the L2 (gemm_tile, pf_c).  The claim for the task after that is started at the beginning of a tile -- its latency hides under
+    // the k loop -- and handed round at its end.  The barriers of the hand-over wait for the LDS only: the stores of the finished
+    // tile drain while the next one starts (a __syncthreads() here waited 20-35 us for them, profiles/r04_gemm_checks_tileprof_1.log).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto claim_now = [&]() -> int {
+        if (tid == 0) s_tile = (int)atomicAdd(&p.ctrl[0], 1u);
+        lds_barrier();
+        const int v = __builtin_amdgcn_readfirstlane(s_tile);     // uniform by construction; tell the compiler (scalar loads of the segment)
+        lds_barrier();
+        return v;
+    };
+    struct Task { int sgi, ti, tj, quad, reps; bool ok, quarter; };
+    auto decode = [&](int t) -> Task {
+        Task k;
+        k.ok = t < p.ntasks;
+        k.quarter = (TS == 128) && t >= p.split_from;
+        k.quad = k.quarter ? ((t - p.split_from) & 3) : 0;
+        const int tt = k.quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
+        k.sgi = (tt >= p.first[2]) ? 2 : ((tt >= p.first[1]) ? 1 : 0);
+        k.ti = k.tj = 0;
+        k.reps = 1;
+        if (!k.ok) return k;
+        const GemmArgs<T>& g = p.seg[k.sgi];
+        const int tl = tt - p.first[k.sgi];
+        if (g.tri_k_lo_b && g.pair_cols) {
+            // B lower triangular in k: column tile c runs c + 1 blocks of k.  One task = the tiles c and
+            // tiles_n - 1 - c of one tile row, tiles_n + 1 blocks together whatever c is: equal tasks.
+            const int half = g.tiles_n >> 1;
+            k.ti = tl / half;
+            k.tj = tl - k.ti * half;
+            k.reps = 2;
+        } else {
+            k.ok = decode_tile(g, tl, k.ti, k.tj);
         }
-        const PersistTask<T> k = persist_decode<T, TS>(p, cur.task);
+        k.ti = __builtin_amdgcn_readfirstlane(k.ti);
+        k.tj = __builtin_amdgcn_readfirstlane(k.tj);
+        return k;
+    };
+    int nlocal = 0;
+    int t = claim_now(), tn = claim_now();
+    while (t < p.ntasks) {
+        int nxt = 0;
+        if (tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);       // the task after `tn`
+        const Task k = decode(t);
         const GemmArgs<T>& g = p.seg[k.sgi];
         bool ok = k.ok;
         if constexpr (TS == 128) {
@@ -366,9 +269,23 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
         if (ok) {
             long long* pr = (p.prof != nullptr && nlocal < 8) ? p.prof + ((int64_t)blockIdx.x * 8 + nlocal) * 8 : nullptr;
             ++nlocal;
+            // where the successor will read its C tile from (a plain 128-tile that reads C; anything else: no prefetch)
+            const T* pf_c = nullptr;
+            int64_t pf_ld = 0;
+            if constexpr (TS == 128) {
+                const Task kn = decode(tn);
+                if (kn.ok && !kn.quarter && kn.reps == 1) {
+                    const GemmArgs<T>& gn = p.seg[kn.sgi];
+                    if (gn.has_beta && kn.ti * TS + TS <= gn.M && kn.tj * TS + TS <= gn.N) {
+                        pf_c = gn.Cin + (int64_t)kn.ti * TS * gn.ldcin + (int64_t)kn.tj * TS;
+                        pf_ld = gn.ldcin;
+                    }
+                }
+            }
 #pragma unroll 1
             for (int r = 0; r < k.reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
-                gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr);
+                gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr,
+                                                          (r == k.reps - 1) ? pf_c : nullptr, pf_ld);
             if (p.sig[k.sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
                 __syncthreads();               // every wave's stores of the tile are out (vmcnt drained before the barrier)
                 if (tid == 0) {
@@ -378,9 +295,11 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
                 }
             }
         }
-        __syncthreads();          // (gemm_tile's operand stages are free again)
-        cur = nxt;
-        nxt = sched.claim_sync(smem);
+        if (tid == 0) s_tile = nxt;
+        lds_barrier();
+        t = tn;
+        tn = __builtin_amdgcn_readfirstlane(s_tile);
+        lds_barrier();
     }
 }
 
@@ -411,23 +330,12 @@ void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, cons
         hipLaunchKernelGGL((gemm_kernel<T, TS, false, false, EDGE>), grid, dim3(256), 0, stream, args);
 }
 
-template <typename T, bool EDGE>
-void launch_stream(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, const GemmArgs<T>& args, int gridx, int batch, int total) {
-    if (a_kmaj && b_kmaj)
-        hipLaunchKernelGGL((gemm_stream_kernel<T, true, true, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
-    else if (a_kmaj && !b_kmaj)
-        hipLaunchKernelGGL((gemm_stream_kernel<T, true, false, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
-    else if (!a_kmaj && b_kmaj)
-        hipLaunchKernelGGL((gemm_stream_kernel<T, false, true, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
-    else
-        hipLaunchKernelGGL((gemm_stream_kernel<T, false, false, EDGE>), grid, dim3(256), 0, stream, args, gridx, batch, total);
-}
-
 // ---- measurement hook: HIP events around every GEMM launch (opt-in, see gpk.h) ----
 struct ProfSlot {
     hipEvent_t a, b;
     int variant;
     double flops;
+    bool ended;
 };
 struct Prof {
     bool on = false;
@@ -442,11 +350,12 @@ struct Prof {
         }
         s.variant = variant;
         s.flops = flops;
+        s.ended = false;
         (void)hipEventRecord(s.a, stream);
         used.push_back(s);
         return &used.back();
     }
-    void end(ProfSlot* s, hipStream_t stream) { (void)hipEventRecord(s->b, stream); }
+    void end(ProfSlot* s, hipStream_t stream) { (void)hipEventRecord(s->b, stream); s->ended = true; }
 };
 Prof g_prof;
 
@@ -454,7 +363,6 @@ int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 
 int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
 int g_trib = 1;                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
 int g_trilo_pairs = 1;            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
-int g_stream = 1;                   // tuning knob (gpk_tune(43, v)): 128-tile launches run as tile streams (gpk_gemm_stream.hpp)
 int g_split_tail = 1;               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
                                     // loses 4 % to plain row-major order (ragged supertiles on the diagonal
@@ -494,7 +402,6 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 31) g_split_tail = (int)value;
     if (key == 36) g_trib = (int)value;
     if (key == 42) g_trilo_pairs = (int)value;
-    if (key == 43) g_stream = (int)value;
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -512,6 +419,7 @@ extern "C" int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, d
     double ms = 0, fl = 0;
     int64_t n = 0;
     for (auto& s : g_prof.used) {
+        if (!s.ended) continue;          // (a launch that bailed out between its two events)
         if (hipEventSynchronize(s.b) != hipSuccess) return GPK_ERR_LAUNCH;
         if (variant >= 0 && s.variant != variant) continue;
         float t = 0;
@@ -621,17 +529,6 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         }
     }
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
-    const bool trib = (flags & 16) && g_trib && a_kmaj && b_kmaj && g.tiles_n == 1 && N <= 128 && g.split_from == INT32_MAX;
-    ProfSlot* slot = nullptr;
-    if (g_prof.on) {
-        // useful (algorithmic) flops: a lower-only update counts the symmetric half
-        // (a triangular operand halves the multiply-adds actually needed: the TRSM / TRMM count)
-        const double fl = (lower_only ? 1.0 : 2.0) * ((flags & (2 | 4 | 8)) ? 0.5 : 1.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
-        // (gemm_trib_kernel is a kernel of its own: codes 128 + ...; round 3 filed it under gemm_kernel's code)
-        const int code = (trib && (nct == 2 || ts == 128)) ? 128 + (sizeof(T) == 8 ? 8 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0)
-                                                           : (sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0);
-        slot = g_prof.begin(code, fl, stream);
-    }
     // triangular A, a grid too small to keep two waves per SIMD busy to the end: pairs of 32-row tiles (gemm_trilo_pair_kernel)
     if (g_trilo_pairs && flags == 4 && a_kmaj && ts == 64 && nct == 1 && batch == 1 && batch2 == 1 && M % 64 == 0 && M >= 256 &&
         (const void*)A != (const void*)C && (const void*)B != (const void*)C && gpk_cdiv(M, 64) * gpk_cdiv(N, 64) <= 2 * (int64_t)device_cus()) {
@@ -653,6 +550,17 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         GPK_CHECK_LAUNCH();
         return GPK_OK;
     }
+    const bool trib = (flags & 16) && g_trib && a_kmaj && b_kmaj && g.tiles_n == 1 && N <= 128 && g.split_from == INT32_MAX;
+    ProfSlot* slot = nullptr;
+    if (g_prof.on) {
+        // useful (algorithmic) flops: a lower-only update counts the symmetric half
+        // (a triangular operand halves the multiply-adds actually needed: the TRSM / TRMM count)
+        const double fl = (lower_only ? 1.0 : 2.0) * ((flags & (2 | 4 | 8)) ? 0.5 : 1.0) * (double)M * (double)N * (double)K * (double)batch * (double)batch2;
+        // (gemm_trib_kernel is a kernel of its own: codes 128 + ...; round 3 filed it under gemm_kernel's code)
+        const int code = (trib && (nct == 2 || ts == 128)) ? 128 + (sizeof(T) == 8 ? 8 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0)
+                                                           : (sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0);
+        slot = g_prof.begin(code, fl, stream);
+    }
     if (trib && nct == 2) {
         if (edge) hipLaunchKernelGGL((gemm_trib_kernel<T, 64, true, 2>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((gemm_trib_kernel<T, 64, false, 2>), grid, dim3(256), 0, stream, g);
@@ -664,13 +572,6 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, true, 2>), grid, dim3(256), 0, stream, g);
         else
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, false, 2>), grid, dim3(256), 0, stream, g);
-    } else if (ts == 128 && g_stream && GPK_GEMM_PIPE != 0 && gridx * batch * batch2 <= INT32_MAX / 2) {
-        const int64_t tasks = gridx * batch * batch2, slots = (int64_t)device_cus() * 2;
-        const dim3 sgrid((unsigned)(tasks < slots ? tasks : slots));
-        if (edge)
-            launch_stream<T, true>(a_kmaj, b_kmaj, sgrid, stream, g, (int)gridx, (int)batch, (int)tasks);
-        else
-            launch_stream<T, false>(a_kmaj, b_kmaj, sgrid, stream, g, (int)gridx, (int)batch, (int)tasks);
     } else if (ts == 128) {
         if (edge)
             launch_layout<T, 128, true>(a_kmaj, b_kmaj, grid, stream, g);
@@ -849,7 +750,6 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     pa.split_from = INT32_MAX;
     pa.ctrl = ctrl;
     pa.prof = nullptr;
-    pa.stream = g_stream;
     if (g_tile_prof != nullptr) {
         if (g_tile_prof_only < 0 || g_tile_prof_count == g_tile_prof_only) pa.prof = g_tile_prof;
         ++g_tile_prof_count;

@@ -146,6 +146,12 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
     return *reinterpret_cast<const T*>(lds + off);
 }
 
+// pf_c / pf_ld (pipelined 128-tile only): first element and leading dimension of the C tile this workgroup will READ NEXT (the
+// persistent kernel knows its next task).  Round 4, from the per-tile time stamps (profiles/r04_gemm_checks_tileprof_1.log): a
+// workgroup waits 20-45 us for the 1024 cache lines of its C tile (HBM misses, a few dozen in flight per CU) before its first
+// MFMA, and the other workgroup of the CU covers that at the lone-wave rate only.  Each thread therefore touches one line of the
+// next tile per chunk during the last few chunks of this one -- just in time: the XCD's 4 MiB L2 turns over in ~25 us -- so that the
+// next tile's C loads are L2 hits.
 // NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
 // Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
 // One output tile (ti, tj) of one problem, computed by the calling workgroup (256 threads).  `smem`:
@@ -161,7 +167,7 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
 template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false, int PIPE = GPK_GEMM_PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
-                                          long long* prof = nullptr) {
+                                          long long* prof = nullptr, const T* pf_c = nullptr, int64_t pf_ld = 0) {
     if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
@@ -198,7 +204,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     T* __restrict__ C = p.C + b * p.sC + b2 * p.sC2;
     const T* __restrict__ Cin = p.Cin + b * p.sC + b2 * p.sC2;
 
+    // tile indices come out of a float square root (decode_tile) or an LDS broadcast: tell the compiler they are wave-uniform, so
+    // that everything derived from them -- the tile's base addresses above all -- is scalar arithmetic
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
     const int m0 = ti * TS, n0 = tj * TS * NCT;
+
+    // C addressing: a wave-uniform base per (fragment, accumulator register) + ONE per-lane byte offset (round 4: the 64 loads and 64
+    // stores of a tile used to compute a 64-bit row * ld + col per element on the vector ALU -- 6 + 5 us of a K = 1024 tile's ~270
+    // went into ISSUING them).  crow(lane, i) = crow(lane, 0) + rstep * i.
+    constexpr int RSTEP = (sizeof(T) == 8) ? 4 : 1;
+    const unsigned lane_off_in = ((unsigned)Traits<T>::crow(lane, 0) * (unsigned)p.ldcin + (unsigned)lr) * (unsigned)sizeof(T);
+    const unsigned lane_off_out = ((unsigned)Traits<T>::crow(lane, 0) * (unsigned)p.ldc + (unsigned)lr) * (unsigned)sizeof(T);
+    auto c_base = [&](int64_t ld, int c, int fi, int fj, int i) -> int64_t {      // (uniform) element offset of the fragment register's first row / column
+        return (int64_t)(m0 + wm * WTM + fi * 16 + RSTEP * i) * ld + (n0 + (cfirst + c) * TS + wn * WT + fj * 16);
+    };
 
     acc_t acc[NCW][FRM][FR];
 #pragma unroll
@@ -213,7 +233,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                         const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
                         const int col = n0 + (cfirst + c) * TS + wn * WT + fj * 16 + lr;
                         T v = T(0);
-                        if (!EDGE || (row < p.M && col < p.N)) v = Cin[(int64_t)row * p.ldcin + col];
+                        if (!EDGE || (row < p.M && col < p.N))
+                            v = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(Cin + c_base(p.ldcin, c, fi, fj, i)) + lane_off_in);
                         acc[c][fi][fj][i] = v * p.beta_over_alpha;
                     }
         } else {
@@ -336,7 +357,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // loads issued one chunk earlier) is written to the other LDS stage (phase 0) and the chunk after that is requested from
     // global memory (phase 1); the one barrier of the chunk sits in the middle of phase 3's MFMAs, and the first fragments of the
     // next chunk are read behind it, under the rest of phase 3.  sched_group_barrier pins that interleaving.
-    if constexpr (PIPE != 0 && TS == 128 && NCT == 1 && NW == 4 && !TRIB && !EDGE) {
+    // (bounds-checked kernels: the interior tiles of a ragged problem take it too -- cfg5's N = 200000, the look-ahead at orders
+    // that are not multiples of 128)
+    constexpr bool PIPE_KERNEL = PIPE != 0 && TS == 128 && NCT == 1 && NW == 4 && !TRIB;
+    const bool pipe_tile = PIPE_KERNEL && (!EDGE || (a_in && b_in && p.K % BK == 0));
+    if constexpr (PIPE_KERNEL) if (pipe_tile) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef typename std::conditional<sizeof(T) == 8, double, f32x2>::type frag_t;
         constexpr int KPP = (sizeof(T) == 8) ? 4 : 8;      // k values per phase
@@ -425,6 +450,21 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         };
         typedef std::integral_constant<int, 0> F0;
         typedef std::integral_constant<int, 1> F1;
+        // the next tile's C lines, one per thread and chunk over the last PFN chunks (see pf_c above); every other chunk the same
+        // instruction re-reads an operand address that is in the L1 anyway -- the loop body stays free of branches
+        constexpr int LPR = TS * (int)sizeof(T) / 128;          // cache lines per tile row
+        constexpr int PFN = TS * LPR / NT;                      // lines per thread: 4 (fp64) / 2 (fp32)
+        const char* pf_lane = pf_c == nullptr ? nullptr
+                                              : reinterpret_cast<const char*>(pf_c + (int64_t)(tid / LPR) * pf_ld) + (tid % LPR) * 128;
+        const int64_t pf_step = (int64_t)(NT / LPR) * pf_ld * (int64_t)sizeof(T);
+        int left = nk - kc0;                    // chunks of this tile still to be multiplied (>= 1)
+        int pfv = 0;
+        auto pf_tick = [&]() {
+            asm volatile("" ::"v"(pfv));        // (the previous one is back: it is a chunk old)
+            const int j = left - 3;             // chunks left - 3 = PFN - 1 ... 0: the tile's last lines go last
+            const char* a = (pf_lane != nullptr && j >= 0 && j < PFN) ? pf_lane + j * pf_step : reinterpret_cast<const char*>(pa[0]);
+            pfv = *reinterpret_cast<const int*>(a);
+        };
         // One chunk.  On entry: LDS stage `stage` holds the chunk, fragment set 0 its phase 0, qa / qb the next chunk; it writes that
         // one to the other stage, requests the one after it and reads the next chunk's phase 0 at the end.
         // The source order IS the schedule: sched_barrier(0) after every slice keeps the compiler from regrouping it.
@@ -443,6 +483,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                 f_mma1(F1{}, q);
                 f_read1(F0{}, stage, 2, q);
                 if constexpr (G) g_issue1(q);
+                if (q == NSL - 1) pf_tick();         // (behind the chunk's own loads: nothing younger than it is waited for within the next chunk)
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -471,12 +512,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
             for (int j = 0; j < 2 * NV; ++j) g_issue1(j);
         };
-        int left = nk - kc0;                    // chunks of this tile (>= 1)
         g_arm();
         g_issue();
 #pragma unroll
         for (int j = 0; j < 2 * NV; ++j) g_commit1(0, j);
         __syncthreads();
+        if (prof != nullptr && threadIdx.x == 0) prof[6] = wall_clock64();      // C values and the first chunk have arrived
         g_arm();
         g_issue();
 #pragma unroll
@@ -487,7 +528,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             chunk(1);
             if (--left == 0) break;
         }
-    } else
+        asm volatile("" ::"v"(pfv));
+    }
+    if (!pipe_tile) {
     if (PF2) {
         issue(S0{}, kc0);
         if (kc0 + 1 < nk) issue(S1{}, kc0 + 1);
@@ -518,6 +561,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             __syncthreads();
         }
     }
+    }
 
     if (prof != nullptr && threadIdx.x == 0) {      // k loop done
         prof[2] = wall_clock64();
@@ -535,7 +579,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                     const int row = m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
                     const int col = n0 + (cfirst + c) * TS + wn * WT + fj * 16 + lr;
                     if (!EDGE || (row < p.M && col < p.N))
-                        C[(int64_t)row * p.ldc + col] = p.alpha * acc[c][fi][fj][i];
+                        *reinterpret_cast<T*>(reinterpret_cast<char*>(C + c_base(p.ldc, c, fi, fj, i)) + lane_off_out) = p.alpha * acc[c][fi][fj][i];
                 }
     if (prof != nullptr) {
         __builtin_amdgcn_s_waitcnt(0);          // (profiling only) stores retired

@@ -1404,15 +1404,16 @@ static void tile_profile(int k = 1024, int lower = 1, int warm = 0) {
     gpk_tune_tile_prof(nullptr);
     auto h = prof.down();
     for (int ti = 0; ti < 8; ++ti) {
-        double a = 0, b = 0, c = 0, gap = 0, cyc = 0; int cnt = 0, cg = 0;
+        double a = 0, b = 0, c = 0, gap = 0, cyc = 0, arr = 0; int cnt = 0, cg = 0;
         for (int w = 0; w < grid; ++w) {
             const long long* q = &h[((size_t)w * 8 + ti) * 8];
             if (q[3] == 0) continue;
             a += (q[1] - q[0]) * 0.01; b += (q[2] - q[1]) * 0.01; c += (q[3] - q[2]) * 0.01; cyc += (double)(q[5] - q[4]); ++cnt;
+            if (q[6]) arr += (q[6] - q[1]) * 0.01;
             if (ti > 0) { const long long* pq = &h[((size_t)w * 8 + ti - 1) * 8]; gap += (q[0] - pq[3]) * 0.01; ++cg; }
         }
-        if (cnt) printf("TILEPROF tile #%d of a workgroup (%d workgroups): request C %.1f us | k loop (incl. C arrival, first chunk) %.1f us = %.3f us per chunk at %.0f MHz shader clock | stores retired %.1f us | gap to previous tile %.1f us\n",
-                        ti, cnt, a / cnt, b / cnt, b / cnt / (k / 16), cyc / b, c / cnt, cg ? gap / cg : 0.0);
+        if (cnt) printf("TILEPROF tile #%d of a workgroup (%d workgroups): request C %.1f us | k loop (incl. C arrival, first chunk) %.1f us = %.3f us per chunk at %.0f MHz shader clock, of it C + first chunk arrived after %.1f us | stores retired %.1f us | gap to previous tile %.1f us\n",
+                        ti, cnt, a / cnt, b / cnt, b / cnt / (k / 16), cyc / b, arr / cnt, c / cnt, cg ? gap / cg : 0.0);
     }
     // start-time spread of the first tiles and of the last stamps
     long long t0 = LLONG_MAX, t1 = 0, e0 = LLONG_MAX, e1 = 0;
