@@ -273,31 +273,32 @@ int gpk_kmat_vjp_dense(int dtype, const int* kinds, const double* variances, con
 int gpk_prof_start(void);
 int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops);
 
-/* Development aids: tuning knobs for A/B measurements (native self-test `--set KEY VALUE`); defaults are the
- * measured optima, the product path never calls these.  key 1: use 64x64 GEMM tiles below this many 128-tiles;
- * 2: XCD super-tile order from this many tiles; 4: row-pair tile order from this many tiles; 6: look-ahead overlaps while the trailing matrix has at least this many
- * rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the persistent update takes 64x64 tiles
- * below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain algorithm (0 = 6144);
- * 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written last;
- * 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 13: column-major GEMM tile order from this ratio of
- * tile columns to tile rows (off by default); 17: 1 = one-workgroup-per-matrix TRSV for batches of small factors;
- * 18: 1 = the CUs reserved for the look-ahead chain rejoin the trailing update once the chain is done (default);
- * 20: gpk_tune_tile_prof stamps only the v-th persistent launch since this knob was set (-1 = every launch);
- * 30: 1 = 512-thread diagonal-block kernel (default), 0 = the 256-thread kernel of rounds 1-2; 31: quarter tiles for the last partial
- * round of a 128-tile GEMM launch; 32: fused panel-step kernel (batched / fallback path); 34: compact 1-D grid for lower-triangle
- * kernel matrices; 36: triangular-operand fragment skipping in panel solves; 37: 1 = one pipelined launch per panel for single
- * matrices (default), 0 = diagonal-block kernel + panel-step kernel per 128 columns; 38: the rest of a panel's trailing update rides
- * in the next panel's launch; 39: workgroups that take panel tasks first in such a launch (0 = a third of the CUs); 40 / 41: the
- * look-ahead's update of the next diagonal block is the first segment of the trailing update while that has at least (40) rows
- * and the outer block is at most (41) wide; 42: small products with a lower-triangular A (the leaves of the recursive solve) as pairs
- * of 32-row tiles with equal K per workgroup.
+/* Development aids.  The RELEASE library (stheno_amd/csrc/libgpk.so) has no tuning knobs: every one of them is a compile-time
+ * constant at its measured optimum and gpk_tune() does nothing.  The dev build (stheno_amd/csrc/dev/libgpk.so, -DGPK_DEV_KNOBS;
+ * what the native self-test links against and what GPK_DEV=1 makes the Python binding load) keeps them mutable for A/B runs
+ * (`gpk_selftest --set KEY VALUE`).  key 1: use 64x64 GEMM tiles below this many 128-tiles; 6: look-ahead overlaps while the
+ * trailing matrix has at least this many rows; 7: 0 = look-ahead algorithm on one stream, 1 = with the helper stream; 8: the
+ * persistent update takes 64x64 tiles below this many 128-tiles; 9: gpk_potrf_la finishes the last this-many rows with the plain
+ * algorithm (0 = 6144); 10: panel GEMM of gpk_potrf_la as 0 = plain launch, 1 / 2 = persistent (paired tiles); 11: strip written
+ * last; 12: 1 = row-band kernel-matrix kernel, 0 = one tile per workgroup; 17: 1 = one-workgroup-per-matrix TRSV for batches of
+ * small factors; 18: 1 = the CUs reserved for the look-ahead chain rejoin the trailing update once the chain is done;
+ * 20: gpk_tune_tile_prof stamps only the v-th persistent launch since this knob was set (-1 = every launch); 31: quarter tiles for
+ * the last partial round of a 128-tile GEMM launch; 32: fused panel-step kernel (batched / fallback path); 34: compact 1-D grid for
+ * lower-triangle kernel matrices; 36: triangular-operand fragment skipping in panel solves; 37: 1 = one pipelined launch per panel
+ * for single matrices, 0 = diagonal-block kernel + panel-step kernel per 128 columns (the batched path's steps); 38: the rest of a
+ * panel's trailing update rides in the next panel's launch; 39: workgroups that take panel tasks first in such a launch (0 = a
+ * third of the CUs); 40 / 41: the look-ahead's update of the next diagonal block is the first segment of the trailing update while
+ * that has at least (40) rows and the outer block is at most (41) wide; 42: small products with a lower-triangular A (the leaves of
+ * the recursive solve) as pairs of 32-row tiles with equal K per workgroup.  (Removed in round 4 with the code they selected: 2 / 4 /
+ * 13 -- XCD super-tile, row-pair and column-major tile orders -- and 30, the 256-thread diagonal-block kernel of rounds 1-2.)
  * gpk_tune_diag_prof: device buffer (32 int64 per diagonal block, or NULL) for cycle / wall-clock stamps of the diagonal-block
  * kernel and of the pipelined panel's chain and critical tasks (read by `gpk_selftest --diagprof`). */
 void gpk_tune(int key, int64_t value);
 void gpk_tune_diag_prof(long long* dev_buf);
 /* device buffer (grid x 8 tiles x 8 int64, or NULL): stamps of the persistent update's first 8 tiles per workgroup:
  * [0..3] wall clock (10 ns ticks) at entry / C tile requested / k loop done / stores retired, [4], [5] shader-cycle
- * counter at the start and the end of the k loop (so the clock the loop ran at can be read off), [6], [7] unused. */
+ * counter at the start and the end of the k loop (so the clock the loop ran at can be read off), [6] wall clock when the C values
+ * and the first operand chunk have arrived (pipelined 128-tile), [7] unused. */
 void gpk_tune_tile_prof(long long* dev_buf);
 
 /* Strided 2-D copy (rows x cols). */

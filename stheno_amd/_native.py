@@ -108,7 +108,12 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libgpk.so")
+    """``csrc/libgpk.so`` -- the release library (no tuning knobs).  ``GPK_DEV=1`` selects ``csrc/dev/libgpk.so``, the same sources
+    built with mutable knobs (``make -C stheno_amd/csrc``), for A/B measurements; never set in a product run."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    if os.environ.get("GPK_DEV") == "1":
+        return os.path.join(here, "dev", "libgpk.so")
+    return os.path.join(here, "libgpk.so")
 
 
 def load():
@@ -132,8 +137,9 @@ def load():
 
         atexit.register(lib.gpk_shutdown)      # helper streams must not outlive the HIP runtime's own teardown
         # Development aid for A/B runs of the library's tuning knobs (gpk_tune in include/gpk.h), e.g.
-        # GPK_DEV=1 GPK_TUNE="21=0,9=4096".  Ignored unless GPK_DEV=1 is set as well: a stray GPK_TUNE in a user's
-        # environment must not change what the product path runs.
+        # GPK_DEV=1 GPK_TUNE="9=4096,38=0" (GPK_DEV=1 loads the dev build above; in the release library gpk_tune does nothing).
+        # Ignored unless GPK_DEV=1 is set as well: a stray GPK_TUNE in a user's environment must not change what the product
+        # path runs.
         if os.environ.get("GPK_DEV") == "1":
             for item in filter(None, os.environ.get("GPK_TUNE", "").split(",")):
                 key, _, value = item.partition("=")

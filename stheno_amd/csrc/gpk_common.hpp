@@ -11,6 +11,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Tuning knobs.  A RELEASE build (the default) has none: every "knob" is a compile-time constant at its measured optimum, the
+// branches it guards are folded away and gpk_tune() does nothing.  `make dev` (-DGPK_DEV_KNOBS, into dev/) builds the library with
+// mutable knobs for A/B measurements through `gpk_selftest --set KEY VALUE` / GPK_DEV=1 GPK_TUNE=... .
+#ifdef GPK_DEV_KNOBS
+#define GPK_KNOB(type, name, value) type name = (value)
+#define GPK_KNOB_SET(stmt) stmt
+#else
+#define GPK_KNOB(type, name, value) constexpr type name = (value)
+#define GPK_KNOB_SET(stmt) ((void)0)
+#endif
+
 #define GPK_WAVE 64
 #define GPK_TILE 128      // GEMM block tile (rows and cols)
 #define GPK_DB 128        // diagonal block factorised in LDS by one workgroup

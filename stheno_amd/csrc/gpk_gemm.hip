@@ -26,10 +26,10 @@
 //    k-rows of a 32-lane group on different bank halves).
 //  * blockIdx -> tile mapping: plain row-major (triangular for the lower-only mode);
 //    workgroup b runs on XCD b % 8, so consecutive tiles of a tile row spread over the 8
-//    L2s.  An 8x8-super-tile-per-XCD order (each XCD's 64 tiles in flight share 16 operand
-//    panels of its 4 MiB L2) is implemented behind g_swizzle_from but OFF by default: on
-//    MI355X it measured 4 % SLOWER on the Cholesky trailing update (ragged diagonal
-//    super-tiles unbalance the XCDs; the 256 MB MALL already serves the panel re-reads).
+//    L2s.  Three other orders were built and measured in rounds 1-3 and are gone: an 8x8 super-tile per XCD (4 % SLOWER on the
+//    Cholesky trailing update: ragged diagonal super-tiles unbalance the XCDs, the 256 MB MALL already serves the panel re-reads),
+//    a row-pair order for triangular grids (no change) and a column-major walk for wide rectangular problems (cfg5: 87 vs 64 ms
+//    per step although it cut the fabric-side re-reads of K_zx).  profiles/r01_experiments.md, r02_experiments.md.
 //  * accumulators are initialised with C * (beta / alpha) so the epilogue is a
 //    pure store of alpha * acc (exact for alpha = -1, beta = 1).
 #include "gpk_common.hpp"
@@ -52,63 +52,19 @@ __device__ __forceinline__ void tri_decode(int s, int& I, int& J) {
 template <typename T>
 __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& ti, int& tj) {
     const bool tri = p.lower_only && p.tiles_m == p.tiles_n;   // square: triangular enumeration
-    if (!p.swizzle) {
-        if (tri && p.tri_pairs) {
-            // rows in pairs, columns in chunks of 8: [row 2q, cols c..c+7][row 2q+1, cols c..c+7] ...
-            // the two tiles of a column sit 8 workgroups apart = on the same XCD, back to back:
-            // each B panel is fetched once per row PAIR into that XCD's L2.  Pair q spans 2q+2 columns.
-            int q = (int)((sqrtf(1.f + 2.f * (float)bid) - 1.f) * 0.5f);
-            while (2 * (q + 1) * (q + 2) <= bid) ++q;
-            while (2 * q * (q + 1) > bid) --q;
-            const int w = bid - 2 * q * (q + 1), width = 2 * q + 2;
-            const int c = w >> 4, i = w & 15;
-            int r, col;
-            if (8 * c + 8 <= width) {
-                r = i >> 3;
-                col = 8 * c + (i & 7);
-            } else {
-                const int rem = width - 8 * c;
-                r = i / rem;
-                col = 8 * c + i % rem;
-            }
-            ti = 2 * q + r;
-            tj = col;
-            return ti < p.tiles_m && tj <= ti && r < 2;
-        }
-        if (tri) {
-            tri_decode(bid, ti, tj);
-            return ti < p.tiles_m;
-        }
-        if (p.tri_k_lo_b) {   // B lower triangular in k: column tile tj runs tj + 1 blocks of k -- longest columns first
-            tj = p.tiles_n - 1 - bid / p.tiles_m;
-            ti = bid - (bid / p.tiles_m) * p.tiles_m;
-            return tj >= 0;
-        }
-        if (p.colmajor) {     // few tile rows, many tile columns: walk down the columns, so that the (large) B operand is
-                              // streamed once while the (small) A operand stays in the L2s
-            tj = bid / p.tiles_m;
-            ti = bid - tj * p.tiles_m;
-            if (p.tri_k_lo) ti = p.tiles_m - 1 - ti;
-            return tj < p.tiles_n && (!p.lower_only || tj <= ti);
-        }
-        ti = bid / p.tiles_n;
-        tj = bid - ti * p.tiles_n;
-        if (p.tri_k_lo && ti < p.tiles_m) ti = p.tiles_m - 1 - ti;
-        return ti < p.tiles_m && (!p.lower_only || tj <= ti);
-    }
-    const int xcd = bid & 7, local = bid >> 3;
-    const int s = (local >> 6) * 8 + xcd, w = local & 63;
-    if (s >= p.n_super) return false;
-    int I, J;
     if (tri) {
-        tri_decode(s, I, J);
-    } else {
-        I = s / p.SN;
-        J = s - I * p.SN;
+        tri_decode(bid, ti, tj);
+        return ti < p.tiles_m;
     }
-    ti = I * 8 + (w >> 3);
-    tj = J * 8 + (w & 7);
-    return ti < p.tiles_m && tj < p.tiles_n && (!p.lower_only || tj <= ti);
+    if (p.tri_k_lo_b) {   // B lower triangular in k: column tile tj runs tj + 1 blocks of k -- longest columns first
+        tj = p.tiles_n - 1 - bid / p.tiles_m;
+        ti = bid - (bid / p.tiles_m) * p.tiles_m;
+        return tj >= 0;
+    }
+    ti = bid / p.tiles_n;
+    tj = bid - ti * p.tiles_n;
+    if (p.tri_k_lo && ti < p.tiles_m) ti = p.tiles_m - 1 - ti;
+    return ti < p.tiles_m && (!p.lower_only || tj <= ti);
 }
 
 
@@ -359,14 +315,10 @@ struct Prof {
 };
 Prof g_prof;
 
-int64_t g_small_tile_below = 1024;  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
-int g_tri_pairs_from = INT32_MAX;   // tuning knob (gpk_tune(4, v)): row-pair order from this many tiles
-int g_trib = 1;                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
-int g_trilo_pairs = 1;            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
-int g_split_tail = 1;               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
-int g_swizzle_from = INT32_MAX;     // tuning knob (gpk_tune(2, v)); r01 sweep: the 8x8 XCD supertile order
-                                    // loses 4 % to plain row-major order (ragged supertiles on the diagonal
-                                    // unbalance the XCDs), so it is off unless asked for
+GPK_KNOB(int64_t, g_small_tile_below, 1024);  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
+GPK_KNOB(int, g_trib, 1);                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
+GPK_KNOB(int, g_trilo_pairs, 1);            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
+GPK_KNOB(int, g_split_tail, 1);               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 
 }  // namespace
 
@@ -374,9 +326,7 @@ namespace {
 long long* g_tile_prof = nullptr;       // development aid (gpk_tune_tile_prof)
 int64_t g_tile_prof_only = -1;          // tuning knob (gpk_tune(20, v)): stamp only the v-th persistent launch since the knob was set (-1: every one)
 int64_t g_tile_prof_count = 0;
-int g_colmajor_ratio = INT32_MAX;       // tuning knob (gpk_tune(13, v)): column-major tile order from this many times more tile columns than
-                                        // rows -- OFF: measured 87 vs 64 ms per cfg5 step although it cuts the fabric-side re-reads of K_zx
-int64_t g_persist_small_below = 512;   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
+GPK_KNOB(int64_t, g_persist_small_below, 512);   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
 int g_cu_count[64] = {0};
 int device_cus() {
     int dev = 0;
@@ -394,14 +344,11 @@ void gpk_set_tile_prof(long long* dev_buf) { g_tile_prof = dev_buf; }
 
 // Tuning knobs of this file (gpk_tune in include/gpk.h): A/B runs on the GPU box.
 void gpk_tune_gemm(int key, int64_t value) {
-    if (key == 1) g_small_tile_below = value;
-    if (key == 2) g_swizzle_from = (int)value;
-    if (key == 4) g_tri_pairs_from = (int)value;
-    if (key == 8) g_persist_small_below = value;
-    if (key == 13) g_colmajor_ratio = (int)value;
-    if (key == 31) g_split_tail = (int)value;
-    if (key == 36) g_trib = (int)value;
-    if (key == 42) g_trilo_pairs = (int)value;
+    if (key == 1) GPK_KNOB_SET(g_small_tile_below = value;);
+    if (key == 8) GPK_KNOB_SET(g_persist_small_below = value;);
+    if (key == 31) GPK_KNOB_SET(g_split_tail = (int)value;);
+    if (key == 36) GPK_KNOB_SET(g_trib = (int)value;);
+    if (key == 42) GPK_KNOB_SET(g_trilo_pairs = (int)value;);
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -482,30 +429,11 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.tri_k_lo = (flags & 4) ? 1 : 0;
     g.tri_k_lo_b = (flags & 8) ? 1 : 0;
     g.pair_cols = 0;
-    g.colmajor = 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
                                      : (int64_t)g.tiles_m * g.tiles_n;
-    g.colmajor = (!lower_only && !g.tri_k_lo_b && (int64_t)g.tiles_n >= (int64_t)g_colmajor_ratio * g.tiles_m) ? 1 : 0;
-    int64_t gridx;
-    g.swizzle = (total >= g_swizzle_from) ? 1 : 0;
-    g.n_super = 0;
-    g.tri_pairs = 0;
-    g.SN = 1;
-    if (g.swizzle) {
-        const int SM = (g.tiles_m + 7) / 8;
-        g.SN = (g.tiles_n + 7) / 8;
-        g.n_super = tri ? SM * (SM + 1) / 2 : SM * g.SN;
-        gridx = gpk_cdiv(g.n_super, 8) * 8 * 64;
-    } else {
-        gridx = total;
-        g.tri_pairs = (tri && total >= g_tri_pairs_from) ? 1 : 0;
-        if (g.tri_pairs) {
-            const int64_t P = (g.tiles_m + 1) / 2;
-            gridx = 2 * P * (P + 1);
-        }
-    }
+    int64_t gridx = total;
 
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&
                          (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
@@ -519,7 +447,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     // launched as four 64 x 64 quarter tiles each: they fit one or two rounds of ~0.35 tile times.  Same results (a tile's entries are
     // computed by the same k order whichever kernel body does it).
     g.split_from = INT32_MAX;
-    if (g_split_tail && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && !g.swizzle && !g.tri_pairs && !g.colmajor && (flags & (2 | 4 | 8)) == 0 &&
+    if (g_split_tail && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && (flags & (2 | 4 | 8)) == 0 &&
         (const void*)A != (const void*)C && (const void*)B != (const void*)C) {      // (in-place: one workgroup must own all columns of its rows)
         const int64_t slots = (int64_t)device_cus() * 2;
         const int64_t rem = total % slots;
@@ -534,7 +462,6 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         (const void*)A != (const void*)C && (const void*)B != (const void*)C && gpk_cdiv(M, 64) * gpk_cdiv(N, 64) <= 2 * (int64_t)device_cus()) {
         g.tiles_m = (int)(M / 32);
         g.tiles_n = (int)gpk_cdiv(N, 64);
-        g.colmajor = 0; g.swizzle = 0; g.tri_pairs = 0;
         const bool e2 = !aligned || (N % 64) || (K % BK);
         const dim3 pgrid((unsigned)((g.tiles_m / 2) * g.tiles_n), 1, 1);
         ProfSlot* ps = nullptr;
@@ -724,9 +651,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         g.tiles_m = (int)gpk_cdiv(q.M, ts); g.tiles_n = (int)gpk_cdiv(q.N, ts);
         g.lower_only = q.lower_only ? 1 : 0;
         g.tri_k = g.tri_k_lo = 0;
-        g.colmajor = 0;
         g.tri_k_lo_b = q.tri_b ? 1 : 0;
-        g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1;
         const bool aligned = ((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && (q.lda % VEC == 0) &&
                              (q.ldb % VEC == 0);
         g.vec_ok = aligned ? 1 : 0;
@@ -912,8 +837,8 @@ int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, in
     g.M = (int)m; g.N = GPK_DB; g.K = GPK_DB;
     g.alpha = T(1); g.beta_over_alpha = T(0); g.has_beta = 0;
     g.tiles_m = (int)gpk_cdiv(m, ts); g.tiles_n = 1;
-    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
-    g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
+    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
+    g.split_from = INT32_MAX;
     const bool aligned = ((uintptr_t)P % 16 == 0) && ((uintptr_t)W % 16 == 0) && (ld % VEC == 0);
     g.vec_ok = aligned ? 1 : 0;
     GemmArgs<T>& u = pa.upd;

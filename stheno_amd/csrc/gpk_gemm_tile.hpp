@@ -37,12 +37,7 @@ struct GemmArgs {
     int tri_k_lo;     // A (M x K) is lower triangular (zero for k > row): stop at k = m0 + TS; tile rows run
                       // longest-first (bottom rows first)
     int tri_k_lo_b;   // B (N x K) is lower triangular (zero for k > column index n): stop at k = n0 + tile width
-    int colmajor;     // column-major tile order (rectangular problems with many more tile columns than tile rows)
     int pair_cols;    // persistent kernel, tri_k_lo_b: one task = column tiles c and tiles_n - 1 - c of a tile row
-    int swizzle;
-    int tri_pairs;    // triangular enumeration by row pairs / 8-column chunks (see decode_tile)
-    int n_super;
-    int SN;
     int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
                       // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };
@@ -366,7 +361,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         typedef typename std::conditional<sizeof(T) == 8, double, f32x2>::type frag_t;
         constexpr int KPP = (sizeof(T) == 8) ? 4 : 8;      // k values per phase
         constexpr int NPH = BK / KPP;                       // phases per chunk
-        constexpr int MPP = FRM * FR * (KPP / 4);           // MFMAs per phase and wave
         static_assert(NPH == 4, "four phases per chunk");
         frag_t Fa[2][FRM], Fb[2][FR];
         vec_t qa[NV], qb[NV];

@@ -18,11 +18,11 @@
 
 enum { GPK_K_EQ = 0, GPK_K_MATERN12 = 1, GPK_K_MATERN32 = 2, GPK_K_MATERN52 = 3, GPK_K_LINEAR = 4, GPK_K_CONST = 5 };
 
-int g_kmat_compact = 1;   // tuning knob (gpk_tune(34, v)): 1-D compact grid for the lower triangle of a square matrix
-int g_kmat_band = 1;      // tuning knob (gpk_tune(12, v)): 1 = row-band kernel, 0 = the one-tile-per-workgroup kernel
+GPK_KNOB(int, g_kmat_compact, 1);   // tuning knob (gpk_tune(34, v)): 1-D compact grid for the lower triangle of a square matrix
+GPK_KNOB(int, g_kmat_band, 1);      // tuning knob (gpk_tune(12, v)): 1 = row-band kernel, 0 = the one-tile-per-workgroup kernel
 void gpk_tune_kmat(int key, int64_t value) {
-    if (key == 12) g_kmat_band = (int)value;
-    if (key == 34) g_kmat_compact = (int)value;
+    if (key == 12) GPK_KNOB_SET(g_kmat_band = (int)value;);
+    if (key == 34) GPK_KNOB_SET(g_kmat_compact = (int)value;);
 }
 
 namespace {

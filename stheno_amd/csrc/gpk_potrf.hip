@@ -104,123 +104,6 @@ __device__ __forceinline__ typename Traits<T>::acc_t lds_mm_nn(const T* S, int a
 
 // ---- pieces of the in-LDS factorisation of the 128x128 block (S: [128][LDP]) ----
 
-// 16x16 Cholesky of the micro-block at (c0, c0) by ONE wave: lane lr owns row lr (the four
-// 16-lane groups compute redundantly), pivots and multipliers travel through v_readlane.
-template <typename T>
-__device__ __forceinline__ void micro_chol(T* S, T* rdiag, int c0, int lane, int lr, int* info, int off) {
-    T a[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = S[(c0 + lr) * LDP + c0 + c];
-    // The 16 columns are one dependent chain: nothing but the chain goes inside the loop.  The
-    // non-positive-pivot report and the reciprocal pivots are collected in registers and leave once,
-    // after the loop (16 exec-masked atomics / LDS stores inside it cost ~10 % of the micro-step).
-    int bad = 0;
-    T myr = T(0);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const T d = lane_bcast(a[j], j);
-        bad = (!(d > T(0)) && bad == 0) ? j + 1 : bad;
-        T ljj, rinv;
-        sqrt_rsqrt(d, ljj, rinv);
-        a[j] = (lr == j) ? ljj : a[j] * rinv;
-        myr = (lr == j) ? rinv : myr;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-            const T lcj = lane_bcast(a[j], c);
-            a[c] -= a[j] * lcj;
-        }
-    }
-    if (lane < 16) {
-        rdiag[c0 + lr] = myr;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) S[(c0 + lr) * LDP + c0 + c] = a[c];
-    }
-    if (bad != 0 && lane == 0) atomicCAS(info, 0, off + c0 + bad);
-}
-
-// micro-panel TRSM: one thread per row below the micro-block at (c0, c0); right-looking, so
-// the 15 - j updates after each pivot are independent (dependency chain of 16, not 120)
-template <typename T>
-__device__ __forceinline__ void micro_trsm(T* S, const T* rdiag, int c0, int tid) {
-    const int row = c0 + 16 + tid;
-    if (row < GPK_DB) {
-        // All 120 multipliers of the 16x16 factor, its 16 reciprocal pivots and this thread's row are
-        // fetched from LDS up front (the workgroup owns the CU: 512 VGPRs per lane are there to be used).
-        // Left to itself the compiler interleaves one ds_read with one or two FMAs and pays an LDS latency
-        // ~60 times per micro-step (measured 4k cycles per step, a quarter of the kernel).
-        T l[16][16], rd[16], x[16];
-#pragma unroll
-        for (int c = 1; c < 16; ++c)
-#pragma unroll
-            for (int j = 0; j < c; ++j) l[c][j] = S[(c0 + c) * LDP + c0 + j];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) rd[j] = rdiag[c0 + j];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) x[c] = S[row * LDP + c0 + c];
-        __builtin_amdgcn_sched_barrier(0);     // keep the loads above, the dependent chain below
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            x[j] *= rd[j];
-#pragma unroll
-            for (int c = j + 1; c < 16; ++c) x[c] -= x[j] * l[c][j];
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) S[row * LDP + c0 + c] = x[c];
-    }
-}
-
-// One level of the recursive-doubling inversion, pair size 2H (H = 16, 32, 64), both passes.
-// Each wave owns PER = (128 / 2H) * (H/16)^2 / 4 output tiles and advances them together:
-// per 16-wide k-block all operands are read first, then the 4 * PER MFMAs are issued.
-template <typename T, int H>
-__device__ __forceinline__ void invert_level(T* S, int wave, int lane, int lr, int kq) {
-    typedef typename Traits<T>::acc_t acc_t;
-    constexpr int HB = H / 16, TPP = HB * HB, NPAIR = GPK_DB / (2 * H), PER = NPAIR * TPP / 4;
-    int ti[PER], tj[PER], o[PER];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-        const int item = wave * PER + q;
-        const int t = item % TPP;
-        ti[q] = t / HB;
-        tj[q] = t % HB;
-        o[q] = (item / TPP) * 2 * H;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        acc_t acc[PER];
-#pragma unroll
-        for (int q = 0; q < PER; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = T(0);
-#pragma unroll
-        for (int kb = 0; kb < HB; ++kb) {
-            T av[PER][4], bv[PER][4];
-#pragma unroll
-            for (int q = 0; q < PER; ++q)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 16 * kb + 4 * kk + kq;
-                    if (pass == 0) {   // T = C * Ainv
-                        av[q][kk] = S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + k];
-                        bv[q][kk] = S[(o[q] + k) * LDP + o[q] + 16 * tj[q] + lr];
-                    } else {           // C' = -Dinv * T
-                        av[q][kk] = -S[(o[q] + H + 16 * ti[q] + lr) * LDP + o[q] + H + k];
-                        bv[q][kk] = S[(o[q] + H + k) * LDP + o[q] + 16 * tj[q] + lr];
-                    }
-                }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int q = 0; q < PER; ++q) acc[q] = Traits<T>::mfma(av[q][kk], bv[q][kk], acc[q]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PER; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                S[(o[q] + H + 16 * ti[q] + Traits<T>::crow(lane, i)) * LDP + o[q] + 16 * tj[q] + lr] = acc[q][i];
-        __syncthreads();
-    }
-}
-
 // tile t of an update list after micro-step s: mode 0 = micro-column s+1 (bi = s+1+t),
 // mode 1 = lower triangle of the tiles with s+2 <= bj <= bi <= 7
 __device__ __forceinline__ void tile_of(int mode, int s, int t, int& bi, int& bj) {
@@ -274,186 +157,8 @@ __device__ __forceinline__ void rank16_update(T* S, int c0, int mode, int s, int
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
-    typedef typename Traits<T>::acc_t acc_t;
-    __shared__ __attribute__((aligned(16))) T S[GPK_DB * LDP + GPK_DB];
-    T* rdiag = S + GPK_DB * LDP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, kq = lane >> 4;
-    const int64_t b = blockIdx.x;
-    T* __restrict__ A = p.A + b * p.bstride + p.off * p.ld + p.off;
-    int rem = p.n - (int)p.off;
-    const int nv = rem < GPK_DB ? rem : GPK_DB;
-
-    // ---- phase 0: load the lower triangle; pad with identity ----
-    // All global loads of a thread are issued before the first LDS store (one
-    // latency, not one per element).
-    typedef typename Traits<T>::vec_t vec_t;
-    constexpr int VEC = Traits<T>::VEC;
-    constexpr int CPR = GPK_DB / VEC;              // 16-byte chunks per row
-    constexpr int PER = GPK_DB * CPR / 256;        // chunks per thread
-    const bool vec_io = (nv == GPK_DB) && ((uintptr_t)A % 16 == 0) && (p.ld % VEC == 0);
-    PROF_MARK(0);
-    if (vec_io) {
-        vec_t buf[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
-            const int r = id / CPR, c = (id % CPR) * VEC;
-            if (c <= r) {
-                buf[i] = *reinterpret_cast<const vec_t*>(A + (int64_t)r * p.ld + c);
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) buf[i][v] = T(0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
-            const int r = id / CPR, c = (id % CPR) * VEC;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) S[r * LDP + c + v] = (c + v <= r) ? buf[i][v] : T(0);
-        }
-    } else {
-        for (int base = 0; base < GPK_DB * GPK_DB; base += 256 * 16) {
-            T buf[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = base + tid + 256 * i;
-                const int r = idx >> 7, c = idx & 127;
-                buf[i] = (r < nv && c <= r) ? A[(int64_t)r * p.ld + c] : ((r == c) ? T(1) : T(0));
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int idx = base + tid + 256 * i;
-                S[(idx >> 7) * LDP + (idx & 127)] = buf[i];
-            }
-        }
-    }
-    __syncthreads();
-    PROF_MARK(1);
-
-    // ---- phase 1: factorise, 16-column micro-panels, software-pipelined ----
-    //   (b)_s  micro-TRSM of panel s                       all threads
-    //   (c1)_s rank-16 update of micro-column s+1           all waves
-    //   (a)_{s+1} 16x16 Cholesky of the next micro-block    wave 0   } concurrently
-    //   (c2)_s rank-16 update of the remaining tiles        waves 1-3}
-    long long t_b = 0, t_c1 = 0, t_a = 0, t0 = 0;
-    const bool prof = (p.prof != nullptr && blockIdx.x == 0);
-    if (wave == 0) micro_chol<T>(S, rdiag, 0, lane, lr, p.info + b, (int)p.off + p.info_base);
-    __syncthreads();
-    for (int s = 0; s < 8; ++s) {
-        const int c0 = 16 * s;
-        if (prof) t0 = (long long)__builtin_readcyclecounter();
-        micro_trsm<T>(S, rdiag, c0, tid);
-        __syncthreads();
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); t_b += t1 - t0; t0 = t1; }
-        if (s == 7) break;
-        rank16_update<T>(S, c0, 0, s, 7 - s, wave, 4, lane, lr, kq);
-        __syncthreads();
-        if (prof) { const long long t1 = (long long)__builtin_readcyclecounter(); t_c1 += t1 - t0; t0 = t1; }
-        if (wave == 0)
-            micro_chol<T>(S, rdiag, c0 + 16, lane, lr, p.info + b, (int)p.off + p.info_base);
-        else
-            rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - 1, 3, lane, lr, kq);
-        if (prof && tid == 0) t_a += (long long)__builtin_readcyclecounter() - t0;
-        __syncthreads();
-    }
-    if (prof && tid == 0) {
-        p.prof[(p.off / GPK_DB) * 16 + 8] = t_b;
-        p.prof[(p.off / GPK_DB) * 16 + 9] = t_c1;
-        p.prof[(p.off / GPK_DB) * 16 + 10] = t_a;
-    }
-
-    PROF_MARK(2);
-    // ---- phase 2: write L (lower triangle only; the upper triangle is never touched) ----
-    if (vec_io) {
-        vec_t wbuf[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
-            const int r = id / CPR, c = (id % CPR) * VEC;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) wbuf[i][v] = S[r * LDP + c + v];
-        }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int id = tid + 256 * i;
-            const int r = id / CPR, c = (id % CPR) * VEC;
-            if (c + VEC - 1 <= r) {
-                *reinterpret_cast<vec_t*>(A + (int64_t)r * p.ld + c) = wbuf[i];
-            } else if (c <= r) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    if (c + v <= r) A[(int64_t)r * p.ld + c + v] = wbuf[i][v];
-            }
-        }
-    } else {
-        for (int idx = tid; idx < GPK_DB * GPK_DB; idx += 256) {
-            const int r = idx >> 7, c = idx & 127;
-            if (r < nv && c <= r) A[(int64_t)r * p.ld + c] = S[r * LDP + c];
-        }
-    }
-
-    if (p.dinv == nullptr) return;
-    __syncthreads();   // phase 2 reads of S complete before the in-place inversion
-    PROF_MARK(3);
-
-    // ---- phase 3: invert L in place ----
-    // I. the eight 16x16 diagonal micro-blocks: 16-lane group g of waves 0/1 owns
-    //    micro-block 4*wave + g; lane lr solves for column lr of the inverse.
-    if (wave < 2) {
-        const int c0 = 16 * (4 * wave + kq);
-        T x[16], l[16][16], rd[16];
-#pragma unroll
-        for (int i = 1; i < 16; ++i)
-#pragma unroll
-            for (int k = 0; k < i; ++k) l[i][k] = S[(c0 + i) * LDP + c0 + k];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rd[i] = rdiag[c0 + i];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            T v = (i == lr) ? T(1) : T(0);
-#pragma unroll
-            for (int k = 0; k < i; ++k) v -= l[i][k] * x[k];
-            x[i] = v * rd[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[(c0 + i) * LDP + c0 + lr] = x[i];   // zeros above the diagonal
-    }
-    __syncthreads();
-    PROF_MARK(6);
-    // II. recursive doubling: [A 0; C D]^-1 = [Ai 0; -Di C Ai, Di].
-    invert_level<T, 16>(S, wave, lane, lr, kq);
-    invert_level<T, 32>(S, wave, lane, lr, kq);
-    invert_level<T, 64>(S, wave, lane, lr, kq);
-
-    PROF_MARK(4);
-    // ---- phase 4: write inv(L) (identity-padded, zeros above the diagonal) ----
-    T* __restrict__ W = p.dinv + b * p.dinv_bstride + (p.off / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int id = tid + 256 * i;
-        const int r = id / CPR, c = (id % CPR) * VEC;
-        vec_t w;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) w[v] = S[r * LDP + c + v];
-        *reinterpret_cast<vec_t*>(W + (int64_t)r * GPK_DB + c) = w;
-    }
-    if (p.zero_next) {
-        uint4* z = reinterpret_cast<uint4*>(W + (int64_t)GPK_DB * GPK_DB);
-        z[tid] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    PROF_MARK(5);
-}
-
 // ---------------------------------------------------------------------------
-// potrf_diag3_kernel -- potrf_diag_kernel restructured around what a lone wave per SIMD costs on gfx950 (scripts/dev/mfma_latency.hip:
+// potrf_diag3_kernel -- the diagonal-block kernel, built around what a lone wave per SIMD costs on gfx950 (scripts/dev/mfma_latency.hip:
 // one wave issues an fp64 v_mfma 16x16x4 every ~140 cycles at best -- 46 % of the pipe -- and ~180 on a dependent chain; two waves per
 // SIMD reach the pipe rate between them):
 //  * 512 threads = two waves per SIMD: every MFMA phase (rank-16 updates, the three merge levels of the inverse) gets twice the
@@ -465,7 +170,8 @@ __global__ __launch_bounds__(256, 1) void potrf_diag_kernel(DiagArgs<T> p) {
 //    arithmetic, so that they need no communication) cover the whole micro-panel;
 //  * per micro-step: (U1) all eight waves update micro-column s+1 by column s (one tile each), then the panel waves factorise
 //    micro-panel s+1 WHILE the other waves apply column s to the rest of the trailing tiles (U2).
-// Everything else (load, write-back, in-LDS inversion by recursive doubling) as in potrf_diag_kernel, on eight waves.
+// (The 256-thread kernel of rounds 1-2 -- micro-Cholesky on one wave, separate micro-TRSM, inversion by recursive doubling after the
+// factorisation: 95k cycles per fp64 block against 66.5k -- was removed in round 4; profiles/r03_experiments.md sections 1-3.)
 // ---------------------------------------------------------------------------
 constexpr int D3_THREADS = 512;
 constexpr int D3_WAVES = D3_THREADS / 64;
@@ -1042,8 +748,8 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
     g.M = p.m; g.K = GPK_DB;
     g.tiles_m = R;
-    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
-    g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
+    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
+    g.split_from = INT32_MAX;
     g.vec_ok = p.vec_ok;
     int k = 0;
     const bool fill_first = (int)blockIdx.x > p.panel_wgs;
@@ -1149,14 +855,10 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_pipe_kernel(PipeArgs<T> p
 }
 
 long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
-int g_diag_v2 = 1;                  // tuning knob (gpk_tune(30, v)): 1 = potrf_diag3_kernel (512 threads, panel factorisation), 0 = potrf_diag_kernel
 
 template <typename T>
 void launch_diag(const DiagArgs<T>& d, unsigned batch, hipStream_t stream) {
-    if (g_diag_v2)
-        hipLaunchKernelGGL((potrf_diag3_kernel<T>), dim3(batch), dim3(D3_THREADS), 0, stream, d);
-    else
-        hipLaunchKernelGGL((potrf_diag_kernel<T>), dim3(batch), dim3(256), 0, stream, d);
+    hipLaunchKernelGGL((potrf_diag3_kernel<T>), dim3(batch), dim3(D3_THREADS), 0, stream, d);
 }
 
 template <typename T>
@@ -1235,12 +937,12 @@ int potrf_panel_fused(const PanelCtx<T>& x, int64_t c0, int64_t w) {
     }
     return GPK_OK;
 }
-int g_fused_step = 1;              // tuning knob (gpk_tune(32, v)): single matrices take potrf_panel_fused
+GPK_KNOB(int, g_fused_step, 1);              // tuning knob (gpk_tune(32, v)): single matrices take potrf_panel_fused
 
-int g_pipe = 1;                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
+GPK_KNOB(int, g_pipe, 1);                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
 int g_pipe_cus = 0;                // CUs of the current device (queried once)
-int g_pipe_fill = 1;               // tuning knob (gpk_tune(38, v)): the trailing update right of the NEXT panel rides along in that panel's launch
-int g_pipe_panel_wgs = 0;          // tuning knob (gpk_tune(39, v)): workgroups that take panel tasks first when a launch carries fill tiles (0: a third of the CUs)
+GPK_KNOB(int, g_pipe_fill, 1);               // tuning knob (gpk_tune(38, v)): the trailing update right of the NEXT panel rides along in that panel's launch
+GPK_KNOB(int, g_pipe_panel_wgs, 0);          // tuning knob (gpk_tune(39, v)): workgroups that take panel tasks first when a launch carries fill tiles (0: a third of the CUs)
 
 // The same panel in ONE launch (potrf_pipe_kernel) -- plus a memset of its control words and, when the panel reaches the last row of
 // the matrix, the diagonal-block kernel for the last block (the control words live in the `dinv` slot of the first diagonal block
@@ -1312,8 +1014,8 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
         g.M = (int)mf; g.N = (int)mf; g.K = (int)fill_k;
         g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
         g.tiles_m = (int)gpk_cdiv(mf, 128); g.tiles_n = g.tiles_m;
-        g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.colmajor = 0; g.pair_cols = 0;
-        g.swizzle = 0; g.tri_pairs = 0; g.n_super = 0; g.SN = 1; g.split_from = INT32_MAX;
+        g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
+        g.split_from = INT32_MAX;
         g.vec_ok = aligned ? 1 : 0;
         fill_edge = !aligned || (mf % 128) || (fill_k % Traits<T>::BK);
         pa.fill_tiles = g.tiles_m * (g.tiles_m + 1) / 2;
@@ -1351,7 +1053,7 @@ __global__ void wait_word_kernel(unsigned* word, unsigned value) {
 
 template <typename T>
 int potrf_panel_any(const PanelCtx<T>& x, int64_t c0, int64_t w) {
-    if (g_pipe && g_diag_v2 && x.batch == 1 && x.dinv != nullptr && x.n - c0 > GPK_DB) {
+    if (g_pipe && x.batch == 1 && x.dinv != nullptr && x.n - c0 > GPK_DB) {
         bool done = false;
         const int st = potrf_panel_pipe<T>(x, c0, w, &done);
         if (st || done) return st;
@@ -1391,7 +1093,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     // previous panel's rank-nbo update are its own columns.  So that update is split: the strip of the next panel's columns is a
     // GEMM launch of its own, the rest (the lower triangle right of the next panel) rides along in the next panel's launch as fill
     // tiles for its idle workers (N = 8192: 5.76 -> 5.4 ms; the last 6144 columns of N = 16384: 3.4 -> 2.9 ms).
-    const bool ride = g_pipe && g_pipe_fill && g_diag_v2 && batch == 1 && dinv != nullptr;
+    const bool ride = g_pipe && g_pipe_fill && batch == 1 && dinv != nullptr;
     int64_t owed = 0;      // width of the previous panel whose update is still owed to the columns from k0 on (0: nothing owed)
     for (int64_t k0 = 0; k0 < n; k0 += nbo) {
         const int64_t k1 = (k0 + nbo < n) ? k0 + nbo : n;
@@ -1464,15 +1166,15 @@ struct LaDevice {
 };
 std::mutex g_la_mutex;
 LaDevice g_la_dev[64];
-int64_t g_la_min_rows = 2048;     // tuning knob (gpk_tune(6, v)): overlap while the trailing matrix has >= this many rows
-int64_t g_la_tail_rows = 0;       // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path;
+GPK_KNOB(int64_t, g_la_min_rows, 2048);     // tuning knob (gpk_tune(6, v)): overlap while the trailing matrix has >= this many rows
+GPK_KNOB(int64_t, g_la_tail_rows, 0);       // tuning knob (gpk_tune(9, v)): the last this-many rows (and matrices up to this order) take the plain path;
                                   // 0 = 6144 (with the pipelined plain panels: fp64 N = 16384 26.6 ms at 6144, 27.6 at 4096, 27.0 at 8192; fp32 nb = 512 N = 16384 15.5 / 15.7)
-int g_la_ps_mode = 0;             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
-int g_la_strip_last = 1;          // tuning knob (gpk_tune(11, v))
-int g_la_rejoin = 1;              // tuning knob (gpk_tune(18, v)): reserved CUs rejoin the trailing update after the chain
-int g_la_mode = 1;                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
-int64_t g_la_fuse_diag_rows = 9216;   // tuning knob (gpk_tune(40, v)): the update of the next diagonal block rides in the trailing update while that has >= this many rows (0: never)
-int g_la_fuse_diag_nb = 512;          // tuning knob (gpk_tune(41, v)): ... and only for outer blocks up to this width
+GPK_KNOB(int, g_la_ps_mode, 0);             // tuning knob (gpk_tune(10, v)): panel GEMM as 0 = plain launch, 1 = persistent, 2 = persistent with paired column tiles
+GPK_KNOB(int, g_la_strip_last, 1);          // tuning knob (gpk_tune(11, v))
+GPK_KNOB(int, g_la_rejoin, 1);              // tuning knob (gpk_tune(18, v)): reserved CUs rejoin the trailing update after the chain
+GPK_KNOB(int, g_la_mode, 1);                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
+GPK_KNOB(int64_t, g_la_fuse_diag_rows, 9216);   // tuning knob (gpk_tune(40, v)): the update of the next diagonal block rides in the trailing update while that has >= this many rows (0: never)
+GPK_KNOB(int, g_la_fuse_diag_nb, 512);          // tuning knob (gpk_tune(41, v)): ... and only for outer blocks up to this width
 
 LaDevice* la_device() {
     int dev = 0;
@@ -1530,19 +1232,18 @@ void gpk_potrf_shutdown() {
 }
 
 void gpk_tune_potrf(int key, int64_t value) {
-    if (key == 6) g_la_min_rows = value;
-    if (key == 7) g_la_mode = (int)value;
-    if (key == 9) g_la_tail_rows = value;
-    if (key == 10) g_la_ps_mode = (int)value;
-    if (key == 18) g_la_rejoin = (int)value;
-    if (key == 11) g_la_strip_last = (int)value;
-    if (key == 30) g_diag_v2 = (int)value;
-    if (key == 32) g_fused_step = (int)value;
-    if (key == 37) g_pipe = (int)value;
-    if (key == 40) g_la_fuse_diag_rows = value;
-    if (key == 41) g_la_fuse_diag_nb = (int)value;
-    if (key == 38) g_pipe_fill = (int)value;
-    if (key == 39) g_pipe_panel_wgs = (int)value;
+    if (key == 6) GPK_KNOB_SET(g_la_min_rows = value;);
+    if (key == 7) GPK_KNOB_SET(g_la_mode = (int)value;);
+    if (key == 9) GPK_KNOB_SET(g_la_tail_rows = value;);
+    if (key == 10) GPK_KNOB_SET(g_la_ps_mode = (int)value;);
+    if (key == 18) GPK_KNOB_SET(g_la_rejoin = (int)value;);
+    if (key == 11) GPK_KNOB_SET(g_la_strip_last = (int)value;);
+    if (key == 32) GPK_KNOB_SET(g_fused_step = (int)value;);
+    if (key == 37) GPK_KNOB_SET(g_pipe = (int)value;);
+    if (key == 40) GPK_KNOB_SET(g_la_fuse_diag_rows = value;);
+    if (key == 41) GPK_KNOB_SET(g_la_fuse_diag_nb = (int)value;);
+    if (key == 38) GPK_KNOB_SET(g_pipe_fill = (int)value;);
+    if (key == 39) GPK_KNOB_SET(g_pipe_panel_wgs = (int)value;);
 }
 
 #define GPK_LA_PAD 16
@@ -1659,7 +1360,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         // (measured: fp32 N = 32768 with 512-blocks, 60 steps: cfg3 127.8 -> 127.0 ms; fp64 N = 16384 with 1024-blocks, 10 steps whose
         // 36 diagonal tiles take ~300 us as 128-tiles of the persistent kernel against 46 us as a launch of 64-tiles: 26.7 -> 26.8 ms.
         // So: blocks up to 512 only.)
-        const bool fuse_diag = overlap && nb <= g_la_fuse_diag_nb && g_la_fuse_diag_rows > 0 && (n - k2) >= g_la_fuse_diag_rows && g_pipe && g_diag_v2 &&
+        const bool fuse_diag = overlap && nb <= g_la_fuse_diag_nb && g_la_fuse_diag_rows > 0 && (n - k2) >= g_la_fuse_diag_rows && g_pipe &&
                                (k2 - k1) > GPK_DB;
         if (!fuse_diag) {
             st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, nb, T(-1), P1, ld, 0, P1, ld, 0, T(1),

@@ -17,9 +17,9 @@
 // so every update is an MFMA GEMM with K = SB, not a rank-128 one.
 #include "gpk_common.hpp"
 
-int g_trsv_batched = 1;      // tuning knob (gpk_tune(17, v)): one-workgroup-per-matrix TRSV for batches of small factors
+GPK_KNOB(int, g_trsv_batched, 1);      // tuning knob (gpk_tune(17, v)): one-workgroup-per-matrix TRSV for batches of small factors
 void gpk_tune_solve(int key, int64_t value) {
-    if (key == 17) g_trsv_batched = (int)value;
+    if (key == 17) GPK_KNOB_SET(g_trsv_batched = (int)value;);
 }
 
 namespace {

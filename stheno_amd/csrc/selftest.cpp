@@ -1481,15 +1481,9 @@ static void cumask_experiment() {
             hipStream_t st;
             if (hipExtStreamCreateWithCUMask(&st, 8, w) == hipSuccess) {
                 time_gemm(st, m.nm);
-                gpk_tune(2, 1 << 30);
-                time_gemm(st, (std::string(m.nm) + " noswz").c_str());
-                gpk_tune(2, 1024);
                 hipStreamDestroy(st);
             }
         }
-        gpk_tune(2, 1 << 30);
-        time_gemm(s_def, "default noswz");
-        gpk_tune(2, 1024);
     }
     overlap(s_def, "default");
     if (e1 == hipSuccess) overlap(s_m8, "mask-8");
@@ -1551,7 +1545,7 @@ static void diag_phase_profile(int n, int ver, int pipe = 0) {
     const int nblk = (n + 127) / 128;
     Dev<long long> prof((size_t)nblk * 32);
     prof.zero();
-    gpk_tune(30, ver);
+    (void)ver;
     gpk_tune(37, pipe);
     gpk_tune_diag_prof(prof.p);
     profile_one<T>(n, 0, 1);
@@ -1760,12 +1754,6 @@ int main(int argc, char** argv) {
         gpk_tune(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
         test_gemm<double>(); test_gemm<float>();
         gpk_tune(1, 1024);              // library default
-        gpk_tune(2, 64);                // the (default-off) XCD super-tile order
-        test_gemm<double>(); test_gemm<float>();
-        gpk_tune(2, (int64_t)1 << 30);
-        gpk_tune(4, 1);                 // the (default-off) row-pair triangular order
-        test_gemm<double>(); test_gemm<float>();
-        gpk_tune(4, (int64_t)1 << 30);
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_lookahead<double>(); test_lookahead<float>();

@@ -20,8 +20,9 @@ same numbers).  Takes a few minutes and ~6 GB on 8 cores.  Re-run:
 
     python tests/golden/make_golden_fullsize.py [cfg2] [cfg3] [cfg5]
 
-cfg3: ~17 GB (the kernel matrix is built in row blocks by the oracle's own ``kernel_matrix`` so that its N x N
-temporaries stay small, then ``np.linalg.cholesky``), cfg5: ~35 GB peak (``oracle.pseudo_obs`` as is).
+cfg3: ~10 GB (the kernel matrix is built in row blocks by the oracle's own ``kernel_matrix`` so that its N x N
+temporaries stay small, then factorised in place block by block, see ``cholesky_blocked``), cfg5: ~35 GB peak
+(``oracle.pseudo_obs`` as is).
 """
 import hashlib
 import json
@@ -58,7 +59,43 @@ def kernel_matrix_blocked(terms, x, rows=2048):
     return k
 
 
+def cholesky_blocked(k, nb=4096):
+    """Lower Cholesky factor of ``k`` IN PLACE, as LAPACK's own blocked right-looking algorithm spelt out on ``nb``-blocks with the
+    oracle's calls: ``np.linalg.cholesky`` (potrf) on the diagonal block, ``scipy.linalg.solve_triangular`` (trsm) for the rows
+    below, ``@`` (gemm) for the trailing update.  Why not ``np.linalg.cholesky(k)`` as ``oracle.cholesky`` does: at N = 32768 the
+    OpenBLAS bundled with this NumPy segfaults inside its parallel potrf on the 8-core build container (twice, same address --
+    ``dmesg``: libscipy_openblas64); at the orders it survives, the two agree to round-off (checked below at N = 6000)."""
+    import scipy.linalg as sla
+
+    n = k.shape[0]
+    for j in range(0, n, nb):
+        je = min(j + nb, n)
+        k[j:je, j:je] = np.linalg.cholesky(k[j:je, j:je])
+        if je < n:
+            k[je:, j:je] = sla.solve_triangular(k[j:je, j:je], k[je:, j:je].T, lower=True, check_finite=False).T
+            for i in range(je, n, nb):          # lower block triangle of the trailing matrix, one block row at a time
+                ie = min(i + nb, n)
+                k[i:ie, je:ie] -= k[i:ie, j:je] @ k[je:ie, j:je].T
+    for j in range(0, n, nb):                   # zeros above the diagonal (np.linalg.cholesky's convention)
+        je = min(j + nb, n)
+        k[j:je, je:] = 0.0
+    return k
+
+
+def _check_blocked_cholesky():
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((6000, 4))
+    a = O.kernel_matrix([("eq", 1.0, 1.0), ("linear", 1.0, 1.0)], x)
+    a[np.diag_indices_from(a)] += NOISE
+    ref = np.linalg.cholesky(a)
+    got = cholesky_blocked(a.copy(), nb=1024)
+    err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+    assert err < 1e-13, err
+    return err
+
+
 def cfg3():
+    print("blocked Cholesky vs np.linalg.cholesky at N = 6000: %.2e" % _check_blocked_cholesky(), flush=True)
     w, t = make_inputs("sum_f32", torch.device("cpu"))
     assert t["x"].dtype == torch.float32 and t["x"].shape == (32768, 4)
     x, y, xs = (t[k].double().numpy() for k in ("x", "y", "xs"))      # the fp32-rounded numbers, in fp64
@@ -69,8 +106,9 @@ def cfg3():
     d = np.diag_indices_from(k)
     k[d] += NOISE                     # fdd.py:79
     k[d] += eps                       # B.reg (same order of additions as oracle.reg)
-    chol = np.linalg.cholesky(k)      # = O.cholesky without the N x N identity temporary
+    chol = cholesky_blocked(k)        # (= O.cholesky: see cholesky_blocked for why not in one LAPACK call)
     del k
+    print("factorised after %.0f s" % (time.perf_counter() - t0), flush=True)
     logdet = O.logdet_chol(chol)
     quad = float(O.iqf_diag(chol, y)[0])
     lp = -(logdet + x.shape[0] * O.LOG_2_PI + quad) / 2
