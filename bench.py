@@ -187,9 +187,21 @@ def _host_threads():
         return os.cpu_count() or 1
 
 
-def cpu_baseline(name):
+def _full_size_cpu_record(name):
+    """The one-off FULL-SIZE run of the CPU baseline (``bench.py --cpu-baseline-full``, committed under ``profiles/``): printed
+    beside the bounded sample's extrapolation so that the extrapolation can be judged."""
+    for rnd in ("r04",):
+        path = os.path.join(ROOT, "profiles", "%s_cpu_baseline_full_%s.json" % (rnd, name))
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f)
+    return None
+
+
+def cpu_baseline(name, full=False):
     """The oracle (NumPy/SciPy restatement of Stheno's NumPy path) on the host cores, on a bounded sample of
-    the same workload (stated in ``sample``); the same op sequence as the GPU step, one shared factorisation."""
+    the same workload (stated in ``sample``); the same op sequence as the GPU step, one shared factorisation.
+    ``full``: the dense workloads at their full N instead (minutes; development / one-off record)."""
     from oracle import gp_oracle as O
 
     w = WORKLOADS[name]
@@ -197,7 +209,7 @@ def cpu_baseline(name):
     np_dt = np.float64 if w["dtype"] == "f64" else np.float32
     eps = 1e-12 if w["dtype"] == "f64" else 1e-6
     if name in ("dense_f64", "sum_f32"):
-        n_s = 8192
+        n_s = w["n"] if full else 8192
         terms = [("eq", 1.0, 1.0)] if name == "dense_f64" else [("eq", 1.0, 1.0), ("linear", 1.0, 1.0)]
         x, y = rng.standard_normal((n_s, w["d"])).astype(np_dt), rng.standard_normal((n_s, 1)).astype(np_dt)
         xs = rng.standard_normal((w["ns"], w["d"])).astype(np_dt)
@@ -214,11 +226,19 @@ def cpu_baseline(name):
         # the kernel-matrix build and the solves against N* scale with N^2, the factorisation with N^3
         r = w["n"] / n_s
         t_fac = dt - t_k
-        full = t_k * r * r + t_fac * r ** 3
-        return {"value": 1.0 / full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
-                "sample": f"oracle/gp_oracle.py (NumPy/SciPy, {w['dtype']}) at N={n_s}, D={w['d']}, N*={w['ns']}: {dt:.2f} s per eval "
-                          f"measured ({t_k:.2f} s of it the N^2 kernel-matrix build); extrapolated to N={w['n']} with the build "
-                          f"scaled by (N/{n_s})^2 and the rest by (N/{n_s})^3"}
+        if full:
+            return {"value": 1.0 / dt, "unit": "evals/s", "cores": _host_threads(), "kind": "port", "seconds_per_eval": dt,
+                    "sample": f"oracle/gp_oracle.py (NumPy/SciPy, {w['dtype']}) at the FULL N={n_s}, D={w['d']}, N*={w['ns']}: {dt:.2f} s per "
+                              f"eval measured ({t_k:.2f} s of it the kernel-matrix build); no extrapolation"}
+        t_full = t_k * r * r + t_fac * r ** 3
+        out = {"value": 1.0 / t_full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
+               "sample": f"oracle/gp_oracle.py (NumPy/SciPy, {w['dtype']}) at N={n_s}, D={w['d']}, N*={w['ns']}: {dt:.2f} s per eval "
+                         f"measured ({t_k:.2f} s of it the N^2 kernel-matrix build); extrapolated to N={w['n']} with the build "
+                         f"scaled by (N/{n_s})^2 and the rest by (N/{n_s})^3"}
+        rec = _full_size_cpu_record(name)
+        if rec is not None:
+            out["full_size_measured"] = {k: rec[k] for k in ("value", "unit", "cores", "seconds_per_eval", "sample") if k in rec}
+        return out
     if name == "batched_f32":
         n_g = 4
         x = rng.standard_normal((n_g, w["n"], w["d"])).astype(np_dt)
@@ -364,11 +384,16 @@ def main():
     ap.add_argument("--workload", default="dense_f64", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override N (development only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="ONLY time the CPU baseline of a dense workload at its full N (minutes of host time, no GPU) and print it as JSON")
     ap.add_argument("--no-batched-record", action="store_true", help="skip the `batched` sub-record (configs[3] sharded over the ranks)")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="GPU-less proof of the N-rank path: gloo, a stand-in step, the same launch / barrier / all-gather / JSON code")
     args = ap.parse_args()
 
+    if args.cpu_baseline_full:
+        print(json.dumps(cpu_baseline(args.workload, full=True)), flush=True)
+        return
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
     if args.gpus > 1 and not launched:
         raise SystemExit(_relaunch_under_torchrun(args.gpus, sys.argv[1:]))

@@ -661,7 +661,7 @@ __device__ __forceinline__ bool pipe_poll(unsigned* w, bool mine, unsigned want,
         if (__all(ok)) return true;
         __builtin_amdgcn_s_sleep(2);
         if ((++it & 255u) == 0) {
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;      // (reported by pipe_wait's caller)
             if (it > PIPE_SPIN_LIMIT) {
                 __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
@@ -737,7 +737,7 @@ __device__ __forceinline__ void pipe_chain(const PipeArgs<T>& p, T* __restrict__
 }
 
 template <typename T, bool EDGE>
-__device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, int* s_ctl) {
+__device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, int* s_ctl, int role) {
     const int tid = threadIdx.x;
     const int npb = p.sh.npb, R = p.sh.R;
     unsigned* abort_word = p.ctrl + 1;
@@ -752,7 +752,7 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     g.split_from = INT32_MAX;
     g.vec_ok = p.vec_ok;
     int k = 0;
-    const bool fill_first = (int)blockIdx.x > p.panel_wgs;
+    const bool fill_first = role > p.panel_wgs;
     bool fill_left = p.fill_tiles > 0, panel_left = true;
     for (;;) {
         if (fill_left && (fill_first || !panel_left)) {
@@ -850,8 +850,16 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_pipe_kernel(PipeArgs<T> p
     static_assert(sizeof(T) * D3_LDS_ELEMS >= 2 * 5 * op_bytes(GPK_PIPE_FINE) && sizeof(T) * D3_LDS_ELEMS >= 2 * 3 * op_bytes(GPK_PIPE_STRIP) &&
                       sizeof(T) * D3_LDS_ELEMS >= 2 * 2 * op_bytes(128),
                   "the worker's operand tiles live in the chain's block");
-    if (blockIdx.x == 0) pipe_chain<T>(p, S, s_ctl);
-    else pipe_worker<T, EDGE>(p, reinterpret_cast<char*>(S), s_ctl);
+    // Roles by ARRIVAL, not by block index: the first workgroup that gets to run takes the chain, so the chain is
+    // resident whenever any worker is -- whatever part of the grid the dispatcher has placed, in whatever order.
+    if (threadIdx.x == 0) s_ctl[1] = (int)__hip_atomic_fetch_add(p.ctrl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int role = s_ctl[1];
+    __syncthreads();
+    if (role == 0) pipe_chain<T>(p, S, s_ctl);
+    else pipe_worker<T, EDGE>(p, reinterpret_cast<char*>(S), s_ctl, role);
+    // whoever leaves after an abort reports it (the chain may have finished its blocks and gone before a worker gave up)
+    if (threadIdx.x == 0 && __hip_atomic_load(p.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(p.info, -1);
 }
 
 long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof

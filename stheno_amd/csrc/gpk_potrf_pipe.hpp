@@ -32,7 +32,7 @@
 
 #define GPK_PIPE_MAX_BLOCKS 64        // npb <= this
 #define GPK_PIPE_MAX_SEGS (3 * GPK_PIPE_MAX_BLOCKS + 2)
-#define GPK_PIPE_CTRL_HEAD 96         // control words before the progress arrays: [0] task counter, [1] abort, [16 + j] inverse of block j published
+#define GPK_PIPE_CTRL_HEAD 96         // control words before the progress arrays: [0] task counter, [1] abort, [2] fill-tile counter, [3] role ticket (first workgroup to arrive = the chain), [16 + j] inverse of block j published
 #define GPK_PIPE_STRIP 64
 #define GPK_PIPE_FINE 32
 
