@@ -11,7 +11,7 @@ import csv, glob, json, os, subprocess, sys
 
 workload, out_path = sys.argv[1], sys.argv[2]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = [sys.executable, os.path.join(repo, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+cmd = [sys.executable, os.path.join(repo, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-batched-record"]
 
 
 def one_pass(counter):

@@ -250,7 +250,9 @@ def test_pipelined_panel_against_lapack_and_the_two_launch_path(dtype, n, nbo):
         dinv, info = be.potrf_(m, nbo)
         torch.cuda.synchronize()
         if not pipelined:
-            assert rel(torch.tril(m[1]), torch.tril(m[0])) == 0.0 and int(info[0]) == int(info[1])
+            assert int(info[0]) == int(info[1])
+            if int(info[0]) == 0:       # (a failed factorisation leaves NaNs behind the bad pivot)
+                assert rel(torch.tril(m[1]), torch.tril(m[0])) == 0.0
             m, dinv = m[0], dinv[0]
         return torch.tril(m), dinv, int(info.max())
 
