@@ -169,6 +169,19 @@ int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_
              const void* a, int64_t lda, int64_t sa, const void* b, int64_t ldb, int64_t sb, double beta,
              void* c, int64_t ldc, int64_t sc, int64_t batch, int flags, void* stream);
 
+/* The same contraction with a column scaling and column statistics folded into the store (unbatched, beta = 0, no GPK_GEMM_LOWER):
+ *   c[m][n] = alpha * sum_k a(m,k) b(n,k) * colscale[n]          (colscale NULL: no scaling)
+ *   colss[r][n] = sum over the 64 rows of slab r of (alpha * sum_k a(m,k) b(n,k))^2      (colss NULL: not computed)
+ * colss: gpk_gemm_colss_rows(m) rows of ldss >= n elements; the column sums of squares of the UNSCALED product are the sums of its
+ * rows.  What SURVEY 8(b) proposed as `gpk_syrk_scaled`, cut where the pseudo-point path needs it: V = L_z^{-1} K_zx leaves the
+ * kernel as V K_n^{-1/2}, and Q_x_diag = column sums of squares of V (`B.matmul_diag`) is a by-product -- the stand-alone scaling
+ * and reduction passes over the M x N matrix are gone.  Replaces `B.solve` + `B.matmul_diag` + the K_n^{-1/2} scalings at
+ * stheno/model/observations.py:301, 305, 322, 327. */
+int64_t gpk_gemm_colss_rows(int64_t m);
+int gpk_gemm_colscale(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
+                      const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, int flags,
+                      const void* colscale, void* colss, int64_t ldss, void* stream);
+
 /* Up to two rank-k updates in ONE persistent launch (a resident set of workgroups pulls 128x128 tiles of
  * both problems from a device-side counter: one ramp, one tail):
  *   c[m][n] = cin[m][n] + alpha * sum_k a[m][k] b[n][k]        a: m x k, b: n x k, both row-major

@@ -132,6 +132,16 @@ int gpk_gemm(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_
                                  (hipStream_t)stream));
 }
 
+int64_t gpk_gemm_colss_rows(int64_t m) { return 2 * gpk_cdiv(m, GPK_TILE); }
+
+int gpk_gemm_colscale(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t n, int64_t k, double alpha,
+                      const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, int flags,
+                      const void* colscale, void* colss, int64_t ldss, void* stream) {
+    if (colss != nullptr && ldss < n) return GPK_ERR_ARG(17);
+    D1(dtype, gpk_gemm_launch2<T>(a_kmajor != 0, b_kmajor != 0, m, n, k, (T)alpha, (const T*)a, lda, 0, 0, (const T*)b, ldb, 0, 0,
+                                  (T)0, (T*)c, ldc, 0, 0, 1, 1, flags, (hipStream_t)stream, (const T*)colscale, (T*)colss, ldss));
+}
+
 int gpk_logdet_chol(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, int64_t batch,
                     void* out, void* stream) {
     D1(dtype, gpk_logdet_launch<T>((const T*)l, n, ld, sl, batch, (T*)out, (hipStream_t)stream));

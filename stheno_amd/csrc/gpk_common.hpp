@@ -111,7 +111,8 @@ template <typename T>
 int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                      const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
-                     int64_t batch, int64_t batch2, int flags, hipStream_t stream);
+                     int64_t batch, int64_t batch2, int flags, hipStream_t stream,
+                     const T* colscale = nullptr, T* colss = nullptr, int64_t ldss = 0);     // fused column scaling / sums of squares (gpk_gemm_colscale)
 
 // Persistent two-problem update (see gemm_persist_kernel in gpk_gemm.hip): each segment is
 //   C[m][n] = Cin[m][n] + alpha * sum_k A[m][k] B[n][k]     (A: M x K, B: N x K, both k contiguous)

@@ -385,8 +385,11 @@ template <typename T>
 int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                      const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
-                     int64_t batch, int64_t batch2, int flags, hipStream_t stream) {
+                     int64_t batch, int64_t batch2, int flags, hipStream_t stream, const T* colscale, T* colss, int64_t ldss) {
     const bool lower_only = (flags & 1) != 0;
+    const bool fused_cols = colscale != nullptr || colss != nullptr;      // (gpk_gemm_colscale: the 128-tile kernels' epilogue)
+    if (fused_cols && (batch != 1 || batch2 != 1 || lower_only || (const void*)A == (const void*)C || (const void*)B == (const void*)C))
+        return GPK_ERR_ARG(17);
     if (M <= 0 || N <= 0 || batch <= 0 || batch2 <= 0) return GPK_OK;
     if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || batch > 65535 || batch2 > 65535)
         return GPK_ERR_ARG(3);
@@ -409,7 +412,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     {
         const int64_t tm = gpk_cdiv(M, 128), tn = gpk_cdiv(N, 128);
         const int64_t t128 = (lower_only && tm == tn ? tm * (tm + 1) / 2 : tm * tn) * batch * batch2;
-        if (t128 < g_small_tile_below) ts = 64;
+        if (t128 < g_small_tile_below && !fused_cols) ts = 64;
         // In-place use (C aliases the A operand: the panel TRSM  P <- P inv(L_cc)^T  of the Cholesky):
         // every workgroup reads the full K range of its rows of A and then overwrites a column slice
         // of them, so ONE workgroup must own all N columns of a row tile -- with two column tiles a
@@ -447,7 +450,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     // launched as four 64 x 64 quarter tiles each: they fit one or two rounds of ~0.35 tile times.  Same results (a tile's entries are
     // computed by the same k order whichever kernel body does it).
     g.split_from = INT32_MAX;
-    if (g_split_tail && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && (flags & (2 | 4 | 8)) == 0 &&
+    g.colscale = colscale; g.colss = colss; g.ldss = ldss;
+    if (g_split_tail && !fused_cols && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && (flags & (2 | 4 | 8)) == 0 &&
         (const void*)A != (const void*)C && (const void*)B != (const void*)C) {      // (in-place: one workgroup must own all columns of its rows)
         const int64_t slots = (int64_t)device_cus() * 2;
         const int64_t rem = total % slots;
@@ -521,7 +525,7 @@ int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T
                     T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, int flags,
                     hipStream_t stream) {
     return gpk_gemm_launch2<T>(a_kmaj, b_kmaj, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C,
-                               ldc, sC, 0, batch, 1, flags, stream);
+                               ldc, sC, 0, batch, 1, flags, stream, nullptr, nullptr, 0);
 }
 
 // ---- the library's helper stream: confined (CU mask) to one CU per XCD, whose identities the persistent
@@ -651,6 +655,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         g.tiles_m = (int)gpk_cdiv(q.M, ts); g.tiles_n = (int)gpk_cdiv(q.N, ts);
         g.lower_only = q.lower_only ? 1 : 0;
         g.tri_k = g.tri_k_lo = 0;
+        g.colscale = nullptr; g.colss = nullptr; g.ldss = 0;
         g.tri_k_lo_b = q.tri_b ? 1 : 0;
         const bool aligned = ((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && (q.lda % VEC == 0) &&
                              (q.ldb % VEC == 0);
@@ -839,6 +844,7 @@ int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, in
     g.tiles_m = (int)gpk_cdiv(m, ts); g.tiles_n = 1;
     g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
     g.split_from = INT32_MAX;
+    g.colscale = nullptr; g.colss = nullptr; g.ldss = 0;
     const bool aligned = ((uintptr_t)P % 16 == 0) && ((uintptr_t)W % 16 == 0) && (ld % VEC == 0);
     g.vec_ok = aligned ? 1 : 0;
     GemmArgs<T>& u = pa.upd;
@@ -877,7 +883,7 @@ template int gpk_panel_step_launch<float>(float*, int64_t, int64_t, int64_t, con
 #define GPK_INST(T)                                                                                  \
     template int gpk_gemm_launch2<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,    \
                                      int64_t, int64_t, const T*, int64_t, int64_t, int64_t, T, T*,   \
-                                     int64_t, int64_t, int64_t, int64_t, int64_t, int, hipStream_t); \
+                                     int64_t, int64_t, int64_t, int64_t, int64_t, int, hipStream_t, const T*, T*, int64_t); \
     template int gpk_gemm_launch<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,     \
                                     int64_t, const T*, int64_t, int64_t, T, T*, int64_t, int64_t,    \
                                     int64_t, int, hipStream_t);                                      \

@@ -38,6 +38,9 @@ struct GemmArgs {
                       // longest-first (bottom rows first)
     int tri_k_lo_b;   // B (N x K) is lower triangular (zero for k > column index n): stop at k = n0 + tile width
     int pair_cols;    // persistent kernel, tri_k_lo_b: one task = column tiles c and tiles_n - 1 - c of a tile row
+    const T* colscale;   // (128-tile kernels, optional) C[m][n] = alpha * sum * colscale[n]: a column scaling folded into the store
+    T* colss;            // (optional) column sums of squares of the UNSCALED alpha * sum over each wave's 64 rows: row 2 ti + wm of a
+    int64_t ldss;        //   [2 tiles_m][ldss] buffer (the caller adds the rows up) -- the pseudo-point path's Q_x_diag without a pass over V
     int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
                       // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };
@@ -562,6 +565,37 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         prof[5] = (long long)__builtin_readcyclecounter();
     }
     // (in-place use: every global read of this workgroup's rows of A happened above)
+    // Fused column statistics / scaling (round 4; `gpk_gemm_colscale`, what SURVEY 8(b) called gpk_syrk_scaled, split where the path
+    // needs it): V = L_z^{-1} K_zx leaves this kernel already multiplied by K_n^{-1/2} per column, and the column sums of squares of the
+    // unscaled V (`B.matmul_diag`, observations.py:305) are written per 64-row slab on the way -- the stand-alone scaling pass and the
+    // reduction pass over the 3.3 GB of V are gone.  Rows beyond M of a ragged tile hold zeros (their A rows were loaded as zeros).
+    if constexpr (TS == 128 && NCT == 1 && NW == 4 && !TRIB) {
+        if (p.colscale != nullptr || p.colss != nullptr) {
+#pragma unroll
+            for (int fj = 0; fj < FR; ++fj) {
+                const int col = n0 + wn * WT + fj * 16 + lr;
+                const bool cvalid = !EDGE || col < p.N;
+                T ss = T(0);
+#pragma unroll
+                for (int fi = 0; fi < FRM; ++fi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const T v = p.alpha * acc[0][fi][fj][i];
+                        ss += v * v;
+                    }
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                if (p.colss != nullptr && kq == 0 && cvalid) p.colss[(int64_t)(2 * ti + wm) * p.ldss + col] = ss;
+                if (p.colscale != nullptr) {
+                    const T sc = cvalid ? p.colscale[col] : T(1);
+#pragma unroll
+                    for (int fi = 0; fi < FRM; ++fi)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[0][fi][fj][i] *= sc;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NCW; ++c)
 #pragma unroll

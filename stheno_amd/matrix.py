@@ -252,6 +252,21 @@ class Chol:
             return None
         return ops.get_backend().gemm(dsb[0, 0][: self.n, : self.n], b, a_kmajor=True, b_kmajor=False, tri_k_lower=True)
 
+    def solve_scaled(self, b, colscale, want_colss):
+        """``(L^{-1} b) diag(colscale)`` and (``want_colss``) the column sums of squares of ``L^{-1} b``, from ONE triangular GEMM with
+        both folded into its store -- when the whole factor has been inverted (``_solve_block``: far more right-hand sides than
+        unknowns, the pseudo-point path).  ``None`` when that does not apply (the caller takes the separate passes)."""
+        if self.l.dim() != 2 or b.dim() != 2 or b.shape[-1] <= 8:
+            return None
+        be = ops.get_backend()
+        if not hasattr(be, "gemm_colscale"):
+            return None
+        sb, dsb = self._blocks(b.shape[-1])
+        if dsb is None or sb < self.n:
+            return None
+        return be.gemm_colscale(dsb[0, 0][: self.n, : self.n], b, colscale, want_colss=want_colss, a_kmajor=True, b_kmajor=False,
+                                tri_k_lower=True)
+
     def solve_(self, b):
         """``L^{-1} b``, overwriting ``b`` where possible (``b``: (..., n, nrhs), unit inner stride).
         Use the RETURN value: the single-GEMM case writes a fresh buffer and leaves ``b`` as it was."""

@@ -322,22 +322,36 @@ class AbstractPseudoObservations(AbstractObservations):
             )
         K_n = noise_x.diag()
 
-        v = K_z.chol().solve_(K_zx)                                           # :300-301
+        if self.method not in {"vfe", "fitc", "dtc"}:  # pragma: no cover
+            raise ValueError(f'Invalid approximation method "{self.method}".')
+        # VFE / DTC: K_n is known before V is: the K_n^{-1/2} column scaling and Q_x_diag = colsumsq(V) come out of the SAME GEMM that
+        # forms V = L_z^{-1} K_zx (`Chol.solve_scaled`, gpk_gemm_colscale) -- no scaling pass, no reduction pass over the M x N matrix.
+        # (FITC's K_n depends on Q_x_diag: the separate passes below.)
+        fused = None
+        if self.method != "fitc" and K_zx.dim() == 2:
+            s = torch.rsqrt(K_n)
+            fused = K_z.chol().solve_scaled(K_zx, s, want_colss=self.method == "vfe")
+        if fused is not None:
+            v, q_x_diag = fused                                               # :300-301, 305, and the scalings of :322, 327
+            del K_zx
+        else:
+            v = K_z.chol().solve_(K_zx)                                       # :300-301
+            q_x_diag = None
         zero = torch.zeros(v.shape[:-2], dtype=x.dtype, device=x.device)
         trace_part = zero
         if self.method in {"vfe", "fitc"}:
             k_x_diag = measure.kernels[p_x].elwise(x)[..., 0]                 # :304
-            _, q_x_diag = be.colreduce(v, want_ss=True)                       # :305
+            if q_x_diag is None:
+                _, q_x_diag = be.colreduce(v, want_ss=True)                   # :305
             corr = k_x_diag - q_x_diag
             if self.method == "vfe":
                 trace_part = (corr / K_n).sum(-1)                             # :310
             else:
                 K_n = K_n + corr                                              # :312
-        elif self.method != "dtc":  # pragma: no cover
-            raise ValueError(f'Invalid approximation method "{self.method}".')
 
-        s = torch.rsqrt(K_n)
-        be.scale_cols_(v, s)                                                  # V K_n^{-1/2}
+        if fused is None:
+            s = torch.rsqrt(K_n)
+            be.scale_cols_(v, s)                                              # V K_n^{-1/2}
         m = z.shape[-2]
         # stats: rows 0..m-1 = [ V K_n^{-1} V^T (lower) | V K_n^{-1} y ]; row m = logdet(2 pi K_n), y^T K_n^{-1} y, trace
         # (ONE buffer, so that the sharded path needs one all-reduce; the scalars have a row of their own: any m >= 1)

@@ -333,6 +333,30 @@ class HipBackend:
         return out
 
     @_on_operand_device
+    def gemm_colscale(self, a, b, colscale=None, *, want_colss=False, a_kmajor=True, b_kmajor=True, tri_k_lower=False):
+        """``out[m, n] = sum_k a(m, k) b(n, k) * colscale[n]`` (unbatched) and, with ``want_colss``, the column sums of squares of the
+        UNSCALED product -- both in the epilogue of the one GEMM (``gpk_gemm_colscale``).  Returns ``(out, colss or None)``."""
+        M, K = (a.shape[0], a.shape[1]) if a_kmajor else (a.shape[1], a.shape[0])
+        N, K2 = (b.shape[0], b.shape[1]) if b_kmajor else (b.shape[1], b.shape[0])
+        if a.dim() != 2 or b.dim() != 2 or K != K2:
+            raise ValueError("gemm_colscale takes two matrices with matching inner dimensions")
+        self._check(a, b, None)
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        part = None
+        if want_colss:
+            part = torch.empty((int(self.lib.gpk_gemm_colss_rows(M)), N), dtype=a.dtype, device=a.device)
+        if colscale is not None:
+            colscale = colscale.to(dtype=a.dtype).contiguous()
+            if colscale.shape != (N,):
+                raise ValueError("colscale must have one entry per column")
+        code = self.lib.gpk_gemm_colscale(_dtype_id(a), int(a_kmajor), int(b_kmajor), M, N, K, 1.0, self._ptr(a), _ld(a), self._ptr(b),
+                                          _ld(b), self._ptr(out), _ld(out), 4 if tri_k_lower else 0,
+                                          self._ptr(colscale) if colscale is not None else None,
+                                          self._ptr(part) if part is not None else None, N, self._stream())
+        self._st(code, "gpk_gemm_colscale")
+        return out, (part.sum(0) if part is not None else None)       # (64 x N partial sums: a statistics buffer, added up by torch)
+
+    @_on_operand_device
     def gemv(self, a, x, *, alpha=1.0, beta=0.0, out=None):
         """``out = alpha * a @ x + beta * out`` for (..., M, K) @ (..., K, nrhs <= 8)."""
         a3, bshape = _as3(a)

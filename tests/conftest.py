@@ -106,6 +106,15 @@ class OracleBackend:
         out.copy_(res + beta * out if beta != 0.0 else res)
         return out
 
+    def gemm_colscale(self, a, b, colscale=None, *, want_colss=False, a_kmajor=True, b_kmajor=True, tri_k_lower=False):
+        A = a if a_kmajor else a.transpose(-1, -2)
+        Bt = b.transpose(-1, -2) if b_kmajor else b
+        res = A @ Bt
+        ss = (res * res).sum(-2) if want_colss else None
+        if colscale is not None:
+            res = res * colscale.reshape(1, -1)
+        return res.contiguous(), ss
+
     def gemv(self, a, x, *, alpha=1.0, beta=0.0, out=None):
         res = alpha * (a @ x)
         if out is None:
