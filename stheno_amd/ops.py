@@ -340,7 +340,9 @@ class HipBackend:
         N, K2 = (b.shape[0], b.shape[1]) if b_kmajor else (b.shape[1], b.shape[0])
         if a.dim() != 2 or b.dim() != 2 or K != K2:
             raise ValueError("gemm_colscale takes two matrices with matching inner dimensions")
-        self._check(a, b, None)
+        a3, _ = _as3(a)
+        b3, _ = _as3(b)
+        self._check(a3, b3, None)
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
         part = None
         if want_colss:
@@ -349,8 +351,8 @@ class HipBackend:
             colscale = colscale.to(dtype=a.dtype).contiguous()
             if colscale.shape != (N,):
                 raise ValueError("colscale must have one entry per column")
-        code = self.lib.gpk_gemm_colscale(_dtype_id(a), int(a_kmajor), int(b_kmajor), M, N, K, 1.0, self._ptr(a), _ld(a), self._ptr(b),
-                                          _ld(b), self._ptr(out), _ld(out), 4 if tri_k_lower else 0,
+        code = self.lib.gpk_gemm_colscale(_dtype_id(a3), int(a_kmajor), int(b_kmajor), M, N, K, 1.0, self._ptr(a3), _ld(a3), self._ptr(b3),
+                                          _ld(b3), self._ptr(out), N, 4 if tri_k_lower else 0,
                                           self._ptr(colscale) if colscale is not None else None,
                                           self._ptr(part) if part is not None else None, N, self._stream())
         self._st(code, "gpk_gemm_colscale")
