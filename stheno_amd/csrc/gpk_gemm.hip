@@ -315,7 +315,9 @@ struct Prof {
 };
 Prof g_prof;
 
-GPK_KNOB(int64_t, g_small_tile_below, 1024);  // tuning knob (gpk_tune(1, v)); r01 sweep: 256 -> 1024 = -1 % POTRF time
+GPK_KNOB(int64_t, g_small_tile_below, 512);   // tuning knob (gpk_tune(1, v)); r01 sweep (old k loop): 256 -> 1024 = -1 % POTRF time; r04 sweep with the pipelined
+                                              // 128-tile loop: 1024 -> 512 = TRSM 9.85 -> 9.24 ms (fp64 cfg2), 18.0 -> 17.5 (fp32 cfg3), POTRF / batched unchanged
+                                              // (profiles/r04_sweep_small_tile_threshold.log): a launch of 512 128-tiles is exactly one round
 GPK_KNOB(int, g_trib, 1);                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
 GPK_KNOB(int, g_trilo_pairs, 1);            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
 GPK_KNOB(int, g_split_tail, 1);               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
