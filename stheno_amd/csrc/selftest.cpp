@@ -567,7 +567,7 @@ static void test_lookahead() {
         test_update2_case<T>(1000, 256, 1100, 128, 1, 2);
         test_update2_case<T>(129, 1, 5, 3, 1, 1);
     }
-    gpk_tune(1, 1024);
+    gpk_tune(1, 512);
     test_potrf_la_case<T>(700, 256, 1, 0);
     test_potrf_la_case<T>(1024, 256, 1, 0);
     test_potrf_la_case<T>(1200, 512, 1, 0);
@@ -1753,7 +1753,7 @@ int main(int argc, char** argv) {
         test_gemm<double>(); test_gemm<float>();
         gpk_tune(1, (int64_t)1 << 40);  // force the 64x64-tile kernels
         test_gemm<double>(); test_gemm<float>();
-        gpk_tune(1, 1024);              // library default
+        gpk_tune(1, 512);               // library default
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_lookahead<double>(); test_lookahead<float>();
