@@ -12,7 +12,6 @@
 #ifndef GPK_GEMM_PIPE
 #define GPK_GEMM_PIPE 1
 #endif
-
 namespace {
 
 // One operand tile of TS rows in LDS, either image: k-contiguous [TS][128 B] or
@@ -596,6 +595,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             }
         }
     }
+    // (Round 4 also built the store of a finished 128-tile THROUGH LDS -- the tile laid out row-major in the free operand stages and
+    // written as 16-byte stores of whole rows, 16 wave-instructions per thread instead of 64, full 128-byte lines -- and measured it
+    // against this loop on one box: fp64 K = 1024 update 62.7 vs 64.0 TFLOP/s, fp32 137 vs 138, POTRF fp64 26.3-26.7 vs 26.1 ms, batched
+    // fp32 POTRF 15.3 vs 15.55 ms: the three extra barriers cost what the wider stores save.  profiles/r04_ab_c_tile_through_lds.log.)
+    {
 #pragma unroll
     for (int c = 0; c < NCW; ++c)
 #pragma unroll
@@ -609,6 +613,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                     if (!EDGE || (row < p.M && col < p.N))
                         *reinterpret_cast<T*>(reinterpret_cast<char*>(C + c_base(p.ldc, c, fi, fj, i)) + lane_off_out) = p.alpha * acc[c][fi][fj][i];
                 }
+    }
     if (prof != nullptr) {
         __builtin_amdgcn_s_waitcnt(0);          // (profiling only) stores retired
         if (threadIdx.x == 0) prof[3] = wall_clock64();
