@@ -12,6 +12,9 @@
 #ifndef GPK_GEMM_PIPE
 #define GPK_GEMM_PIPE 1
 #endif
+#ifndef GPK_GEMM_PIPE64
+#define GPK_GEMM_PIPE64 1      // ... for the 64-tile too
+#endif
 namespace {
 
 // One operand tile of TS rows in LDS, either image: k-contiguous [TS][128 B] or
@@ -356,7 +359,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // next chunk are read behind it, under the rest of phase 3.  sched_group_barrier pins that interleaving.
     // (bounds-checked kernels: the interior tiles of a ragged problem take it too -- cfg5's N = 200000, the look-ahead at orders
     // that are not multiples of 128)
-    constexpr bool PIPE_KERNEL = PIPE != 0 && TS == 128 && NCT == 1 && NW == 4 && !TRIB;
+    // (round 4, later: the 64-tile -- 32 x 32 per wave, four workgroups per CU: the narrow panel / solve GEMMs, 23 % of a cfg2 step -- takes
+    // the same loop with four slices per phase instead of eight)
+    constexpr bool PIPE_KERNEL = PIPE != 0 && (TS == 128 || (TS == 64 && GPK_GEMM_PIPE64 != 0)) && NCT == 1 && NW == 4 && !TRIB;
     const bool pipe_tile = PIPE_KERNEL && (!EDGE || (a_in && b_in && p.K % BK == 0));
     if constexpr (PIPE_KERNEL) if (pipe_tile) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -427,32 +432,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             if (j < FRM) Fa[set][j] = frag(std::integral_constant<bool, A_KMAJ>{}, sA, wm * WTM + j * 16, ph);
             else Fb[set][j - FRM] = frag(std::integral_constant<bool, B_KMAJ>{}, sA + OPB, wn * WT + (j - FRM) * 16, ph);
         };
-        // slice q of the NSL slices of a phase's MFMAs: fragment column q / 2, fragment rows 2 (q % 2), 2 (q % 2) + 1
-        constexpr int NSL = FRM * FR / 2;
-        static_assert(NSL == 8 && FRM + FR == 8 && 2 * NV == 8, "eight slices, eight fragments, eight vectors per phase");
+        // A phase is NSL slices: one fragment read, one vector moved, CPS fragment products each.  128-tile: 8 slices of 2 products
+        // (fragment column q / 2, rows 2 (q % 2), 2 (q % 2) + 1); 64-tile: 4 slices of 1.
+        constexpr int NSL = FRM + FR;
+        constexpr int CPS = FRM * FR / NSL;
+        static_assert(CPS * NSL == FRM * FR && 2 * NV == NSL && NSL % 2 == 0, "slices cover the fragment products and the vectors of a chunk");
         auto f_mma1 = [&](auto set_c, int q) {
             constexpr int set = decltype(set_c)::value;
-            const int fj = q >> 1, f0 = (q & 1) * 2;
-            if constexpr (sizeof(T) == 8) {
-                acc[0][f0][fj] = Traits<T>::mfma(Fa[set][f0], Fb[set][fj], acc[0][f0][fj]);
-                acc[0][f0 + 1][fj] = Traits<T>::mfma(Fa[set][f0 + 1], Fb[set][fj], acc[0][f0 + 1][fj]);
-            } else {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    acc[0][f0][fj] = Traits<T>::mfma((T)Fa[set][f0][e], (T)Fb[set][fj][e], acc[0][f0][fj]);
-                    acc[0][f0 + 1][fj] = Traits<T>::mfma((T)Fa[set][f0 + 1][e], (T)Fb[set][fj][e], acc[0][f0 + 1][fj]);
+            for (int e = 0; e < (sizeof(T) == 8 ? 1 : 2); ++e)
+#pragma unroll
+                for (int u = 0; u < CPS; ++u) {
+                    const int idx = q * CPS + u, fj = idx / FRM, fi = idx % FRM;
+                    if constexpr (sizeof(T) == 8) acc[0][fi][fj] = Traits<T>::mfma(Fa[set][fi], Fb[set][fj], acc[0][fi][fj]);
+                    else acc[0][fi][fj] = Traits<T>::mfma((T)Fa[set][fi][e], (T)Fb[set][fj][e], acc[0][fi][fj]);
                 }
-            }
         };
         typedef std::integral_constant<int, 0> F0;
         typedef std::integral_constant<int, 1> F1;
         // the next tile's C lines, one per thread and chunk over the last PFN chunks (see pf_c above); every other chunk the same
         // instruction re-reads an operand address that is in the L1 anyway -- the loop body stays free of branches
         constexpr int LPR = TS * (int)sizeof(T) / 128;          // cache lines per tile row
-        constexpr int PFN = TS * LPR / NT;                      // lines per thread: 4 (fp64) / 2 (fp32)
-        const char* pf_lane = pf_c == nullptr ? nullptr
-                                              : reinterpret_cast<const char*>(pf_c + (int64_t)(tid / LPR) * pf_ld) + (tid % LPR) * 128;
-        const int64_t pf_step = (int64_t)(NT / LPR) * pf_ld * (int64_t)sizeof(T);
+        constexpr int PFN = TS == 128 ? TS * LPR / NT : 0;      // lines per thread: 4 (fp64) / 2 (fp32)
+        const char* pf_lane = (pf_c == nullptr || TS != 128) ? nullptr
+                                              : reinterpret_cast<const char*>(pf_c + (int64_t)(tid / (LPR > 0 ? LPR : 1)) * pf_ld) + (tid % (LPR > 0 ? LPR : 1)) * 128;
+        const int64_t pf_step = (int64_t)(NT / (LPR > 0 ? LPR : 1)) * pf_ld * (int64_t)sizeof(T);
         int left = nk - kc0;                    // chunks of this tile still to be multiplied (>= 1)
         int pfv = 0;
         auto pf_tick = [&]() {
