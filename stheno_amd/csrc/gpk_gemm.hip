@@ -85,6 +85,14 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
             return;
         }
     }
+    if (p.xcd_batch > 0) {       // workgroup L runs on XCD L % 8: the tiles of matrix m = (L / 8 / tiles) * 8 + L % 8 all land there
+        const int L = (int)blockIdx.x, s = L >> 3;
+        const int m = (s / p.xcd_tiles) * 8 + (L & 7);
+        if (m >= p.xcd_batch) return;
+        if (!decode_tile(p, s % p.xcd_tiles, ti, tj)) return;
+        gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, m, 0, smem);
+        return;
+    }
     if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
     gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
@@ -319,6 +327,7 @@ GPK_KNOB(int64_t, g_small_tile_below, 512);   // tuning knob (gpk_tune(1, v)); r
                                               // 128-tile loop: 1024 -> 512 = TRSM 9.85 -> 9.24 ms (fp64 cfg2), 18.0 -> 17.5 (fp32 cfg3), POTRF / batched unchanged
                                               // (profiles/r04_sweep_small_tile_threshold.log): a launch of 512 128-tiles is exactly one round
 GPK_KNOB(int, g_trib, 1);                     // tuning knob (gpk_tune(36, v)): panel solves skip the zero half of the inverted diagonal block per fragment
+GPK_KNOB(int, g_xcd_batch, 1);              // tuning knob (gpk_tune(45, v)): batched 128-tile launches keep every matrix on one XCD (r04: 15.57 -> 15.37 ms per 512 x 2048^2 fp32 POTRF)
 GPK_KNOB(int, g_trilo_pairs, 1);            // tuning knob (gpk_tune(42, v)): small products with a lower-triangular A take gemm_trilo_pair_kernel
 GPK_KNOB(int, g_split_tail, 1);               // tuning knob (gpk_tune(31, v)): cut the last, partial round of a 128-tile launch into quarter tiles
 
@@ -351,6 +360,7 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 31) GPK_KNOB_SET(g_split_tail = (int)value;);
     if (key == 36) GPK_KNOB_SET(g_trib = (int)value;);
     if (key == 42) GPK_KNOB_SET(g_trilo_pairs = (int)value;);
+    if (key == 45) GPK_KNOB_SET(g_xcd_batch = (int)value;);
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
@@ -453,6 +463,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     // computed by the same k order whichever kernel body does it).
     g.split_from = INT32_MAX;
     g.colscale = colscale; g.colss = colss; g.ldss = ldss;
+    g.xcd_batch = 0; g.xcd_tiles = 0;
     if (g_split_tail && !fused_cols && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && (flags & (2 | 4 | 8)) == 0 &&
         (const void*)A != (const void*)C && (const void*)B != (const void*)C) {      // (in-place: one workgroup must own all columns of its rows)
         const int64_t slots = (int64_t)device_cus() * 2;
@@ -463,6 +474,10 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         }
     }
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
+    if (g_xcd_batch && (flags & 16) == 0 && ts == 128 && nct == 1 && batch >= 16 && batch2 == 1 && g.split_from == INT32_MAX && gridx * gpk_cdiv(batch, 8) * 8 < INT32_MAX) {
+        g.xcd_batch = (int)batch; g.xcd_tiles = (int)gridx;
+        grid = dim3((unsigned)(gridx * gpk_cdiv(batch, 8) * 8), 1, 1);
+    }
     // triangular A, a grid too small to keep two waves per SIMD busy to the end: pairs of 32-row tiles (gemm_trilo_pair_kernel)
     if (g_trilo_pairs && flags == 4 && a_kmaj && ts == 64 && nct == 1 && batch == 1 && batch2 == 1 && M % 64 == 0 && M >= 256 &&
         (const void*)A != (const void*)C && (const void*)B != (const void*)C && gpk_cdiv(M, 64) * gpk_cdiv(N, 64) <= 2 * (int64_t)device_cus()) {
@@ -657,7 +672,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         g.tiles_m = (int)gpk_cdiv(q.M, ts); g.tiles_n = (int)gpk_cdiv(q.N, ts);
         g.lower_only = q.lower_only ? 1 : 0;
         g.tri_k = g.tri_k_lo = 0;
-        g.colscale = nullptr; g.colss = nullptr; g.ldss = 0;
+        g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
         g.tri_k_lo_b = q.tri_b ? 1 : 0;
         const bool aligned = ((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && (q.lda % VEC == 0) &&
                              (q.ldb % VEC == 0);
@@ -846,7 +861,7 @@ int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, in
     g.tiles_m = (int)gpk_cdiv(m, ts); g.tiles_n = 1;
     g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
     g.split_from = INT32_MAX;
-    g.colscale = nullptr; g.colss = nullptr; g.ldss = 0;
+    g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
     const bool aligned = ((uintptr_t)P % 16 == 0) && ((uintptr_t)W % 16 == 0) && (ld % VEC == 0);
     g.vec_ok = aligned ? 1 : 0;
     GemmArgs<T>& u = pa.upd;

@@ -43,6 +43,8 @@ struct GemmArgs {
     const T* colscale;   // (128-tile kernels, optional) C[m][n] = alpha * sum * colscale[n]: a column scaling folded into the store
     T* colss;            // (optional) column sums of squares of the UNSCALED alpha * sum over each wave's 64 rows: row 2 ti + wm of a
     int64_t ldss;        //   [2 tiles_m][ldss] buffer (the caller adds the rows up) -- the pseudo-point path's Q_x_diag without a pass over V
+    int xcd_batch;    // (knob 45) batched launch as a 1-D grid with all tiles of a matrix on ONE XCD: xcd_batch = batch size, else 0
+    int xcd_tiles;    //   tiles per matrix of such a launch
     int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
                       // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };

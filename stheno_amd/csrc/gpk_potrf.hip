@@ -750,7 +750,7 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     g.tiles_m = R;
     g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
     g.split_from = INT32_MAX;
-    g.colscale = nullptr; g.colss = nullptr; g.ldss = 0;
+    g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
     g.vec_ok = p.vec_ok;
     int k = 0;
     const bool fill_first = role > p.panel_wgs;
@@ -1025,7 +1025,7 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
         g.tiles_m = (int)gpk_cdiv(mf, 128); g.tiles_n = g.tiles_m;
         g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
         g.split_from = INT32_MAX;
-        g.colscale = nullptr; g.colss = nullptr; g.ldss = 0;
+        g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
         g.vec_ok = aligned ? 1 : 0;
         fill_edge = !aligned || (mf % 128) || (fill_k % Traits<T>::BK);
         pa.fill_tiles = g.tiles_m * (g.tiles_m + 1) / 2;
