@@ -302,7 +302,8 @@ int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* usef
  * panel's trailing update rides in the next panel's launch; 39: workgroups that take panel tasks first in such a launch (0 = a
  * third of the CUs); 40 / 41: the look-ahead's update of the next diagonal block is the first segment of the trailing update while
  * that has at least (40) rows and the outer block is at most (41) wide; 42: small products with a lower-triangular A (the leaves of
- * the recursive solve) as pairs of 32-row tiles with equal K per workgroup.  (Removed in round 4 with the code they selected: 2 / 4 /
+ * the recursive solve) as pairs of 32-row tiles with equal K per workgroup; 45: batched 128-tile GEMM launches as a 1-D grid with all
+ * tiles of a matrix on one XCD.  (Removed in round 4 with the code they selected: 2 / 4 /
  * 13 -- XCD super-tile, row-pair and column-major tile orders -- and 30, the 256-thread diagonal-block kernel of rounds 1-2.)
  * gpk_tune_diag_prof: device buffer (32 int64 per diagonal block, or NULL) for cycle / wall-clock stamps of the diagonal-block
  * kernel and of the pipelined panel's chain and critical tasks (read by `gpk_selftest --diagprof`). */

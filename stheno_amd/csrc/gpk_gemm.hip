@@ -474,7 +474,8 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         }
     }
     dim3 grid((unsigned)gridx, (unsigned)batch, (unsigned)batch2);
-    if (g_xcd_batch && (flags & 16) == 0 && ts == 128 && nct == 1 && batch >= 16 && batch2 == 1 && g.split_from == INT32_MAX && gridx * gpk_cdiv(batch, 8) * 8 < INT32_MAX) {
+    // (many small problems only: the 25 strided K-slices of cfg5's split-K SYRK, 528 tiles each, deal badly over 8 XCDs -- 64.4 vs 56.4 ms per step)
+    if (g_xcd_batch && (flags & 16) == 0 && ts == 128 && nct == 1 && batch >= 64 && batch2 == 1 && g.split_from == INT32_MAX && gridx * gpk_cdiv(batch, 8) * 8 < INT32_MAX) {
         g.xcd_batch = (int)batch; g.xcd_tiles = (int)gridx;
         grid = dim3((unsigned)(gridx * gpk_cdiv(batch, 8) * 8), 1, 1);
     }
