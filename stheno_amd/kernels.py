@@ -418,11 +418,21 @@ def _merge_terms(terms):
     return out
 
 
+def _scale_stamp(t):
+    """Identity + version of a length-scale vector (``None`` scale: a constant stamp; a tensor nothing vouches for: ``None``)."""
+    if t is None:
+        return (0, 0)
+    if not torch.is_tensor(t) or t.is_inference() or not t.is_cuda:
+        return None
+    return (id(t), t._version)
+
+
 class Sum(Kernel):
     def __init__(self, a, b):
         self.a, self.b = a, b
         self.stationary = a.stationary and b.stationary
         self._view = _UNSET
+        self._view_stamp = None
 
     def num_outputs(self, x):
         return self.a.num_outputs(x)
@@ -442,8 +452,13 @@ class Sum(Kernel):
     def input_scaled_view(self):
         # asked several times per FDD / log-density: the comparison of the two length-scale vectors (a device-to-host
         # synchronisation when they live on the GPU) is made once per kernel object
-        if self._view is _UNSET:
+        # -- and again whenever one of them has been written in place since (the answer of `torch.equal` must not outlive
+        # the values it compared; tensors without a version counter are compared every time)
+        va, vb = self.a.input_scaled_view(), self.b.input_scaled_view()
+        stamp = tuple(_scale_stamp(v[1]) for v in (va, vb) if v is not None)
+        if self._view is _UNSET or None in stamp or stamp != self._view_stamp:
             self._view = self._input_scaled_view()
+            self._view_stamp = stamp
         return self._view
 
     def _input_scaled_view(self):

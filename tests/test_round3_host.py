@@ -168,3 +168,21 @@ def test_normal_computed_does_not_compute():
     assert not d.computed("mean") and not d.computed("var") and not d.computed("var_diag") and made == []
     d.var_diag
     assert made == ["var"] and d.computed("var") and d.computed("var_diag") and not d.computed("mean")
+
+
+def test_common_length_scale_view_is_not_remembered_past_an_in_place_write():
+    """``Sum.input_scaled_view`` caches the comparison of the summands' length-scale vectors -- an in-place write to one of
+    them afterwards must be seen (mlkernels' ``Stretched`` has no such cache: ``k(x / l)`` is evaluated with the current ``l``)."""
+    rng = np.random.default_rng(5)
+    x = T(rng.standard_normal((30, 3)), f64)
+    la, lb = T(np.array([0.7, 1.1, 1.9]), f64), T(np.array([0.7, 1.1, 1.9]), f64)
+    k = st.EQ().stretch(la) + st.Matern32().stretch(lb)
+    assert k.input_scaled_view() is not None                    # equal vectors: one division, one fused launch
+    ref1 = O.kernel_matrix([("eq", 1.0, 1.0)], x.cpu().numpy() / la.cpu().numpy()) + \
+        O.kernel_matrix([("matern32", 1.0, 1.0)], x.cpu().numpy() / lb.cpu().numpy())
+    assert np.max(np.abs(k.pairwise(x).cpu().numpy() - ref1)) < 1e-8
+    lb[1] = 2.5                                                  # now they differ
+    assert k.input_scaled_view() is None
+    ref2 = O.kernel_matrix([("eq", 1.0, 1.0)], x.cpu().numpy() / la.cpu().numpy()) + \
+        O.kernel_matrix([("matern32", 1.0, 1.0)], x.cpu().numpy() / lb.cpu().numpy())
+    assert np.max(np.abs(k.pairwise(x).cpu().numpy() - ref2)) < 1e-8
