@@ -359,7 +359,10 @@ class InputScaled(Kernel):
     def __init__(self, k, scales):
         if k.terms() is None:
             raise NotImplementedError("stretch is implemented for sums of primitive kernels")
-        scales = torch.as_tensor(scales)
+        # (a tensor is kept AS IT IS -- the caller's object: in-place updates and autograd leaves must stay visible; under a
+        # `torch.set_default_device(...)` mode `torch.as_tensor(tensor)` would silently copy it to that device)
+        if not torch.is_tensor(scales):
+            scales = torch.as_tensor(scales)
         if scales.dim() != 1:
             raise ValueError("per-dimension length scales are a vector (one entry per input dimension)")
         if not bool((scales > 0).all()):
@@ -393,7 +396,7 @@ class InputScaled(Kernel):
 
     def stretch(self, scale):
         if _is_vector_scale(scale):
-            return InputScaled(self.k, self.scales * torch.as_tensor(scale).to(self.scales))
+            return InputScaled(self.k, self.scales * (scale if torch.is_tensor(scale) else torch.as_tensor(scale)).to(self.scales))
         return InputScaled(self.k, self.scales * _as_float(scale))
 
     def __reversed__(self):

@@ -41,7 +41,7 @@ def backend(request):
         try:
             yield request.param
         finally:
-            torch.set_default_device("cpu")
+            torch.set_default_device(None)      # (NOT "cpu": that leaves a device mode behind under which torch.as_tensor(cuda_tensor) copies to the host)
             _DEV[0] = "cpu"
             ops.set_backend(prev)
 

@@ -177,6 +177,7 @@ def test_common_length_scale_view_is_not_remembered_past_an_in_place_write():
     x = T(rng.standard_normal((30, 3)), f64)
     la, lb = T(np.array([0.7, 1.1, 1.9]), f64), T(np.array([0.7, 1.1, 1.9]), f64)
     k = st.EQ().stretch(la) + st.Matern32().stretch(lb)
+    assert k.a.scales is la and k.b.scales is lb                # the caller's tensors, not copies (also under a default-device mode)
     assert k.input_scaled_view() is not None                    # equal vectors: one division, one fused launch
     ref1 = O.kernel_matrix([("eq", 1.0, 1.0)], x.cpu().numpy() / la.cpu().numpy()) + \
         O.kernel_matrix([("matern32", 1.0, 1.0)], x.cpu().numpy() / lb.cpu().numpy())
@@ -186,3 +187,10 @@ def test_common_length_scale_view_is_not_remembered_past_an_in_place_write():
     ref2 = O.kernel_matrix([("eq", 1.0, 1.0)], x.cpu().numpy() / la.cpu().numpy()) + \
         O.kernel_matrix([("matern32", 1.0, 1.0)], x.cpu().numpy() / lb.cpu().numpy())
     assert np.max(np.abs(k.pairwise(x).cpu().numpy() - ref2)) < 1e-8
+    # a default-device mode must not make the kernel copy the caller's vector
+    torch.set_default_device(str(la.device))
+    try:
+        k2 = st.EQ().stretch(lb)
+        assert k2.scales is lb
+    finally:
+        torch.set_default_device(None)
