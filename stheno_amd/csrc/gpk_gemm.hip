@@ -453,7 +453,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&
                          (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
                          (sA2 % VEC == 0) && (sB2 % VEC == 0);
-    const bool edge = !aligned || (M % ts) || (N % (ts * nct)) || (K % BK);
+    const bool edge = !aligned || (M % ts) || (N % (ts * nct)) || (K % BK) || lda >= GPK_PIPE_LD_MAX || ldb >= GPK_PIPE_LD_MAX;
     g.vec_ok = aligned ? 1 : 0;
 
     // The last, partial round.  The hardware hands out workgroups in index order as slots free up, so with equal tiles the last
@@ -678,7 +678,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         const bool aligned = ((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && (q.lda % VEC == 0) &&
                              (q.ldb % VEC == 0);
         g.vec_ok = aligned ? 1 : 0;
-        edge = edge || !aligned || (q.M % ts) || (q.N % ts) || (q.K % BK);
+        edge = edge || !aligned || (q.M % ts) || (q.N % ts) || (q.K % BK) || q.lda >= GPK_PIPE_LD_MAX || q.ldb >= GPK_PIPE_LD_MAX;
         const bool tri = g.lower_only && g.tiles_m == g.tiles_n;
         int64_t nt = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
         g.pair_cols = (q.tri_b == 2 && !g.lower_only && g.tiles_n >= 2 && g.tiles_n % 2 == 0) ? 1 : 0;
@@ -872,7 +872,7 @@ int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, in
     u.N = (int)ncols;
     u.alpha = T(-1); u.beta_over_alpha = T(-1); u.has_beta = 1;
     u.tiles_n = (int)gpk_cdiv(ncols > 0 ? ncols : 1, GPK_DB);
-    const bool edge = !aligned || (m % ts) || (ncols % GPK_DB) || (GPK_DB % BK);
+    const bool edge = !aligned || (m % ts) || (ncols % GPK_DB) || (GPK_DB % BK) || ld >= GPK_PIPE_LD_MAX;
     pa.flags = flags;
     pa.nstrips = (int)gpk_cdiv(m, ts);
     pa.ncb = (int)gpk_cdiv(ncols, GPK_DB);

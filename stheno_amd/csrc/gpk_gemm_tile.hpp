@@ -20,6 +20,8 @@ namespace {
 // One operand tile of TS rows in LDS, either image: k-contiguous [TS][128 B] or
 // row-contiguous [BK][TS + 16] (BK * sizeof(T) = 128 B), so (TS + 16) * 128 bytes cover both.
 constexpr int op_bytes(int ts) { return (ts + 16) * 128; }
+// leading dimensions (elements) from which the pipelined k loop's 32-bit operand offsets could overflow (128 rows * ld * 8 bytes < 2^32)
+constexpr int64_t GPK_PIPE_LD_MAX = (int64_t)1 << 21;
 
 template <typename T>
 struct GemmArgs {
@@ -161,9 +163,10 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // last LDS read when the function returns.
 // NW: waves of the workgroup, as an (NW / 2) x 2 grid over the tile.  NW = 4 (256 threads): 64 x 64 of a 128-tile per wave -- what
 // every kernel of this file instantiates.  NW = 8 (512 threads, 32 x 64 per wave, two workgroups = FOUR waves per SIMD) was built
-// and measured in round 3 on the hypothesis that two waves per SIMD starve the matrix pipe whenever one of them waits: same
-// results, 2-4 % SLOWER (fp64 8192^3 68.6 vs 71.4 TFLOP/s, trailing update 59.6 vs 60.8, POTRF N = 16384 28.6 vs 28.1 ms); the
-// kernels were removed, the parameter stays.
+// and measured twice on the hypothesis that two waves per SIMD starve the matrix pipe whenever one of them waits: round 3 with the
+// old k loop (same results, 2-4 % SLOWER: fp64 8192^3 68.6 vs 71.4 TFLOP/s, POTRF N = 16384 28.6 vs 28.1 ms), round 4 with the
+// pipelined loop in a persistent kernel at 128 registers (1-1.5 % slower: the K = 1024 fp64 update 3.89 vs 3.84 ms, the fp32 look-ahead
+// 90.6 vs 89.3 ms; profiles/r04_ab_nw8.log).  The kernels were removed, the parameter stays.
 // TRIB: the B operand (N x K) is LOWER TRIANGULAR and the tile starts at column 0 of it (the panel solve P inv(L_cc)^T of the
 // Cholesky): a 16-column fragment at columns j0.. only needs k < j0 + 16, the MFMAs beyond are skipped per fragment and per group of
 // k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
@@ -363,7 +366,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // that are not multiples of 128)
     // (round 4, later: the 64-tile -- 32 x 32 per wave, four workgroups per CU: the narrow panel / solve GEMMs, 23 % of a cfg2 step -- takes
     // the same loop with four slices per phase instead of eight)
-    constexpr bool PIPE_KERNEL = PIPE != 0 && (TS == 128 || (TS == 64 && GPK_GEMM_PIPE64 != 0)) && NCT == 1 && NW == 4 && !TRIB;
+    constexpr bool PIPE_KERNEL = PIPE != 0 && NCT == 1 && !TRIB && NW == 4 && (TS == 128 || (TS == 64 && GPK_GEMM_PIPE64 != 0));
     const bool pipe_tile = PIPE_KERNEL && (!EDGE || (a_in && b_in && p.K % BK == 0));
     if constexpr (PIPE_KERNEL) if (pipe_tile) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -373,34 +376,80 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         static_assert(NPH == 4, "four phases per chunk");
         frag_t Fa[2][FRM], Fb[2][FR];
         vec_t qa[NV], qb[NV];
-        const T* pa[NV];
-        const T* pb[NV];
-        // per-thread source pointers of the NV vectors of an operand tile (bumped by one chunk per issue)
-        auto init_ptrs = [&](const T* (&ptr)[NV], auto kmaj_c, const T* base, int64_t ld, int r0) {
-            constexpr bool KMAJ = decltype(kmaj_c)::value;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                if (KMAJ) {
-                    ptr[i] = base + (int64_t)(r0 + (tid >> 3) + (NT / 8) * i) * ld + (int64_t)kc0 * BK + (tid & 7) * VEC_;
-                } else {
-                    constexpr int CPR = TS / VEC_;
-                    const int id = tid + NT * i;
-                    ptr[i] = base + ((int64_t)kc0 * BK + id / CPR) * ld + r0 + (id % CPR) * VEC_;
-                }
-            }
+        // Operand addresses.  BUF (kernels without bounds checks): buffer loads -- ONE wave-uniform 64-bit origin per operand (the tile's
+        // first row at the current chunk, moved on by the scalar ALU) in a buffer descriptor, one per-lane 32-bit byte offset per
+        // operand (voffset) and the uniform offset of the thread's i-th vector (soffset).  Per-thread 64-bit pointers take 4 NV vector
+        // registers and two vector adds per load: 250 -> 232 registers for the fp64 persistent kernel, the fp32 look-ahead 90.7 -> 89.3 ms
+        // (profiles/r04_experiments.md section 12).  Offsets are 32 bits: 128 rows * ld * sizeof(T) < 2^32 -- the launchers send leading
+        // dimensions >= GPK_PIPE_LD_MAX to the bounds-checked kernels.
+        // !BUF (bounds-checked kernels): per-thread pointers.  Those kernels hold this loop AND the one below for their edge tiles and sit
+        // at the scalar-register limit; the descriptors' 20 scalar registers pushed the fp64 ones into spilling accumulators inside the loop.
+        constexpr bool BUF = !EDGE;
+        auto uni = [](const void* q) -> const char* {            // (only ever fed to a descriptor: the address space does not matter)
+            const uint64_t v = reinterpret_cast<uint64_t>(q);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
         };
-        init_ptrs(pa, std::integral_constant<bool, A_KMAJ>{}, A, p.lda, m0);
-        init_ptrs(pb, std::integral_constant<bool, B_KMAJ>{}, B, p.ldb, n0);
-        const int64_t stepA = A_KMAJ ? (int64_t)BK : (int64_t)BK * p.lda, stepB = B_KMAJ ? (int64_t)BK : (int64_t)BK * p.ldb;
-        // one vector of the next-but-one chunk: global -> registers (and the pointer moves on by a chunk)
-        // (the pointers stop at the tile's last chunk: past the end of the k range the loop re-reads that chunk and nobody uses it --
+        auto rsrc = [](const char* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xffffffffu, 0x00020000); };
+        constexpr int RPP_A = A_KMAJ ? NT / 8 : NT / (TS / VEC_), RPP_B = B_KMAJ ? NT / 8 : NT / (TS / VEC_);     // rows a pass of the workgroup covers
+        static_assert(NT % (TS / VEC_) == 0, "a thread's vectors sit in the same columns of successive k rows");
+        auto lane_off = [&](auto kmaj_c, int64_t ld) -> unsigned {
+            constexpr bool KMAJ = decltype(kmaj_c)::value;
+            constexpr int CPR = TS / VEC_;
+            return KMAJ ? ((unsigned)(tid >> 3) * (unsigned)ld + (unsigned)(tid & 7) * VEC_) * (unsigned)sizeof(T)
+                        : ((unsigned)(tid / CPR) * (unsigned)ld + (unsigned)(tid % CPR) * VEC_) * (unsigned)sizeof(T);
+        };
+        const char* ua = nullptr;               // BUF: the operands' origins, lane offsets and the offset of one pass of the workgroup
+        const char* ub = nullptr;
+        unsigned la = 0, lb = 0, passA = 0, passB = 0;
+        const T* pa[NV];                        // !BUF: per-thread source pointers of the NV vectors of an operand tile
+        const T* pb[NV];
+        if constexpr (BUF) {
+            la = lane_off(std::integral_constant<bool, A_KMAJ>{}, p.lda);
+            lb = lane_off(std::integral_constant<bool, B_KMAJ>{}, p.ldb);
+            ua = uni(A_KMAJ ? A + (int64_t)m0 * p.lda + (int64_t)kc0 * BK : A + (int64_t)kc0 * BK * p.lda + m0);
+            ub = uni(B_KMAJ ? B + (int64_t)n0 * p.ldb + (int64_t)kc0 * BK : B + (int64_t)kc0 * BK * p.ldb + n0);
+            passA = __builtin_amdgcn_readfirstlane((unsigned)RPP_A * (unsigned)p.lda * (unsigned)sizeof(T));
+            passB = __builtin_amdgcn_readfirstlane((unsigned)RPP_B * (unsigned)p.ldb * (unsigned)sizeof(T));
+        } else {
+            auto init_ptrs = [&](const T* (&ptr)[NV], auto kmaj_c, const T* base, int64_t ld, int r0) {
+                constexpr bool KMAJ = decltype(kmaj_c)::value;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    if (KMAJ) {
+                        ptr[i] = base + (int64_t)(r0 + (tid >> 3) + (NT / 8) * i) * ld + (int64_t)kc0 * BK + (tid & 7) * VEC_;
+                    } else {
+                        constexpr int CPR = TS / VEC_;
+                        const int id = tid + NT * i;
+                        ptr[i] = base + ((int64_t)kc0 * BK + id / CPR) * ld + r0 + (id % CPR) * VEC_;
+                    }
+                }
+            };
+            init_ptrs(pa, std::integral_constant<bool, A_KMAJ>{}, A, p.lda, m0);
+            init_ptrs(pb, std::integral_constant<bool, B_KMAJ>{}, B, p.ldb, n0);
+        }
+        // a chunk along k, in bytes (BUF) / elements (!BUF)
+        const int64_t stepA = (A_KMAJ ? (int64_t)BK : (int64_t)BK * p.lda) * (BUF ? (int64_t)sizeof(T) : 1);
+        const int64_t stepB = (B_KMAJ ? (int64_t)BK : (int64_t)BK * p.ldb) * (BUF ? (int64_t)sizeof(T) : 1);
+        // one vector of the next-but-one chunk: global -> registers (and the origin / pointer moves on by a chunk)
+        // (they stop at the tile's last chunk: past the end of the k range the loop re-reads that chunk and nobody uses it --
         // one loop body for every chunk instead of three tail variants, which cost 800 bytes of scratch)
         int64_t curA = 0, curB = 0;
         auto g_issue1 = [&](int j) {
-            if (j < NV) { qa[j] = *reinterpret_cast<const vec_t*>(pa[j]); pa[j] += curA; }
-            else { qb[j - NV] = *reinterpret_cast<const vec_t*>(pb[j - NV]); pb[j - NV] += curB; }
+            if constexpr (BUF) {
+                if (j < NV) {
+                    qa[j] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc(ua), la, (unsigned)j * passA, 0));
+                    if (j == NV - 1) ua += curA;
+                } else {
+                    qb[j - NV] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc(ub), lb, (unsigned)(j - NV) * passB, 0));
+                    if (j == 2 * NV - 1) ub += curB;
+                }
+            } else {
+                if (j < NV) { qa[j] = *reinterpret_cast<const vec_t*>(pa[j]); pa[j] += curA; }
+                else { qb[j - NV] = *reinterpret_cast<const vec_t*>(pb[j - NV]); pb[j - NV] += curB; }
+            }
         };
-        int adv = nk - kc0 - 1;                 // how many more times the pointers may move on
+        int adv = nk - kc0 - 1;                 // how many more times they may move on
         auto g_arm = [&]() { curA = adv > 0 ? stepA : 0; curB = adv > 0 ? stepB : 0; --adv; };
         // one vector of the next chunk: registers -> LDS stage
         auto g_commit1 = [&](int stage, int j) {
@@ -436,9 +485,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         };
         // A phase is NSL slices: one fragment read, one vector moved, CPS fragment products each.  128-tile: 8 slices of 2 products
         // (fragment column q / 2, rows 2 (q % 2), 2 (q % 2) + 1); 64-tile: 4 slices of 1.
-        constexpr int NSL = FRM + FR;
-        constexpr int CPS = FRM * FR / NSL;
-        static_assert(CPS * NSL == FRM * FR && 2 * NV == NSL && NSL % 2 == 0, "slices cover the fragment products and the vectors of a chunk");
+        // (the formulas also cover 8 waves on the 128-tile -- 4 slices of 2 products, the 6 fragments read 2 + 2 + 2 + 0: measured in round 4,
+        // see NW above)
+        constexpr int NSL = 2 * NV;                                  // one vector moved per slice
+        constexpr int CPS = FRM * FR / NSL;                          // fragment products per slice
+        constexpr int NFG = FRM + FR;                                // fragments of a phase
+        constexpr int RPS = (NFG + NSL - 1) / NSL;                   // fragments read per slice
+        constexpr int RPS2 = (NFG + NSL / 2 - 1) / (NSL / 2);        // ... in the half phase behind the barrier
+        static_assert(CPS * NSL == FRM * FR && NSL % 2 == 0 && CPS >= 1, "slices cover the fragment products and the vectors of a chunk");
+        auto f_reads = [&](auto set_c, int stage, int ph, int q, int per) {      // the fragments [q per, (q + 1) per) of a phase
+#pragma unroll
+            for (int u = 0; u < per; ++u)
+                if (q * per + u < NFG) f_read1(set_c, stage, ph, q * per + u);
+        };
         auto f_mma1 = [&](auto set_c, int q) {
             constexpr int set = decltype(set_c)::value;
 #pragma unroll
@@ -456,16 +515,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         // instruction re-reads an operand address that is in the L1 anyway -- the loop body stays free of branches
         constexpr int LPR = TS * (int)sizeof(T) / 128;          // cache lines per tile row
         constexpr int PFN = TS == 128 ? TS * LPR / NT : 0;      // lines per thread: 4 (fp64) / 2 (fp32)
-        const char* pf_lane = (pf_c == nullptr || TS != 128) ? nullptr
-                                              : reinterpret_cast<const char*>(pf_c + (int64_t)(tid / (LPR > 0 ? LPR : 1)) * pf_ld) + (tid % (LPR > 0 ? LPR : 1)) * 128;
+        const bool pf_on = pf_c != nullptr && TS == 128 && (!BUF || pf_ld < GPK_PIPE_LD_MAX);
         const int64_t pf_step = (int64_t)(NT / (LPR > 0 ? LPR : 1)) * pf_ld * (int64_t)sizeof(T);
+        const unsigned pf_off = ((unsigned)(tid / (LPR > 0 ? LPR : 1)) * (unsigned)pf_ld) * (unsigned)sizeof(T) + (unsigned)(tid % (LPR > 0 ? LPR : 1)) * 128u;
+        const char* pf_base = BUF ? uni(pf_c) : nullptr;        // BUF: uniform origin + one 32-bit lane offset, like the operands
+        const char* pf_lane = (BUF || !pf_on) ? nullptr          // !BUF: a per-thread pointer
+                                              : reinterpret_cast<const char*>(pf_c + (int64_t)(tid / (LPR > 0 ? LPR : 1)) * pf_ld) + (tid % (LPR > 0 ? LPR : 1)) * 128;
         int left = nk - kc0;                    // chunks of this tile still to be multiplied (>= 1)
         int pfv = 0;
         auto pf_tick = [&]() {
             asm volatile("" ::"v"(pfv));        // (the previous one is back: it is a chunk old)
             const int j = left - 3;             // chunks left - 3 = PFN - 1 ... 0: the tile's last lines go last
-            const char* a = (pf_lane != nullptr && j >= 0 && j < PFN) ? pf_lane + j * pf_step : reinterpret_cast<const char*>(pa[0]);
-            pfv = *reinterpret_cast<const int*>(a);
+            const bool on = pf_on && j >= 0 && j < PFN;         // (uniform)
+            if constexpr (BUF) {
+                pfv = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc(on ? pf_base + j * pf_step : ua), on ? pf_off : la, 0, 0);
+            } else {
+                const char* a = on ? pf_lane + j * pf_step : reinterpret_cast<const char*>(pa[0]);
+                pfv = *reinterpret_cast<const int*>(a);
+            }
         };
         // One chunk.  On entry: LDS stage `stage` holds the chunk, fragment set 0 its phase 0, qa / qb the next chunk; it writes that
         // one to the other stage, requests the one after it and reads the next chunk's phase 0 at the end.
@@ -476,14 +543,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
             for (int q = 0; q < NSL; ++q) {          // phase 0: multiply set 0, read phase 1 into set 1, write the next chunk
                 f_mma1(F0{}, q);
-                f_read1(F1{}, stage, 1, q);
+                f_reads(F1{}, stage, 1, q, RPS);
                 if constexpr (W) g_commit1(stage ^ 1, q);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int q = 0; q < NSL; ++q) {          // phase 1: multiply set 1, read phase 2 into set 0, request the chunk after next
                 f_mma1(F1{}, q);
-                f_read1(F0{}, stage, 2, q);
+                f_reads(F0{}, stage, 2, q, RPS);
                 if constexpr (G) g_issue1(q);
                 if (q == NSL - 1) pf_tick();         // (behind the chunk's own loads: nothing younger than it is waited for within the next chunk)
                 __builtin_amdgcn_sched_barrier(0);
@@ -491,7 +558,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
             for (int q = 0; q < NSL; ++q) {          // phase 2: multiply set 0, read phase 3 into set 1
                 f_mma1(F0{}, q);
-                f_read1(F1{}, stage, 3, q);
+                f_reads(F1{}, stage, 3, q, RPS);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -503,10 +570,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
 #pragma unroll
             for (int q = NSL / 2; q < NSL; ++q) {    // phase 3, second half: read phase 0 of the next chunk into set 0
                 f_mma1(F1{}, q);
-                if constexpr (W) {
-                    f_read1(F0{}, stage ^ 1, 0, 2 * (q - NSL / 2));
-                    f_read1(F0{}, stage ^ 1, 0, 2 * (q - NSL / 2) + 1);
-                }
+                if constexpr (W) f_reads(F0{}, stage ^ 1, 0, q - NSL / 2, RPS2);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };

@@ -1027,7 +1027,7 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
         g.split_from = INT32_MAX;
         g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
         g.vec_ok = aligned ? 1 : 0;
-        fill_edge = !aligned || (mf % 128) || (fill_k % Traits<T>::BK);
+        fill_edge = !aligned || (mf % 128) || (fill_k % Traits<T>::BK) || g.lda >= GPK_PIPE_LD_MAX;
         pa.fill_tiles = g.tiles_m * (g.tiles_m + 1) / 2;
         // the panel is chain-bound: a third of the chip keeps its task list moving, the rest starts with the fill tiles
         workers = cus - 1;
