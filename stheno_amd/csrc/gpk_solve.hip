@@ -211,7 +211,7 @@ int gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda
 // Batched TRSV, one workgroup per matrix (many small independent factors: stheno's batched computation): the whole solve of
 // one right-hand-side set runs inside ONE workgroup -- no inter-workgroup dependency, one launch instead of 2 x n/128 --
 // left-looking over 128-blocks:   r_q -= L[q, 0:q] x[0:q]  (rows read once, contiguously),   x_q = inv(L_qq) r_q.
-// x lives in LDS; a wave owns a row at a time (lanes across the columns, 16-byte loads, wave reduction).  HBM-bound: the
+// x lives in LDS; a wave owns eight rows at a time (lanes across the columns, 16-byte loads, wave reduction).  HBM-bound: the
 // lower triangle and the inverted diagonal blocks are read once.  nrhs <= NR.
 // ---------------------------------------------------------------------------
 template <typename T, int NR>
@@ -238,50 +238,78 @@ __global__ __launch_bounds__(256) void trsv_batched_kernel(const T* __restrict__
         const int r0 = q * GPK_DB;
         // 1. r_q -= L[q-block rows, 0:r0] x[0:r0]
         if (q > 0) {
-            for (int rr = wave; rr < GPK_DB; rr += 4) {
-                const int row = r0 + rr;
-                if (row >= n) break;                           // (uniform per wave)
-                T acc[NR];
+            // RU rows per wave at a time: one WG streams its matrix alone (two WGs per CU at a batch of 512), so what it gets out of
+            // the memory system is what it keeps in flight -- RU 16-byte loads per lane instead of one (round 4: 512 x 2048^2 fp32
+            // 1.53 -> see profiles/r04_experiments.md section 13)
+            constexpr int RU = 8;
+            for (int g = 0; g < GPK_DB / (4 * RU); ++g) {
+                const int rbase = r0 + (g * 4 + wave) * RU;          // rows rbase .. rbase + RU - 1 (uniform per wave)
+                if (rbase >= n) break;
+                T acc[RU][NR];
 #pragma unroll
-                for (int c = 0; c < NR; ++c) acc[c] = T(0);
-                const T* __restrict__ lrow = Lb + (int64_t)row * ld;
+                for (int u = 0; u < RU; ++u)
+#pragma unroll
+                    for (int c = 0; c < NR; ++c) acc[u][c] = T(0);
                 if (vec_ok) {
                     for (int k = lane * VEC; k < r0; k += 64 * VEC) {
-                        const vec_t lv = *reinterpret_cast<const vec_t*>(lrow + k);
+                        vec_t lv[RU];
+#pragma unroll
+                        for (int u = 0; u < RU; ++u) {
+                            const int row = (rbase + u < n) ? rbase + u : n - 1;      // (past the end: a valid row, result dropped)
+                            lv[u] = *reinterpret_cast<const vec_t*>(Lb + (int64_t)row * ld + k);
+                        }
 #pragma unroll
                         for (int v = 0; v < VEC; ++v)
 #pragma unroll
-                            for (int c = 0; c < NR; ++c) acc[c] += lv[v] * xs[(k + v) * NR + c];
+                            for (int c = 0; c < NR; ++c) {
+                                const T xv = xs[(k + v) * NR + c];
+#pragma unroll
+                                for (int u = 0; u < RU; ++u) acc[u][c] += lv[u][v] * xv;
+                            }
                     }
                 } else {
                     for (int k = lane; k < r0; k += 64)
 #pragma unroll
-                        for (int c = 0; c < NR; ++c) acc[c] += lrow[k] * xs[k * NR + c];
+                        for (int u = 0; u < RU; ++u) {
+                            const int row = (rbase + u < n) ? rbase + u : n - 1;
+                            const T lv = Lb[(int64_t)row * ld + k];
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) acc[u][c] += lv * xs[k * NR + c];
+                        }
                 }
 #pragma unroll
-                for (int c = 0; c < NR; ++c) {
-                    T v = acc[c];
+                for (int u = 0; u < RU; ++u)
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    acc[c] = v;
-                }
+                    for (int c = 0; c < NR; ++c) {
+                        T v = acc[u][c];
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                        acc[u][c] = v;
+                    }
                 if (lane == 0) {
 #pragma unroll
-                    for (int c = 0; c < NR; ++c) xs[row * NR + c] -= acc[c];
+                    for (int u = 0; u < RU; ++u)
+                        if (rbase + u < n) {
+#pragma unroll
+                            for (int c = 0; c < NR; ++c) xs[(rbase + u) * NR + c] -= acc[u][c];
+                        }
                 }
             }
             __syncthreads();
         }
         // 2. x_q = inv(L_qq) r_q   (128 x 128 block, identity-padded past n): results held until every wave has read r_q
         const T* __restrict__ Wq = Wb + (int64_t)q * GPK_DB * GPK_DB;
-        T res[GPK_DB / 4][NR];
+        // (two rows per wave at a time, one per half-wave: a 128-element row is 32 lanes of 16 bytes in fp32)
+        const int half = lane >> 5, l32 = lane & 31;
+        T res[GPK_DB / 8][NR];
 #pragma unroll
-        for (int j = 0; j < GPK_DB / 4; ++j) {
-            const int rr = wave + 4 * j;
+        for (int j = 0; j < GPK_DB / 8; ++j) {
+            const int rr = wave + 4 * (2 * j + half);
             T acc[NR];
 #pragma unroll
             for (int c = 0; c < NR; ++c) acc[c] = T(0);
-            for (int k = lane * VEC; k < GPK_DB; k += 64 * VEC) {
+#pragma unroll
+            for (int k = l32 * VEC; k < GPK_DB; k += 32 * VEC) {
                 const vec_t wv = *reinterpret_cast<const vec_t*>(Wq + (int64_t)rr * GPK_DB + k);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
@@ -292,16 +320,16 @@ __global__ __launch_bounds__(256) void trsv_batched_kernel(const T* __restrict__
             for (int c = 0; c < NR; ++c) {
                 T v = acc[c];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                 res[j][c] = v;
             }
         }
         __syncthreads();
-        if (lane == 0) {
+        if (l32 == 0) {
 #pragma unroll
-            for (int j = 0; j < GPK_DB / 4; ++j)
+            for (int j = 0; j < GPK_DB / 8; ++j)
 #pragma unroll
-                for (int c = 0; c < NR; ++c) xs[(r0 + wave + 4 * j) * NR + c] = res[j][c];
+                for (int c = 0; c < NR; ++c) xs[(r0 + wave + 4 * (2 * j + half)) * NR + c] = res[j][c];
         }
         __syncthreads();
     }

@@ -1660,6 +1660,17 @@ int main(int argc, char** argv) {
                 const float ms = tm.stop();
                 if (rep) printf("BATCHED potrf_f32 512x2048 nbo=%d  %.3f ms  %.2f TFLOP/s\n", nbo, ms, batch * (double)n * n * n / 3.0 / ms * 1e-9);
             }
+            // the forward solve of one right-hand side per matrix (the quadratic form of the log-density)
+            auto hy = randv<float>((size_t)batch * n);
+            Dev<float> Y(hy.size());
+            for (int rep = 0; rep < 4; ++rep) {
+                Y.up(hy);
+                tm.start();
+                gpk_trsv_lower(GPK_F32, K.p, n, n, (int64_t)n * n, dinv.p, 128, Y.p, 1, 1, n, nullptr, batch, nullptr);
+                const float ms = tm.stop();
+                if (rep) printf("BATCHED trsv_f32 512x2048  %.3f ms  %.2f TB/s (lower triangle + inverted diagonal blocks)\n", ms,
+                                batch * (0.5 * n * (double)(n - 128) + 128.0 * n) * sizeof(float) / ms * 1e-9);
+            }
             return 0;
         }
         if (!strcmp(argv[i], "--cumask")) { cumask_experiment(); return 0; }
