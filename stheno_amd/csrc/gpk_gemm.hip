@@ -226,7 +226,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             if (ok && k.quarter) {              // the last, partial round of the launch: 64 x 64 quarters of a 128-tile
                 const int ti2 = 2 * k.ti + (k.quad >> 1), tj2 = 2 * k.tj + (k.quad & 1);
                 if (!((g.lower_only && tj2 > ti2) || ti2 * 64 >= g.M || tj2 * 64 >= g.N))
-                    gemm_tile<T, 64, true, true, EDGE, 1, NW>(g, ti2, tj2, 0, 0, smem, nullptr);
+                    gemm_tile<T, 64, true, true, EDGE, 1, NW, false, 1>(g, ti2, tj2, 0, 0, smem, nullptr);
                 ok = false;
             }
         }
@@ -248,7 +248,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             }
 #pragma unroll 1
             for (int r = 0; r < k.reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
-                gemm_tile<T, TS, true, true, EDGE, 1, NW>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr,
+                gemm_tile<T, TS, true, true, EDGE, 1, NW, false, 1>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr,
                                                           (r == k.reps - 1) ? pf_c : nullptr, pf_ld);
             if (p.sig[k.sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
                 __syncthreads();               // every wave's stores of the tile are out (vmcnt drained before the barrier)

@@ -8,9 +8,10 @@
 #include <type_traits>
 
 // The k loop of the 128-tile: 0 = one chunk of global loads in flight, MFMA phase, write phase, barrier (rounds 1-3);
-// 1 = the software-pipelined loop (see gemm_tile).  A build-time switch: both loops in one kernel cost registers.
+// 1 = the software-pipelined loop (see gemm_tile), 2 = ... and a ragged K's partial last chunk behind it (bounds-checked kernels; the
+// persistent kernels, whose K is a panel width, pass 1).  A build-time switch: both loops in one kernel cost registers.
 #ifndef GPK_GEMM_PIPE
-#define GPK_GEMM_PIPE 1
+#define GPK_GEMM_PIPE 2
 #endif
 #ifndef GPK_GEMM_PIPE64
 #define GPK_GEMM_PIPE64 1      // ... for the 64-tile too
@@ -367,7 +368,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // (round 4, later: the 64-tile -- 32 x 32 per wave, four workgroups per CU: the narrow panel / solve GEMMs, 23 % of a cfg2 step -- takes
     // the same loop with four slices per phase instead of eight)
     constexpr bool PIPE_KERNEL = PIPE != 0 && NCT == 1 && !TRIB && NW == 4 && (TS == 128 || (TS == 64 && GPK_GEMM_PIPE64 != 0));
-    const bool pipe_tile = PIPE_KERNEL && (!EDGE || (a_in && b_in && p.K % BK == 0));
+    // A ragged K (bounds-checked kernels): the loop takes the whole chunks, the last, partial chunk goes through the bounds-checked
+    // loads of the loop below, once (round 4: with `p.K % BK == 0` as a condition EVERY tile of such a problem took the loop below,
+    // which in the fp64 kernels -- both loops in one function, 256 registers -- runs with spills: fp64 15000^2 K = 1000 21 TFLOP/s
+    // against 55 at K = 1024)
+    const bool k_tail = EDGE && PIPE_KERNEL && PIPE >= 2 && (nk * BK > p.K);
+    const int nk_pipe = k_tail ? nk - 1 : nk;
+    // A ragged M / N (bounds-checked kernels): the tiles on the matrix edge take the loop too -- rows past the end of an operand are
+    // CLAMPED to its last row when the per-thread pointers are set up (nothing changes inside the loop): those rows of the product
+    // are computed from duplicates and never stored.  (An operand stored K x M, rows of it contiguous, needs M to be a whole number of
+    // 16-byte vectors for that.)  Round 4: fp64 8000 x 2000 x 15008 ran at 21 TFLOP/s because its 78 edge tiles of 1008 took the loop
+    // below -- in the fp64 kernels with spills, 3 x slower per tile -- and sat at the end of the launch.
+    // (PIPE >= 2 only: the persistent fp64 kernel answered one more `min` per pointer with spills inside the loop)
+    constexpr bool CLAMP = PIPE >= 2;
+    const bool a_ok = a_in || (CLAMP && EDGE && p.vec_ok && (A_KMAJ || (p.M % VEC_ == 0 && p.M >= VEC_)));
+    const bool b_ok = b_in || (CLAMP && EDGE && p.vec_ok && (B_KMAJ || (p.N % VEC_ == 0 && p.N >= VEC_)));
+    const bool pipe_tile = PIPE_KERNEL && (!EDGE || (a_ok && b_ok && nk_pipe > kc0 && (PIPE >= 2 || p.K % BK == 0)));
     if constexpr (PIPE_KERNEL) if (pipe_tile) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         typedef typename std::conditional<sizeof(T) == 8, double, f32x2>::type frag_t;
@@ -412,21 +428,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
             passA = __builtin_amdgcn_readfirstlane((unsigned)RPP_A * (unsigned)p.lda * (unsigned)sizeof(T));
             passB = __builtin_amdgcn_readfirstlane((unsigned)RPP_B * (unsigned)p.ldb * (unsigned)sizeof(T));
         } else {
-            auto init_ptrs = [&](const T* (&ptr)[NV], auto kmaj_c, const T* base, int64_t ld, int r0) {
+            auto init_ptrs = [&](const T* (&ptr)[NV], auto kmaj_c, const T* base, int64_t ld, int r0, int R) {      // R: rows of the operand
                 constexpr bool KMAJ = decltype(kmaj_c)::value;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     if (KMAJ) {
-                        ptr[i] = base + (int64_t)(r0 + (tid >> 3) + (NT / 8) * i) * ld + (int64_t)kc0 * BK + (tid & 7) * VEC_;
+                        const int row = CLAMP ? min(r0 + (tid >> 3) + (NT / 8) * i, R - 1) : r0 + (tid >> 3) + (NT / 8) * i;
+                        ptr[i] = base + (int64_t)row * ld + (int64_t)kc0 * BK + (tid & 7) * VEC_;
                     } else {
                         constexpr int CPR = TS / VEC_;
                         const int id = tid + NT * i;
-                        ptr[i] = base + ((int64_t)kc0 * BK + id / CPR) * ld + r0 + (id % CPR) * VEC_;
+                        const int col = CLAMP ? min(r0 + (id % CPR) * VEC_, R - VEC_) : r0 + (id % CPR) * VEC_;
+                        ptr[i] = base + ((int64_t)kc0 * BK + id / CPR) * ld + col;
                     }
                 }
             };
-            init_ptrs(pa, std::integral_constant<bool, A_KMAJ>{}, A, p.lda, m0);
-            init_ptrs(pb, std::integral_constant<bool, B_KMAJ>{}, B, p.ldb, n0);
+            init_ptrs(pa, std::integral_constant<bool, A_KMAJ>{}, A, p.lda, m0, p.M);
+            init_ptrs(pb, std::integral_constant<bool, B_KMAJ>{}, B, p.ldb, n0, p.N);
         }
         // a chunk along k, in bytes (BUF) / elements (!BUF)
         const int64_t stepA = (A_KMAJ ? (int64_t)BK : (int64_t)BK * p.lda) * (BUF ? (int64_t)sizeof(T) : 1);
@@ -449,7 +467,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                 else { qb[j - NV] = *reinterpret_cast<const vec_t*>(pb[j - NV]); pb[j - NV] += curB; }
             }
         };
-        int adv = nk - kc0 - 1;                 // how many more times they may move on
+        int adv = nk_pipe - kc0 - 1;            // how many more times they may move on
         auto g_arm = [&]() { curA = adv > 0 ? stepA : 0; curB = adv > 0 ? stepB : 0; --adv; };
         // one vector of the next chunk: registers -> LDS stage
         auto g_commit1 = [&](int stage, int j) {
@@ -521,7 +539,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         const char* pf_base = BUF ? uni(pf_c) : nullptr;        // BUF: uniform origin + one 32-bit lane offset, like the operands
         const char* pf_lane = (BUF || !pf_on) ? nullptr          // !BUF: a per-thread pointer
                                               : reinterpret_cast<const char*>(pf_c + (int64_t)(tid / (LPR > 0 ? LPR : 1)) * pf_ld) + (tid % (LPR > 0 ? LPR : 1)) * 128;
-        int left = nk - kc0;                    // chunks of this tile still to be multiplied (>= 1)
+        int left = nk_pipe - kc0;               // chunks of this tile still to be multiplied (>= 1)
         int pfv = 0;
         auto pf_tick = [&]() {
             asm volatile("" ::"v"(pfv));        // (the previous one is back: it is a chunk old)
@@ -596,6 +614,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         }
         asm volatile("" ::"v"(pfv));
     }
+    if (EDGE && PIPE >= 2 && pipe_tile && k_tail) {          // the partial last chunk
+        issue(S0{}, nk - 1);
+        __syncthreads();                        // (the waves' last fragment reads of the loop above)
+        commit(S0{}, 0);
+        __syncthreads();
+        mma(0, nk - 1);
+        __syncthreads();
+    }
     if (!pipe_tile) {
     if (PF2) {
         issue(S0{}, kc0);
@@ -637,7 +663,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     // Fused column statistics / scaling (round 4; `gpk_gemm_colscale`, what SURVEY 8(b) called gpk_syrk_scaled, split where the path
     // needs it): V = L_z^{-1} K_zx leaves this kernel already multiplied by K_n^{-1/2} per column, and the column sums of squares of the
     // unscaled V (`B.matmul_diag`, observations.py:305) are written per 64-row slab on the way -- the stand-alone scaling pass and the
-    // reduction pass over the 3.3 GB of V are gone.  Rows beyond M of a ragged tile hold zeros (their A rows were loaded as zeros).
+    // reduction pass over the 3.3 GB of V are gone.
     if constexpr (TS == 128 && NCT == 1 && NW == 4 && !TRIB) {
         if (p.colscale != nullptr || p.colss != nullptr) {
 #pragma unroll
@@ -649,7 +675,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
                 for (int fi = 0; fi < FRM; ++fi)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const T v = p.alpha * acc[0][fi][fj][i];
+                        const bool rvalid = !EDGE || m0 + wm * WTM + fi * 16 + Traits<T>::crow(lane, i) < p.M;      // (rows past M: computed from clamped rows)
+                        const T v = rvalid ? p.alpha * acc[0][fi][fj][i] : T(0);
                         ss += v * v;
                     }
                 ss += __shfl_xor(ss, 16);

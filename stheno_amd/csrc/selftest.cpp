@@ -205,6 +205,13 @@ static void test_gemm() {
     test_gemm_case<T>(false, false, 3000, 3100, 50, 1, 1, 1, false, 1);
     test_gemm_case<T>(true, false, 4100, 4100, 40, -1, 1, 1, true, 0);
     test_gemm_case<T>(false, true, 3072, 3328, 48, 1, 0, 1, false, 0);
+    // ragged M, N AND K with aligned operands: the edge tiles take the pipelined loop on clamped rows, the partial last k-chunk goes
+    // through the bounds-checked loads behind it (round 4); an operand stored K x M whose M is not a whole number of vectors does not
+    test_gemm_case<T>(true, true, 1000, 900, 1000, -1, 1, 1, false, 0);
+    test_gemm_case<T>(true, false, 1000, 904, 336, 1, 0, 1, false, 0);
+    test_gemm_case<T>(false, true, 1000, 904, 336, -1, 1, 1, false, 0);
+    test_gemm_case<T>(false, false, 1026, 1030, 200, 1, 1, 1, false, 2);
+    test_gemm_case<T>(true, true, 777, 777, 1000, -1, 1, 1, true, 0);
 }
 
 // ----------------------------------------------------------------------------
