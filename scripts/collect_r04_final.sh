@@ -47,4 +47,6 @@ done
 cd $R/stheno_amd/csrc
 [ $(left) -gt 60 ] && timeout 50 ./gpk_selftest --perf-trsm > $O/r04_native_perf_trsm.log 2>&1
 [ $(left) -gt 80 ] && timeout 70 ./gpk_selftest --perf-la > $O/r04_native_perf_lookahead.log 2>&1
+cd /tmp
+[ $(left) -gt 60 ] && GPK_BENCH_FORCE_DIST=1 NCCL_DEBUG=WARN MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 50 python $R/bench.py --gpus 1 --workload batched_f32 --no-cpu-baseline 2>/dev/null | grep "^{" | tail -1 > $O/r04_bench_batched_f32_rccl_1rank.json
 echo "finished at $SECONDS s"

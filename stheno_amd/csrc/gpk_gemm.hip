@@ -156,7 +156,10 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
     // both operands are k-contiguous: their LDS images use TS * 128 of each op_bytes(TS) slot; the broadcast
     // word lives in the unused tail of the first slot (one more byte of LDS would cost the 64-tile kernel
     // its fourth workgroup per CU)
-    volatile int& s_tile = *reinterpret_cast<volatile int*>(smem + TS * 128);
+    // (an explicit LDS pointer: through a generic `volatile int&` the compiler emitted FLAT loads / stores for this word, and a flat
+    // load's s_waitcnt vmcnt(0) at the hand-over waited for the finished tile's stores to drain)
+    typedef __attribute__((address_space(3))) volatile int lds_word_t;
+    lds_word_t& s_tile = *(lds_word_t*)(uint32_t)(uintptr_t)(smem + TS * 128);
     const int tid = threadIdx.x;
     if (p.reserve) {
         if (tid == 0) {
@@ -217,8 +220,11 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
     int nlocal = 0;
     int t = claim_now(), tn = claim_now();
     while (t < p.ntasks) {
-        int nxt = 0;
-        if (tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);       // the task after `tn`
+        // The claim for the task after `tn` is made INSIDE the tile body, between its k loop and its stores (gemm_tile, claim_ctr): there
+        // nothing else of the wave is outstanding, so the wait for the atomic's result costs its own round trip and no more.  At the top
+        // of the iteration -- where it used to be -- the compiler's s_waitcnt vmcnt(0) behind it also waited for the previous tile's
+        // stores to drain, BEFORE this tile's C tile was even requested.
+        int nxt = -1;
         const Task k = decode(t);
         const GemmArgs<T>& g = p.seg[k.sgi];
         bool ok = k.ok;
@@ -249,7 +255,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
 #pragma unroll 1
             for (int r = 0; r < k.reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
                 gemm_tile<T, TS, true, true, EDGE, 1, NW, false, 1>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr,
-                                                          (r == k.reps - 1) ? pf_c : nullptr, pf_ld);
+                                                                    (r == k.reps - 1) ? pf_c : nullptr, pf_ld, (r == k.reps - 1) ? &p.ctrl[0] : nullptr, &nxt);
             if (p.sig[k.sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
                 __syncthreads();               // every wave's stores of the tile are out (vmcnt drained before the barrier)
                 if (tid == 0) {
@@ -259,6 +265,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
                 }
             }
         }
+        if (!ok && tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);      // (no full tile body ran: a quarter tile of the last round, an empty task)
         if (tid == 0) s_tile = nxt;
         lds_barrier();
         t = tn;

@@ -151,6 +151,7 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
     return *reinterpret_cast<const T*>(lds + off);
 }
 
+// claim_ctr / claimed (persistent kernel): see the claim below the k loop.
 // pf_c / pf_ld (pipelined 128-tile only): first element and leading dimension of the C tile this workgroup will READ NEXT (the
 // persistent kernel knows its next task).  Round 4, from the per-tile time stamps (profiles/r04_gemm_checks_tileprof_1.log): a
 // workgroup waits 20-45 us for the 1024 cache lines of its C tile (HBM misses, a few dozen in flight per CU) before its first
@@ -173,7 +174,8 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
 template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false, int PIPE = GPK_GEMM_PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
-                                          long long* prof = nullptr, const T* pf_c = nullptr, int64_t pf_ld = 0) {
+                                          long long* prof = nullptr, const T* pf_c = nullptr, int64_t pf_ld = 0,
+                                          unsigned* claim_ctr = nullptr, int* claimed = nullptr) {
     if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
@@ -659,6 +661,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
         prof[2] = wall_clock64();
         prof[5] = (long long)__builtin_readcyclecounter();
     }
+    // (persistent kernel) thread 0 claims the workgroup's next-but-one task HERE: no load and no store of this wave is outstanding, so
+    // waiting for the atomic's result costs one round trip of wave 0 and nothing else
+    if (claim_ctr != nullptr && threadIdx.x == 0) *claimed = (int)atomicAdd(claim_ctr, 1u);
     // (in-place use: every global read of this workgroup's rows of A happened above)
     // Fused column statistics / scaling (round 4; `gpk_gemm_colscale`, what SURVEY 8(b) called gpk_syrk_scaled, split where the path
     // needs it): V = L_z^{-1} K_zx leaves this kernel already multiplied by K_n^{-1/2} per column, and the column sums of squares of the
