@@ -70,7 +70,10 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
 
 // NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
 // Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT = 1>
+// PIPE: which k loops the tile body holds (gemm_tile).  0 = the bounds-checked round-1 loop ONLY: what UNALIGNED fp64 problems are
+// sent to -- in the kernel that holds both loops the fp64 tile body needs 256 registers and 360-480 bytes of scratch, most of it in
+// that loop (3 x slower per tile); on its own it needs none.
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT = 1, int PIPE = GPK_GEMM_PIPE>
 __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_kernel(GemmArgs<T> p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (1 + NCT) * op_bytes(TS)];
     int ti, tj;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
             if (!decode_tile(p, p.split_from + (qd >> 2), ti, tj)) return;
             const int ti2 = 2 * ti + ((qd >> 1) & 1), tj2 = 2 * tj + (qd & 1);
             if ((p.lower_only && tj2 > ti2) || ti2 * 64 >= p.M || tj2 * 64 >= p.N) return;
-            gemm_tile<T, 64, A_KMAJ, B_KMAJ, EDGE, 1>(p, ti2, tj2, blockIdx.y, blockIdx.z, smem);
+            gemm_tile<T, 64, A_KMAJ, B_KMAJ, EDGE, 1, 4, false, PIPE>(p, ti2, tj2, blockIdx.y, blockIdx.z, smem);
             return;
         }
     }
@@ -90,11 +93,11 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
         const int m = (s / p.xcd_tiles) * 8 + (L & 7);
         if (m >= p.xcd_batch) return;
         if (!decode_tile(p, s % p.xcd_tiles, ti, tj)) return;
-        gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, m, 0, smem);
+        gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT, 4, false, PIPE>(p, ti, tj, m, 0, smem);
         return;
     }
     if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
-    gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
+    gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT, 4, false, PIPE>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
 
 // The panel solve of the blocked Cholesky,  P <- P inv(L_cc)^T  (both operands k-contiguous, one workgroup owns all 128 columns of its
@@ -289,16 +292,16 @@ __global__ __launch_bounds__(256, (TS == 128 ? 2 : 4)) void gemm_persist_helper_
     persist_body<T, TS, EDGE>(p, smem);
 }
 
-template <typename T, int TS, bool EDGE>
+template <typename T, int TS, bool EDGE, int PIPE = GPK_GEMM_PIPE>
 void launch_layout(bool a_kmaj, bool b_kmaj, dim3 grid, hipStream_t stream, const GemmArgs<T>& args) {
     if (a_kmaj && b_kmaj)
-        hipLaunchKernelGGL((gemm_kernel<T, TS, true, true, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, true, true, EDGE, 1, PIPE>), grid, dim3(256), 0, stream, args);
     else if (a_kmaj && !b_kmaj)
-        hipLaunchKernelGGL((gemm_kernel<T, TS, true, false, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, true, false, EDGE, 1, PIPE>), grid, dim3(256), 0, stream, args);
     else if (!a_kmaj && b_kmaj)
-        hipLaunchKernelGGL((gemm_kernel<T, TS, false, true, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, false, true, EDGE, 1, PIPE>), grid, dim3(256), 0, stream, args);
     else
-        hipLaunchKernelGGL((gemm_kernel<T, TS, false, false, EDGE>), grid, dim3(256), 0, stream, args);
+        hipLaunchKernelGGL((gemm_kernel<T, TS, false, false, EDGE, 1, PIPE>), grid, dim3(256), 0, stream, args);
 }
 
 // ---- measurement hook: HIP events around every GEMM launch (opt-in, see gpk.h) ----
@@ -528,6 +531,11 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, true, 2>), grid, dim3(256), 0, stream, g);
         else
             hipLaunchKernelGGL((gemm_kernel<T, 64, true, true, false, 2>), grid, dim3(256), 0, stream, g);
+    } else if (sizeof(T) == 8 && !aligned) {        // (unaligned fp64: the kernels that hold the bounds-checked loop only, see gemm_kernel)
+        if constexpr (sizeof(T) == 8) {
+            if (ts == 128) launch_layout<T, 128, true, 0>(a_kmaj, b_kmaj, grid, stream, g);
+            else launch_layout<T, 64, true, 0>(a_kmaj, b_kmaj, grid, stream, g);
+        }
     } else if (ts == 128) {
         if (edge)
             launch_layout<T, 128, true>(a_kmaj, b_kmaj, grid, stream, g);
