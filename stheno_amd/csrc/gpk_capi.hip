@@ -138,6 +138,8 @@ int gpk_gemm_colscale(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t 
                       const void* a, int64_t lda, const void* b, int64_t ldb, void* c, int64_t ldc, int flags,
                       const void* colscale, void* colss, int64_t ldss, void* stream) {
     if (colss != nullptr && ldss < n) return GPK_ERR_ARG(17);
+    // the fused epilogue lives in the plain 128-tile kernel only: bit 0 (lower-only) and bit 4 (the panel-solve kernel) have no such epilogue
+    if ((flags & ~(2 | 4 | 8)) != 0) return GPK_ERR_ARG(13);
     D1(dtype, gpk_gemm_launch2<T>(a_kmajor != 0, b_kmajor != 0, m, n, k, (T)alpha, (const T*)a, lda, 0, 0, (const T*)b, ldb, 0, 0,
                                   (T)0, (T*)c, ldc, 0, 0, 1, 1, flags, (hipStream_t)stream, (const T*)colscale, (T*)colss, ldss));
 }

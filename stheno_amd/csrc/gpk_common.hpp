@@ -134,10 +134,16 @@ struct GpkSeg {
     int lower_only;
     int tri_b;      // B (N x K) is lower triangular: k stops at the column tile's last column (2: pair column tiles c, n-1-c)
     int signal;     // every finished tile of this segment is announced: ctrl[2] += 1 behind an agent-scope release (somebody polls it)
+    // Round 5 (aggregated trailing updates of the look-ahead Cholesky): a square lower-only segment restricted to COLUMN GROUPS --
+    // group g = columns [g grp, (g + 1) grp) and the rows from g grp down; bit g of colmask set = the group is part of the segment
+    // (0 = every column: the whole lower triangle).  grp: a multiple of 128.
+    uint64_t colmask;
+    int64_t grp;
 };
-// Cin == nullptr: C = alpha * A B^T (nothing is read from C).  Up to three segments per launch, handed out in order.
+// Cin == nullptr: C = alpha * A B^T (nothing is read from C).  Up to GPK_PERSIST_MAX_SEG segments per launch, handed out in order.
+#define GPK_PERSIST_MAX_SEG 4
 struct GpkPersistSaved {       // what a reserving launch was made of, for gpk_gemm_persist_rejoin
-    alignas(16) char bytes[1024];
+    alignas(16) char bytes[2048];
     int ts, edge, per_cu, valid;
     int signal_tiles;          // tiles of the segments with `signal` set: what ctrl[2] counts up to (set whenever `saved` is given)
 };

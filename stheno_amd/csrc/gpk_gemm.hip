@@ -67,6 +67,40 @@ __device__ __forceinline__ bool decode_tile(const GemmArgs<T>& p, int bid, int& 
     return ti < p.tiles_m && (!p.lower_only || tj <= ti);
 }
 
+// A square lower-only problem restricted to column groups (GemmArgs::colmask; persistent kernel): group g = tile columns
+// [g W, (g + 1) W) with the tile rows from g W down -- a triangle of W (W + 1) / 2 tiles on the diagonal, full rows of W below.
+// Groups in ascending order, inside a group the triangle first, then row-major.  Everything here is wave-uniform scalar work
+// (at most 64 groups), twice per tile.
+template <typename T>
+__device__ __forceinline__ bool decode_striped(const GemmArgs<T>& p, int bid, int& ti, int& tj) {
+    unsigned long long m = p.colmask;
+    const int W = p.grp_tiles;
+    int rem = bid;
+    while (m != 0ull) {
+        const int g = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int c0 = g * W;
+        if (c0 >= p.tiles_n) break;
+        const int w = min(W, p.tiles_n - c0);
+        const int head = w * (w + 1) / 2;
+        const int cnt = head + (p.tiles_m - c0 - w) * w;
+        if (rem < cnt) {
+            if (rem < head) {
+                int i, j;
+                tri_decode(rem, i, j);
+                ti = c0 + i; tj = c0 + j;
+            } else {
+                rem -= head;
+                const int r = rem / w;
+                ti = c0 + w + r; tj = c0 + (rem - r * w);
+            }
+            return true;
+        }
+        rem -= cnt;
+    }
+    ti = tj = 0;
+    return false;
+}
 
 // NCT: column tiles per workgroup (1, or 2 = a TS x 2TS output: the in-place panel TRSM of the
 // Cholesky needs ONE workgroup to own all 128 columns of its rows -- see gpk_gemm_launch2).
@@ -142,9 +176,9 @@ __global__ __launch_bounds__(256, 4) void gemm_trilo_pair_kernel(GemmArgs<T> p) 
 // ctrl[0] = tile counter, ctrl[1] = leavers; zeroed by the launcher (memset node) per launch.
 template <typename T>
 struct PersistArgs {
-    GemmArgs<T> seg[3];
-    int first[4];             // first tile of segment i (first[nseg] = all tiles; unused segments are empty)
-    int sig[3];               // GpkSeg::signal
+    GemmArgs<T> seg[GPK_PERSIST_MAX_SEG];
+    int first[GPK_PERSIST_MAX_SEG + 1];   // first tile of segment i (first[nseg] = all tiles; unused segments are empty)
+    int sig[GPK_PERSIST_MAX_SEG];         // GpkSeg::signal
     int ntiles;               // all tiles
     int ntasks, split_from;   // tasks = tiles, except that the tiles from split_from on are handed out as four quarter tiles each
     unsigned* ctrl;
@@ -200,7 +234,8 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
         k.quarter = (TS == 128) && t >= p.split_from;
         k.quad = k.quarter ? ((t - p.split_from) & 3) : 0;
         const int tt = k.quarter ? p.split_from + ((t - p.split_from) >> 2) : t;
-        k.sgi = (tt >= p.first[2]) ? 2 : ((tt >= p.first[1]) ? 1 : 0);
+        static_assert(GPK_PERSIST_MAX_SEG == 4, "segment selection below");
+        k.sgi = (tt >= p.first[2]) ? ((tt >= p.first[3]) ? 3 : 2) : ((tt >= p.first[1]) ? 1 : 0);
         k.ti = k.tj = 0;
         k.reps = 1;
         if (!k.ok) return k;
@@ -213,6 +248,8 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
             k.ti = tl / half;
             k.tj = tl - k.ti * half;
             k.reps = 2;
+        } else if (g.colmask != 0ull) {
+            k.ok = decode_striped(g, tl, k.ti, k.tj);
         } else {
             k.ok = decode_tile(g, tl, k.ti, k.tj);
         }
@@ -416,6 +453,9 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || batch > 65535 || batch2 > 65535)
         return GPK_ERR_ARG(3);
     if (alpha == T(0)) return GPK_ERR_ARG(6);   // scale-only is not a use of this path
+    if (K < 0) return GPK_ERR_ARG(3);
+    // the C tile's per-lane byte offsets are 32 bits (gemm_tile: up to 12 rows * ldc * sizeof(T))
+    if (ldc >= GPK_C_LD_MAX) return GPK_ERR_ARG(15);
     constexpr int VEC = Traits<T>::VEC;
     constexpr int BK = Traits<T>::BK;
 
@@ -453,7 +493,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.tri_k = (flags & 2) ? 1 : 0;
     g.tri_k_lo = (flags & 4) ? 1 : 0;
     g.tri_k_lo_b = (flags & 8) ? 1 : 0;
-    g.pair_cols = 0;
+    g.pair_cols = 0; g.colmask = 0; g.grp_tiles = 0;
 
     const bool tri = lower_only && g.tiles_m == g.tiles_n;
     const int64_t total = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2
@@ -463,7 +503,9 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % VEC == 0) &&
                          (ldb % VEC == 0) && (sA % VEC == 0) && (sB % VEC == 0) &&
                          (sA2 % VEC == 0) && (sB2 % VEC == 0);
-    const bool edge = !aligned || (M % ts) || (N % (ts * nct)) || (K % BK) || lda >= GPK_PIPE_LD_MAX || ldb >= GPK_PIPE_LD_MAX;
+    // (K < BK -- K = 0 above all, an empty contraction: C = beta C -- goes to the bounds-checked kernels: the pipelined loop of the
+    // others runs at least one chunk, `while (true) { chunk; if (--left == 0) break; }` with left = 0 would spin for 2^32 of them)
+    const bool edge = !aligned || (M % ts) || (N % (ts * nct)) || (K % BK) || K < BK || lda >= GPK_PIPE_LD_MAX || ldb >= GPK_PIPE_LD_MAX;
     g.vec_ok = aligned ? 1 : 0;
 
     // The last, partial round.  The hardware hands out workgroups in index order as slots free up, so with equal tiles the last
@@ -647,14 +689,32 @@ void gpk_helper_shutdown() {
     (void)hipSetDevice(cur);
 }
 
-// ---- persistent launch: up to two k-major problems  C = Cin + alpha * A B^T  in one resident grid ----
+// ---- persistent launch: up to GPK_PERSIST_MAX_SEG k-major problems  C = Cin + alpha * A B^T  in one resident grid ----
 
+// tiles of a square lower-only problem of order M restricted to column groups (decode_striped); area: the elements of C they cover,
+// counted as the library counts a symmetric update (the diagonal tiles' upper halves are not useful work)
+static int64_t striped_tiles(int64_t M, int ts, int64_t grp, uint64_t mask, double* area) {
+    const int64_t tiles = gpk_cdiv(M, ts), W = grp / ts;
+    int64_t n = 0;
+    for (int g = 0; g < 64; ++g) {
+        if (!((mask >> g) & 1u)) continue;
+        const int64_t c0 = g * W;
+        if (c0 >= tiles) break;
+        const int64_t w = (W < tiles - c0) ? W : tiles - c0;
+        n += w * (w + 1) / 2 + (tiles - c0 - w) * w;
+        if (area != nullptr) {
+            const double rows = (double)(M - g * grp), cols = rows < (double)grp ? rows : (double)grp;
+            *area += cols * rows - 0.5 * cols * cols;
+        }
+    }
+    return n;
+}
 
 template <typename T>
 int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* ctrl, int reserve,
                             hipStream_t stream, GpkPersistSaved* saved, bool ctrl_zeroed) {
     if (saved != nullptr) { saved->valid = 0; saved->signal_tiles = 0; }
-    if (nseg < 1 || nseg > 3) return GPK_ERR_ARG(2);
+    if (nseg < 1 || nseg > GPK_PERSIST_MAX_SEG) return GPK_ERR_ARG(2);
     if (ctrl == nullptr) return GPK_ERR_ARG(4);
     if (alpha == T(0)) return GPK_ERR_ARG(3);
     constexpr int VEC = Traits<T>::VEC;
@@ -664,6 +724,12 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         const GpkSeg<T>& q = segs[i];
         if (q.M > INT32_MAX || q.N > INT32_MAX || q.K > INT32_MAX || q.K <= 0) return GPK_ERR_ARG(1);
         if (q.M <= 0 || q.N <= 0) continue;
+        if (q.ldc >= GPK_C_LD_MAX || q.ldcin >= GPK_C_LD_MAX) return GPK_ERR_ARG(1);
+        if (q.colmask != 0) {        // column groups of a square lower-only problem
+            if (!q.lower_only || q.M != q.N || q.tri_b || q.grp < 128 || q.grp % 128 != 0) return GPK_ERR_ARG(1);
+            t128 += striped_tiles(q.M, 128, q.grp, q.colmask, nullptr);
+            continue;
+        }
         const int64_t tm = gpk_cdiv(q.M, 128), tn = gpk_cdiv(q.N, 128);
         t128 += (q.lower_only && tm == tn) ? tm * (tm + 1) / 2 : tm * tn;
     }
@@ -698,16 +764,21 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         int64_t nt = tri ? (int64_t)g.tiles_m * (g.tiles_m + 1) / 2 : (int64_t)g.tiles_m * g.tiles_n;
         g.pair_cols = (q.tri_b == 2 && !g.lower_only && g.tiles_n >= 2 && g.tiles_n % 2 == 0) ? 1 : 0;
         if (g.pair_cols) nt = (int64_t)g.tiles_m * (g.tiles_n / 2);
+        g.colmask = q.colmask; g.grp_tiles = q.colmask != 0 ? (int)(q.grp / ts) : 0;
+        double area = 0;            // elements of C the segment updates (striped segments)
+        if (q.colmask != 0) nt = striped_tiles(q.M, ts, q.grp, q.colmask, &area);
+        if (nt == 0) continue;
         pa.first[live] = (int)total;
         pa.sig[live] = q.signal ? 1 : 0;
         if (q.signal && saved != nullptr) saved->signal_tiles += (int)nt;
         total += nt;
-        flops += (q.lower_only || q.tri_b ? 1.0 : 2.0) * (double)q.M * (double)q.N * (double)q.K;
+        flops += q.colmask != 0 ? 2.0 * area * (double)q.K : (q.lower_only || q.tri_b ? 1.0 : 2.0) * (double)q.M * (double)q.N * (double)q.K;
         ++live;
     }
     if (total > INT32_MAX / 2) return GPK_ERR_ARG(1);
-    for (int i = live; i < 3; ++i) { pa.seg[i] = pa.seg[0]; pa.sig[i] = 0; }
-    for (int i = live; i <= 3; ++i) pa.first[i] = (int)total;      // (empty segments: never selected)
+    if (live == 0) return GPK_OK;
+    for (int i = live; i < GPK_PERSIST_MAX_SEG; ++i) { pa.seg[i] = pa.seg[0]; pa.sig[i] = 0; }
+    for (int i = live; i <= GPK_PERSIST_MAX_SEG; ++i) pa.first[i] = (int)total;      // (empty segments: never selected)
     pa.ntiles = (int)total;
     pa.ntasks = (int)total;
     pa.split_from = INT32_MAX;
@@ -875,7 +946,7 @@ int gpk_panel_step_launch(T* A, int64_t n, int64_t ld, int64_t c, const T* W, in
     g.M = (int)m; g.N = GPK_DB; g.K = GPK_DB;
     g.alpha = T(1); g.beta_over_alpha = T(0); g.has_beta = 0;
     g.tiles_m = (int)gpk_cdiv(m, ts); g.tiles_n = 1;
-    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
+    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0; g.colmask = 0; g.grp_tiles = 0;
     g.split_from = INT32_MAX;
     g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
     const bool aligned = ((uintptr_t)P % 16 == 0) && ((uintptr_t)W % 16 == 0) && (ld % VEC == 0);

@@ -23,6 +23,8 @@ namespace {
 constexpr int op_bytes(int ts) { return (ts + 16) * 128; }
 // leading dimensions (elements) from which the pipelined k loop's 32-bit operand offsets could overflow (128 rows * ld * 8 bytes < 2^32)
 constexpr int64_t GPK_PIPE_LD_MAX = (int64_t)1 << 21;
+// leading dimensions of C (elements) from which the per-lane 32-bit byte offset of a C fragment (<= 12 rows * ldc * 8 bytes) could overflow
+constexpr int64_t GPK_C_LD_MAX = (int64_t)1 << 25;
 
 template <typename T>
 struct GemmArgs {
@@ -48,6 +50,8 @@ struct GemmArgs {
     int64_t ldss;        //   [2 tiles_m][ldss] buffer (the caller adds the rows up) -- the pseudo-point path's Q_x_diag without a pass over V
     int xcd_batch;    // (knob 45) batched launch as a 1-D grid with all tiles of a matrix on ONE XCD: xcd_batch = batch size, else 0
     int xcd_tiles;    //   tiles per matrix of such a launch
+    unsigned long long colmask;   // persistent kernel, square lower-only segments: only the column groups named here (0: all) --
+    int grp_tiles;                //   group g = tile columns [g grp_tiles, (g + 1) grp_tiles), rows from its first column's tile down
     int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
                       // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };

@@ -748,7 +748,7 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
     g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
     g.M = p.m; g.K = GPK_DB;
     g.tiles_m = R;
-    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
+    g.lower_only = 0; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0; g.colmask = 0; g.grp_tiles = 0;
     g.split_from = INT32_MAX;
     g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
     g.vec_ok = p.vec_ok;
@@ -1023,7 +1023,7 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
         g.M = (int)mf; g.N = (int)mf; g.K = (int)fill_k;
         g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
         g.tiles_m = (int)gpk_cdiv(mf, 128); g.tiles_n = g.tiles_m;
-        g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0;
+        g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0; g.colmask = 0; g.grp_tiles = 0;
         g.split_from = INT32_MAX;
         g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
         g.vec_ok = aligned ? 1 : 0;
@@ -1185,6 +1185,13 @@ GPK_KNOB(int, g_la_rejoin, 1);              // tuning knob (gpk_tune(18, v)): re
 GPK_KNOB(int, g_la_mode, 1);                // tuning knob (gpk_tune(7, v)): 0 = same algorithm on one stream (no overlap), 1 = overlap
 GPK_KNOB(int64_t, g_la_fuse_diag_rows, 9216);   // tuning knob (gpk_tune(40, v)): the update of the next diagonal block rides in the trailing update while that has >= this many rows (0: never)
 GPK_KNOB(int, g_la_fuse_diag_nb, 512);          // tuning knob (gpk_tune(41, v)): ... and only for outer blocks up to this width
+// Round 5: AGGREGATED trailing updates.  Column block c of the trailing matrix only has to be up to date when its own panel is
+// factorised, so outer step j updates -- besides the next panel's block j + 1, always -- only the column blocks c = j + 2, j + 2 + m,
+// j + 2 + 2m, ... (c == j mod m), each with ALL the panels it has not seen yet: m nb deep instead of nb.  Same flops, every C tile
+// of the trailing matrix visited N / (m nb) times instead of N / nb times -- a visit costs ~35 us outside its k loop whatever K is
+// (C tile arriving, stores draining: profiles/r04_experiments.md section 4).  m = 1: the classic right-looking update.
+GPK_KNOB(int, g_la_agg, 2);                     // tuning knob (gpk_tune(47, v)): m
+GPK_KNOB(int64_t, g_la_agg_min_rows, 0);        // tuning knob (gpk_tune(48, v)): aggregate only while the trailing matrix has >= this many rows (below: every column block, every step)
 
 LaDevice* la_device() {
     int dev = 0;
@@ -1252,6 +1259,8 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 37) GPK_KNOB_SET(g_pipe = (int)value;);
     if (key == 40) GPK_KNOB_SET(g_la_fuse_diag_rows = value;);
     if (key == 41) GPK_KNOB_SET(g_la_fuse_diag_nb = (int)value;);
+    if (key == 47) GPK_KNOB_SET(g_la_agg = (int)value;);
+    if (key == 48) GPK_KNOB_SET(g_la_agg_min_rows = value;);
     if (key == 38) GPK_KNOB_SET(g_pipe_fill = (int)value;);
     if (key == 39) GPK_KNOB_SET(g_pipe_panel_wgs = (int)value;);
 }
@@ -1330,6 +1339,31 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, n - nb, nb, 1, stream);
         if (st) return st;
     }
+    // applied[c]: panels 0 .. applied[c] - 1 have been subtracted from column block c (columns c nb ..., the rows from its diagonal
+    // block down).  Column block c is updated with its pending panels  L[:, applied[c] nb : k1]  -- contiguous columns of the factor.
+    const int agg = (g_la_agg > 1 && nblk <= 64) ? (int)g_la_agg : 1;      // (the column groups of a segment are a 64-bit mask)
+    std::vector<int> applied((size_t)nblk, 0);
+    struct ColGroup { int from; uint64_t mask; };          // column blocks (bit c - c_first) that are `from` panels deep
+    auto group_cols = [&](int64_t c_first, int64_t j, bool all, std::vector<ColGroup>& out) {
+        out.clear();
+        for (int64_t c = c_first; c < nblk; ++c) {
+            if (!all && (c - j) % agg != 0) continue;
+            size_t g = 0;
+            while (g < out.size() && out[g].from != applied[(size_t)c]) ++g;
+            if (g == out.size()) out.push_back(ColGroup{applied[(size_t)c], 0});
+            out[g].mask |= (uint64_t)1 << (c - c_first);
+            applied[(size_t)c] = (int)(j + 1);
+        }
+    };
+    // column blocks c_first ... of the trailing matrix A[kc:, kc:] (kc = c_first nb), one segment per depth
+    auto col_segment = [&](const ColGroup& cg, int64_t c_first, int64_t k1) -> GpkSeg<T> {
+        const int64_t kc = c_first * nb, ka = (int64_t)cg.from * nb;
+        const T* P = A + kc * ld + ka;
+        const uint64_t every = (nblk - c_first >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << (nblk - c_first)) - 1);
+        return GpkSeg<T>{n - kc, n - kc, k1 - ka, P, ld, P, ld, A + kc * ld + kc, ld, A + kc * ld + kc, ld, 1, 0, 0,
+                         cg.mask == every ? 0 : cg.mask, nb};
+    };
+    std::vector<ColGroup> groups;
     for (int64_t j = 0; j + 1 < nblk; ++j) {
         const int64_t k0 = j * nb, k1 = k0 + nb;
         const int64_t k2 = (k1 + nb < n) ? k1 + nb : n;
@@ -1355,14 +1389,23 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             st = gpk_gemm_persist_launch<T>(&ps, 1, T(1), ctrl, 0, stream);
         }
         if (st) return st;
-        const T* P1 = A + k1 * ld + k0;
         if (n - k1 <= tail_rows) {
-            // last look-ahead step: the whole trailing matrix is updated in place, the rest is factorised the plain way
-            GpkSeg<T> sg{n - k1, n - k1, nb, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0};
-            st = gpk_gemm_persist_launch<T>(&sg, 1, T(-1), ctrl, 0, stream);
-            if (st) return st;
+            // last look-ahead step: the whole trailing matrix is brought up to date in place (every column block with the panels it
+            // has not seen: one segment per depth), the rest is factorised the plain way
+            group_cols(j + 1, j, true, groups);
+            for (size_t g0 = 0; g0 < groups.size(); g0 += GPK_PERSIST_MAX_SEG) {
+                GpkSeg<T> sg[GPK_PERSIST_MAX_SEG];
+                int ns = 0;
+                for (size_t g = g0; g < groups.size() && ns < GPK_PERSIST_MAX_SEG; ++g) sg[ns++] = col_segment(groups[g], j + 1, k1);
+                st = gpk_gemm_persist_launch<T>(sg, ns, T(-1), ctrl, 0, stream);
+                if (st) return st;
+            }
             return finish_plain(k1);
         }
+        // the next panel's column block (diagonal block + strip): the panels it has not seen yet (one with m <= 2, m - 1 in general)
+        const int64_t ka1 = (int64_t)applied[(size_t)(j + 1)] * nb, kd1 = k1 - ka1;
+        applied[(size_t)(j + 1)] = (int)(j + 1);
+        const T* P1 = A + k1 * ld + ka1;
         const bool overlap = g_la_mode == 1 && dev->aux != nullptr && (n - k2) >= g_la_min_rows;
         // diag(j+1): a launch of its own -- or, while the trailing update is long enough to hide a chain that starts a tile later, the
         // FIRST tiles of that update: the chain's kernel waits for them through a counter word instead of a kernel boundary
@@ -1373,9 +1416,21 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         const bool fuse_diag = overlap && nb <= g_la_fuse_diag_nb && g_la_fuse_diag_rows > 0 && (n - k2) >= g_la_fuse_diag_rows && g_pipe &&
                                (k2 - k1) > GPK_DB;
         if (!fuse_diag) {
-            st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, nb, T(-1), P1, ld, 0, P1, ld, 0, T(1),
+            st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, kd1, T(-1), P1, ld, 0, P1, ld, 0, T(1),
                                     A + k1 * ld + k1, ld, 0, 1, 1, stream);
             if (st) return st;
+        }
+        // which column blocks behind the next panel are updated in this step, and how deep
+        if (k2 < n) group_cols(j + 2, j, agg == 1 || (n - k2) < g_la_agg_min_rows, groups);
+        else groups.clear();
+        {   // more depths than the launch below has segments for (only at a change of policy): in-place launches of their own, up front
+            const size_t room = (size_t)(GPK_PERSIST_MAX_SEG - 1 - (fuse_diag ? 1 : 0));
+            while (groups.size() > room) {
+                GpkSeg<T> sg = col_segment(groups.back(), j + 2, k1);
+                groups.pop_back();
+                st = gpk_gemm_persist_launch<T>(&sg, 1, T(-1), ctrl, 0, stream);
+                if (st) return st;
+            }
         }
         hipEvent_t e_fork = nullptr, e_join = nullptr;
         if (overlap) {
@@ -1398,14 +1453,16 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
             // ~0.3 ms for those, which the main stream would otherwise spend idle
             if (k2 < n) {
-                const T* P2 = A + k2 * ld + k0;
-                GpkSeg<T> seg[3];
-                const int d = fuse_diag ? 1 : 0;
-                if (fuse_diag) seg[0] = GpkSeg<T>{k2 - k1, k2 - k1, nb, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0, 1};
-                const int so = g_la_strip_last ? 1 : 0;   // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
-                seg[d + so] = GpkSeg<T>{n - k2, k2 - k1, nb, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
-                seg[d + 1 - so] = GpkSeg<T>{n - k2, n - k2, nb, P2, ld, P2, ld, A + k2 * ld + k2, ld, A + k2 * ld + k2, ld, 1, 0};
-                const int s2 = gpk_gemm_persist_launch<T>(seg, 2 + d, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
+                const T* P2 = A + k2 * ld + ka1;
+                GpkSeg<T> seg[GPK_PERSIST_MAX_SEG];
+                int ns = 0;
+                if (fuse_diag) seg[ns++] = GpkSeg<T>{k2 - k1, k2 - k1, kd1, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0, 1};
+                const GpkSeg<T> strip{n - k2, k2 - k1, kd1, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
+                // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
+                if (!g_la_strip_last) seg[ns++] = strip;
+                for (const ColGroup& cg : groups) seg[ns++] = col_segment(cg, j + 2, k1);
+                if (g_la_strip_last) seg[ns++] = strip;
+                const int s2 = gpk_gemm_persist_launch<T>(seg, ns, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
                 if (s2) return s2;
             }
             if (overlap) {

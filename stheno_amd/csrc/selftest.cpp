@@ -194,6 +194,12 @@ static void test_gemm() {
             test_gemm_case<T>(ak, bk, 100, 70, 37, 1, 1, 1, false, 0);
             test_gemm_case<T>(ak, bk, 300, 200, 150, -1, 0, 3, false, 1);
         }
+    // an empty contraction (K = 0): C = beta C, and no spinning k loop -- whole tiles on purpose (the kernels without
+    // bounds checks run at least one chunk), lda = ldb = pad keeps the leading dimensions legal
+    test_gemm_case<T>(true, true, 128, 128, 0, 1, 1, 1, false, 4);
+    test_gemm_case<T>(true, false, 256, 128, 0, 1, 0, 2, false, 4);
+    test_gemm_case<T>(true, true, 1024, 1024, 0, -1, 1, 1, false, 4);
+    test_gemm_case<T>(true, true, 1024, 1024, 8, -1, 1, 1, false, 0);
     test_gemm_case<T>(true, true, 512, 512, 256, -1, 1, 1, true, 0);
     test_gemm_case<T>(true, true, 5 * 128 + 17, 5 * 128 + 17, 128, -1, 1, 2, true, 0);
     test_gemm_case<T>(true, true, 4352, 4352, 32, -1, 1, 1, true, 0);    // 34x34 tiles -> XCD super-tile path
@@ -598,6 +604,24 @@ static void test_lookahead() {
     test_potrf_la_case<T>(3000, 512, 1, 0, 1500);
     test_potrf_la_case<T>(4096, 1024, 1, 0, 2048);
     test_potrf_la_case<T>(5000, 1024, 1, 1024, 1000);
+    // aggregated trailing updates (round 5): every depth m, ragged orders, with / without the fused diagonal-block segment, a change of
+    // policy half-way (knob 48: several depths in one step), explicit inverses narrower than the outer blocks
+    for (int m : {1, 2, 3, 4, 7}) {
+        gpk_tune(47, m);
+        test_potrf_la_case<T>(3000, 256, 1, 0, 300);
+        test_potrf_la_case<T>(4100, 512, 1, 1024, 600);
+        test_potrf_la_case<T>(2900, 256, 0, 0, 300, 128 * 2);
+        gpk_tune(48, 1800);
+        test_potrf_la_case<T>(3333, 256, 1, 0, 500);
+        gpk_tune(48, 0);
+        gpk_tune(40, 256); gpk_tune(41, 4096);
+        test_potrf_la_case<T>(3000, 256, 1, 0, 300);
+        gpk_tune(48, 1500);
+        test_potrf_la_case<T>(3000, 256, 1, 0, 300);
+        gpk_tune(48, 0);
+        gpk_tune(40, 9216); gpk_tune(41, 512);
+    }
+    gpk_tune(47, 2);
     // a non-positive-definite matrix is reported with the global pivot order
     {
         const int n = 1500, nb = 512, bad = 1111;
@@ -1037,6 +1061,43 @@ static void la_one(int n, int nb, int mode, int64_t minrows, int reps, int ldpad
     }
 }
 
+
+// aggregated trailing updates, A/B in one process:  --perf-agg f64|f32 N NB SB ROUNDS TAIL M1 M2 ...
+template <typename T>
+static void perf_agg(int n, int nb, int sb, int rounds, const std::vector<int>& ms_list, int64_t tail = 0) {
+    const int d = 8;
+    auto hx = randv<T>((size_t)n * d);
+    const int wb = sb > 0 ? sb : nb;
+    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n));
+    Dev<T> dbig((size_t)((n + wb - 1) / wb) * wb * wb), ws((size_t)gpk_potrf_la_ws_elems(n, nb));
+    Dev<int> info(1);
+    X.up(hx);
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    if (tail > 0) gpk_tune(9, tail);
+    std::vector<double> sum(ms_list.size(), 0.0), best(ms_list.size(), 1e30);
+    for (int r = 0; r <= rounds; ++r)          // round 0: warm-up
+        for (size_t c = 0; c < ms_list.size(); ++c) {
+            gpk_tune(47, ms_list[c]);
+            HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st));
+            gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, st);
+            hipEventRecord(a, st);
+            if (sb > 0 && sb < nb) gpk_potrf_la_split(DT<T>::v, K.p, n, n, dinv.p, dbig.p, nb, sb, ws.p, info.p, st);
+            else gpk_potrf_la(DT<T>::v, K.p, n, n, dinv.p, dbig.p, nb, ws.p, info.p, st);
+            hipEventRecord(b, st);
+            HIPCHK(hipStreamSynchronize(st));
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (r > 0) { sum[c] += ms; best[c] = std::min(best[c], (double)ms); }
+            printf("PERFAGG potrf_%s n=%d nb=%d sb=%d tail=%lld m=%d round %d  %.3f ms  info=%d\n", DT<T>::name(), n, nb, wb, (long long)tail, ms_list[c], r, ms, info.down()[0]);
+        }
+    for (size_t c = 0; c < ms_list.size(); ++c)
+        printf("PERFAGG SUMMARY potrf_%s n=%d nb=%d sb=%d tail=%lld m=%d  mean %.3f ms  best %.3f ms  (%.2f TFLOP/s)\n", DT<T>::name(), n, nb, wb, (long long)tail, ms_list[c],
+               sum[c] / rounds, best[c], (double)n * n * n / 3.0 / best[c] * 1e-9);
+    gpk_tune(47, 2); gpk_tune(9, 0);
+}
 
 // shader clock and k-loop pace of chosen trailing updates INSIDE a look-ahead factorisation:  --la-clock f64|f32 N NB
 template <typename T>
@@ -1747,6 +1808,15 @@ int main(int argc, char** argv) {
             const int reps = (i + 6 < argc) ? atoi(argv[i + 6]) : 3;
             const int ldpad = (i + 7 < argc) ? atoi(argv[i + 7]) : 0;
             if (!strcmp(argv[i + 1], "f64")) la_one<double>(n, nb, mode, mr, reps, ldpad); else la_one<float>(n, nb, mode, mr, reps, ldpad);
+            return 0;
+        }
+        if (!strcmp(argv[i], "--perf-agg") && i + 6 < argc) {    // --perf-agg f64|f32 N NB SB ROUNDS TAIL M1 [M2 ...]
+            const int n = atoi(argv[i + 2]), nb = atoi(argv[i + 3]), sb = atoi(argv[i + 4]), rounds = atoi(argv[i + 5]);
+            const int64_t tail = atoll(argv[i + 6]);
+            std::vector<int> ml;
+            for (int q = i + 7; q < argc && argv[q][0] != '-'; ++q) ml.push_back(atoi(argv[q]));
+            if (ml.empty()) ml = {1, 2};
+            if (!strcmp(argv[i + 1], "f64")) perf_agg<double>(n, nb, sb, rounds, ml, tail); else perf_agg<float>(n, nb, sb, rounds, ml, tail);
             return 0;
         }
         if (!strcmp(argv[i], "--la-clock") && i + 3 < argc) {
