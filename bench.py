@@ -108,11 +108,15 @@ def make_step(name, w, t):
     if name in ("dense_f64", "sum_f32"):
         def step():
             forget_scan(t["y"])          # (every step scans y for NaN, as a first call does)
-            f = st.GP(kernel)
-            fdd = f(t["x"], NOISE)
-            lp = fdd.logpdf(t["y"])
-            post = f | (fdd, t["y"])
-            mean, var = post(t["xs"]).marginals()
+            # `st.deferred_checks()` (public API): the factorisation's `info` word is read ONCE, when the block ends --
+            # inside the step, so a failed factorisation still raises in it -- instead of in the middle of `logpdf`, where the host
+            # read left the device idle for ~0.44 ms while Python came back to enqueue the posterior
+            with st.deferred_checks():
+                f = st.GP(kernel)
+                fdd = f(t["x"], NOISE)
+                lp = fdd.logpdf(t["y"])
+                post = f | (fdd, t["y"])
+                mean, var = post(t["xs"]).marginals()
             return lp, mean, var
     elif name == "batched_f32":
         from stheno_amd.dist import sharded_logpdf
@@ -190,7 +194,7 @@ def _host_threads():
 def _full_size_cpu_record(name):
     """The one-off FULL-SIZE run of the CPU baseline (``bench.py --cpu-baseline-full``, committed under ``profiles/``): printed
     beside the bounded sample's extrapolation so that the extrapolation can be judged."""
-    for rnd in ("r04",):
+    for rnd in ("r05", "r04"):
         path = os.path.join(ROOT, "profiles", "%s_cpu_baseline_full_%s.json" % (rnd, name))
         if os.path.exists(path):
             with open(path) as f:
@@ -219,7 +223,24 @@ def cpu_baseline(name, full=False):
         t0 = time.perf_counter()
         k = O.kernel_matrix(terms, x) + NOISE * np.eye(n_s, dtype=np_dt)
         t_k = time.perf_counter() - t0
-        chol = O.cholesky(k, eps)
+        blocked = n_s >= 32768
+        if blocked:
+            # (OpenBLAS' potrf segfaults at this order on the boxes of this pool -- tests/golden/make_golden_fullsize.py met it too -- so
+            # the factorisation is spelt out right-looking on 8192-blocks with the same LAPACK / BLAS calls: potrf, trsm, syrk)
+            import scipy.linalg as sla
+
+            k = O.reg(k, eps)
+            nbk = 8192
+            for c in range(0, n_s, nbk):
+                e = min(c + nbk, n_s)
+                k[c:e, c:e] = np.linalg.cholesky(k[c:e, c:e])
+                if e < n_s:
+                    k[e:, c:e] = sla.solve_triangular(k[c:e, c:e], k[e:, c:e].T, lower=True, check_finite=False).T
+                    k[e:, e:] -= k[e:, c:e] @ k[e:, c:e].T
+            chol = np.tril(k)
+            del k
+        else:
+            chol = O.cholesky(k, eps)
         lp = -(O.logdet_chol(chol) + n_s * O.LOG_2_PI + O.iqf_diag(chol, y)) / 2
         v = O.solve_lower(chol, O.kernel_matrix(terms, x, xs))
         mean = v.T @ O.solve_lower(chol, y)
@@ -232,7 +253,8 @@ def cpu_baseline(name, full=False):
         if n_s == w["n"]:
             return {"value": 1.0 / dt, "unit": "evals/s", "cores": _host_threads(), "kind": "port", "seconds_per_eval": dt,
                     "sample": f"oracle/gp_oracle.py (NumPy/SciPy, {w['dtype']}) at the FULL N={n_s}, D={w['d']}, N*={w['ns']}: {dt:.2f} s per "
-                              f"eval measured ({t_k:.2f} s of it the kernel-matrix build); no extrapolation"}
+                              f"eval measured ({t_k:.2f} s of it the kernel-matrix build); no extrapolation"
+                              + ("; Cholesky spelt out on 8192-blocks (potrf / trsm / syrk of the same BLAS: its potrf segfaults at this order)" if blocked else "")}
         t_full = t_k * r * r + t_fac * r ** 3
         out = {"value": 1.0 / t_full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
                "sample": f"oracle/gp_oracle.py (NumPy/SciPy, {w['dtype']}) at N={n_s}, D={w['d']}, N*={w['ns']}: {dt:.2f} s per eval "
@@ -254,7 +276,7 @@ def cpu_baseline(name, full=False):
         return {"value": n_g / dt, "unit": "GPs/s", "cores": _host_threads(), "kind": "port",
                 "sample": f"oracle/gp_oracle.py gp_logpdf (NumPy/SciPy, fp32 inputs) on {n_g} of the 512 GPs (N={w['n']}, D={w['d']}), one after "
                           f"the other as NumPy's batched path does: {dt:.2f} s"}
-    n_s = 20000
+    n_s = w["n"] if full else 20000
     x, y = rng.standard_normal((n_s, w["d"])).astype(np_dt), rng.standard_normal((n_s, 1)).astype(np_dt)
     z = rng.standard_normal((w["m"], w["d"])).astype(np_dt)
     t0 = time.perf_counter()
@@ -265,10 +287,18 @@ def cpu_baseline(name, full=False):
     t1 = time.perf_counter()
     O.cholesky(O.kernel_matrix([("eq", 1.0, 1.0)], z) + 0.1 * np.eye(w["m"], dtype=np_dt), eps)
     t_m3 = 2 * (time.perf_counter() - t1)
-    full = t_m3 + max(dt - t_m3, 0.0) * (w["n"] / n_s)
-    return {"value": 1.0 / full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
-            "sample": f"oracle/gp_oracle.py pseudo_obs (VFE; NumPy/SciPy, fp32 inputs) at N={n_s}, M={w['m']}: {dt:.2f} s measured; the two "
-                      f"M^3 factorisations ({t_m3:.2f} s) kept, the O(N M^2) rest scaled by N/{n_s} = x{w['n'] // n_s}"}
+    if full:
+        return {"value": 1.0 / dt, "unit": "evals/s", "cores": _host_threads(), "kind": "port", "seconds_per_eval": dt,
+                "sample": f"oracle/gp_oracle.py pseudo_obs (VFE; NumPy/SciPy, fp32 inputs) at the FULL N={n_s}, M={w['m']}: {dt:.2f} s per eval "
+                          f"measured; no extrapolation"}
+    t_full = t_m3 + max(dt - t_m3, 0.0) * (w["n"] / n_s)
+    out = {"value": 1.0 / t_full, "unit": "evals/s", "cores": _host_threads(), "kind": "port",
+           "sample": f"oracle/gp_oracle.py pseudo_obs (VFE; NumPy/SciPy, fp32 inputs) at N={n_s}, M={w['m']}: {dt:.2f} s measured; the two "
+                     f"M^3 factorisations ({t_m3:.2f} s) kept, the O(N M^2) rest scaled by N/{n_s} = x{w['n'] // n_s}"}
+    rec = _full_size_cpu_record(name)
+    if rec is not None:
+        out["full_size_measured"] = {k: rec[k] for k in ("value", "unit", "cores", "seconds_per_eval", "sample") if k in rec}
+    return out
 
 
 def _free_port():
@@ -517,6 +547,7 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
             "config": {"workload": w["desc"], "noise_variance": NOISE, "epsilon": st.B.epsilon,
                        "nan_scan": "every step (the library's per-tensor memo is cleared at the start of each step)",
+                       "info_check": "once per step, at the end of the step's st.deferred_checks() block (dense workloads)",
                        "parallelism": ("replicas only (%d independent evals in flight, one process per GPU)" % world) if name != "batched_f32"
                        else "GPs sharded over %d ranks, all-gather of log-densities" % world},
             "roofline": roofline,

@@ -147,9 +147,12 @@ int gpk_trsm_lower_to(int dtype, const void* l, int64_t n, int64_t ld, int64_t s
                       int sb, void* b, int64_t nrhs, int64_t ldb, int64_t sb_stride, void* x, int64_t ldx,
                       int64_t sx_stride, int64_t batch, void* stream);
 
-/* B <- L^{-1} B, nrhs <= 8 (GEMV sweep, HBM-bound).  tmp: batch * sb * nrhs elements.
+/* B <- L^{-1} B, nrhs <= 8 (GEMV sweep, HBM-bound).  tmp: batch * sb * nrhs + GPK_TRSV_CTRL_ELEMS elements (16-byte aligned;
+ * the extra elements hold the control words of the single-launch sweep -- one right-hand side of one factor runs as ONE resident
+ * launch whose workgroups meet at grid barriers; the call zeroes them).
  * Replaces the solve inside `B.iqf_diag(var, y - mean)`: stheno/random.py:276,
  * stheno/model/observations.py:335. */
+#define GPK_TRSV_CTRL_ELEMS 16
 int gpk_trsv_lower(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl, const void* dinv_sb,
                    int sb, void* b, int nrhs, int64_t ldb, int64_t sb_stride, void* tmp, int64_t batch,
                    void* stream);

@@ -18,8 +18,12 @@
 #include "gpk_common.hpp"
 
 GPK_KNOB(int, g_trsv_batched, 1);      // tuning knob (gpk_tune(17, v)): one-workgroup-per-matrix TRSV for batches of small factors
+GPK_KNOB(int, g_trsv_sweep, 1);        // tuning knob (gpk_tune(49, v)): the single-column solve of one factor as ONE resident launch (trsv_sweep_kernel)
+GPK_KNOB(int64_t, g_trsv_sweep_from, 2048);   // tuning knob (gpk_tune(50, v)): ... from this order
 void gpk_tune_solve(int key, int64_t value) {
     if (key == 17) GPK_KNOB_SET(g_trsv_batched = (int)value;);
+    if (key == 49) GPK_KNOB_SET(g_trsv_sweep = (int)value;);
+    if (key == 50) GPK_KNOB_SET(g_trsv_sweep_from = value;);
 }
 
 namespace {
@@ -339,6 +343,165 @@ __global__ __launch_bounds__(256) void trsv_batched_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// ONE right-hand side, one (large) factor: the whole forward solve in ONE launch (round 5; the per-block sweep below is 2 n / sb
+// launches of 10-40 us each with ~7 us gaps between them: 0.69 ms for 0.21 ms of HBM work at cfg2).  A resident grid of G
+// workgroups (one per CU) walks the sb-blocks LEFT-LOOKING; row i of a block belongs to workgroup i mod G:
+//   phase 1   r_i = b_i - L[i, 0:r0] x[0:r0]      every workgroup streams ITS rows of block row q (the four waves split k, RU rows and
+//                                                 8 / RU k-slices in flight per lane), r -> R (scratch)
+//   phase 2   x_i = W_q[i, 0:i] r[0:i]            the explicit inverse of the diagonal block, same rows, x -> B
+// with a grid barrier (one counter, agent scope: stores -> workgroup barrier -> release -> add; poll -> acquire -> barrier) behind
+// each phase.  Both phases use the whole chip, so the serial chain is 2 n / sb barriers of a few us.  Fixed summation order
+// (lane -> wave -> the four waves in order): deterministic.  A poll that spins for seconds (the grid is not co-resident: a
+// CU-masked stream) raises ctrl[1]; everybody leaves and workgroup 0 poisons the result with NaN.
+// ---------------------------------------------------------------------------
+template <typename T, int RU>
+__global__ __launch_bounds__(256) void trsv_sweep_kernel(const T* __restrict__ L, int64_t ld, const T* __restrict__ W, int sb, T* B, T* R,
+                                                          unsigned* ctrl, int n) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int U = 8 / RU;                    // k-slices in flight per lane
+    constexpr int S = 256 * VEC;                 // columns one pass of the workgroup covers
+    __shared__ T red[4][RU];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = (int)gridDim.x, w = (int)blockIdx.x;
+    const int nsb = (n + sb - 1) / sb;
+    unsigned epoch = 0;
+    auto grid_barrier = [&]() -> bool {          // false: give up (abort raised)
+        ++epoch;
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = epoch * (unsigned)G;
+            int ab = 0;
+            long long t0 = 0;
+            for (unsigned spins = 0;; ++spins) {
+                if (__hip_atomic_load(&ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ab = 1; break; }
+                if ((spins & 1023u) == 1023u) {
+                    const long long now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > 400000000ll) {       // ~4 s at 100 MHz
+                        __hip_atomic_store(&ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ab = 1;
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_abort = ab;
+        }
+        __syncthreads();
+        return s_abort == 0;
+    };
+    bool alive = true;
+    for (int q = 0; q < nsb && alive; ++q) {
+        const int r0 = q * sb;
+        const int rq = (n - r0 < sb) ? n - r0 : sb;
+        const T* __restrict__ Wq = W + (int64_t)q * sb * sb;
+        // ---- phase 1 ----
+        for (int g0 = w; g0 < rq; g0 += G * RU) {                 // this workgroup's rows g0, g0 + G, ... of the block, RU at a time
+            int rows[RU];
+            const T* lrow[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                rows[u] = g0 + u * G;
+                const int rc = rows[u] < rq ? rows[u] : g0;        // (past the end: a valid row, result dropped)
+                lrow[u] = L + (int64_t)(r0 + rc) * ld;
+            }
+            T acc[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) acc[u] = T(0);
+            for (int k = tid * VEC; k < r0; k += S * U) {
+                vec_t lv[U][RU], xv[U];
+#pragma unroll
+                for (int uu = 0; uu < U; ++uu) {
+                    const int kk = k + uu * S;
+                    const bool ok = kk < r0;
+                    const int kc = ok ? kk : 0;
+                    xv[uu] = *reinterpret_cast<const vec_t*>(B + kc);
+                    if (!ok) {
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) xv[uu][v] = T(0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) lv[uu][u] = *reinterpret_cast<const vec_t*>(lrow[u] + kc);
+                }
+#pragma unroll
+                for (int uu = 0; uu < U; ++uu)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                        for (int u = 0; u < RU; ++u) acc[u] += lv[uu][u][v] * xv[uu][v];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                T v = acc[u];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) red[wave][u] = v;
+            }
+            __syncthreads();
+            if (tid < RU && g0 + tid * G < rq) {
+                const int i = g0 + tid * G;
+                R[i] = B[r0 + i] - (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+            }
+            __syncthreads();
+        }
+        alive = grid_barrier();
+        if (!alive) break;
+        // ---- phase 2 ----
+        for (int g0 = w; g0 < rq; g0 += G * RU) {
+            int rows[RU];
+            const T* wrow[RU];
+            int kmax = 0;
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                rows[u] = g0 + u * G;
+                const int rc = rows[u] < rq ? rows[u] : g0;
+                wrow[u] = Wq + (int64_t)rc * sb;
+                if (rows[u] < rq) kmax = rows[u] + 1;
+            }
+            kmax = (kmax + VEC - 1) / VEC * VEC;
+            T acc[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) acc[u] = T(0);
+            for (int k = tid * VEC; k < kmax; k += S) {
+                const vec_t rv = *reinterpret_cast<const vec_t*>(R + k);
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const vec_t wv = *reinterpret_cast<const vec_t*>(wrow[u] + k);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[u] += (k + v <= rows[u]) ? wv[v] * rv[v] : T(0);     // (the inverse is lower triangular)
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                T v = acc[u];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) red[wave][u] = v;
+            }
+            __syncthreads();
+            if (tid < RU && g0 + tid * G < rq) {
+                const int i = g0 + tid * G;
+                B[r0 + i] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+            }
+            __syncthreads();
+        }
+        alive = grid_barrier();
+    }
+    if (!alive && w == 0) {
+        T qnan = T(0) / T(0);
+        asm volatile("" : "+v"(qnan));
+        for (int i = tid; i < n; i += 256) B[i] = qnan;
+    }
+}
+
 }  // namespace
 
 // y[M x nrhs] = alpha * A[M x K] x[K x nrhs] + beta * y, nrhs <= 8, A row-major (k contiguous)
@@ -510,6 +673,24 @@ int gpk_trsv_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv
                 hipLaunchKernelGGL((trsv_batched_kernel<T, 2>), grid, dim3(256), lds, stream, L, ld, sL, dinv_sb, ssb, B, ldb, sB, (int)n, nrhs);
             else
                 hipLaunchKernelGGL((trsv_batched_kernel<T, 4>), grid, dim3(256), lds, stream, L, ld, sL, dinv_sb, ssb, B, ldb, sB, (int)n, nrhs);
+            GPK_CHECK_LAUNCH();
+            return GPK_OK;
+        }
+    }
+    // one right-hand side, one factor of several blocks: the whole sweep in one resident launch (trsv_sweep_kernel)
+    constexpr int VEC = Traits<T>::VEC;
+    if (g_trsv_sweep && batch == 1 && nrhs == 1 && ldb == 1 && nsb >= 2 && sb >= 256 && n >= g_trsv_sweep_from &&
+        (uintptr_t)L % 16 == 0 && ld % VEC == 0 && (uintptr_t)B % 16 == 0 && (uintptr_t)tmp % 16 == 0 && (uintptr_t)dinv_sb % 16 == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 16) {
+            unsigned* ctrl = reinterpret_cast<unsigned*>(tmp + st_tmp);        // (behind the sb elements of r: gpk.h, GPK_TRSV_CTRL_ELEMS)
+            if (hipMemsetAsync(ctrl, 0, 2 * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
+            const int ru = sb / cus >= 4 ? 4 : (sb / cus >= 2 ? 2 : 1);
+            const int G = (sb / ru < cus) ? sb / ru : cus;
+            dim3 grid((unsigned)G);
+            if (ru == 4) hipLaunchKernelGGL((trsv_sweep_kernel<T, 4>), grid, dim3(256), 0, stream, L, ld, dinv_sb, sb, B, tmp, ctrl, (int)n);
+            else if (ru == 2) hipLaunchKernelGGL((trsv_sweep_kernel<T, 2>), grid, dim3(256), 0, stream, L, ld, dinv_sb, sb, B, tmp, ctrl, (int)n);
+            else hipLaunchKernelGGL((trsv_sweep_kernel<T, 1>), grid, dim3(256), 0, stream, L, ld, dinv_sb, sb, B, tmp, ctrl, (int)n);
             GPK_CHECK_LAUNCH();
             return GPK_OK;
         }

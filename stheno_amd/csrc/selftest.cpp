@@ -401,7 +401,7 @@ static void test_potrf_case(int n, int batch, int nbo, int nrhs_small, int nrhs_
         if (nrhs <= 0) continue;
         const int64_t ldb = nrhs + (pass == 0 ? 0 : 2);
         auto Bm = randv<T>((size_t)batch * n * ldb);
-        Dev<T> dB(Bm.size()), tmp((size_t)batch * sb * nrhs);
+        Dev<T> dB(Bm.size()), tmp((size_t)batch * sb * nrhs + GPK_TRSV_CTRL_ELEMS);
         dB.up(Bm);
         int s4 = pass == 0 ? gpk_trsv_lower(DT<T>::v, dA.p, n, ld, sA, dsb.p, sb, dB.p, nrhs, ldb, (int64_t)n * ldb, tmp.p, batch, nullptr)
                            : gpk_trsm_lower(DT<T>::v, dA.p, n, ld, sA, dsb.p, sb, dB.p, nrhs, ldb, (int64_t)n * ldb, tmp.p, batch, nullptr);
@@ -449,6 +449,16 @@ static void test_potrf_case(int n, int batch, int nbo, int nrhs_small, int nrhs_
 }
 template <typename T>
 static void test_potrf() {
+    // the single-launch sweep for one right-hand side (trsv_sweep_kernel): orders from 2048 take it by default; ragged last blocks,
+    // every block width it serves, and (dev build) small orders with the threshold lowered
+    test_potrf_case<T>(2500, 1, 0, 1, 0, 512);
+    test_potrf_case<T>(4500, 1, 0, 1, 0, 1024);
+    test_potrf_case<T>(2304, 1, 0, 1, 0, 256);
+    test_potrf_case<T>(4096, 1, 0, 1, 0, 2048);
+    gpk_tune(50, 0);
+    test_potrf_case<T>(700, 1, 0, 1, 0, 256);
+    test_potrf_case<T>(1664, 1, 256, 1, 0, 512);
+    gpk_tune(50, 2048);
     test_potrf_case<T>(10, 1, 0, 1, 3, 128);
     test_potrf_case<T>(100, 3, 0, 2, 0, 128);
     test_potrf_case<T>(128, 1, 0, 1, 130, 128);
@@ -861,7 +871,7 @@ static void perf() {
         }
         // trsv (nrhs = 1), sb = 128
         {
-            Dev<T> y(n), tmp(512);
+            Dev<T> y(n), tmp(512 + GPK_TRSV_CTRL_ELEMS);
             auto hy = randv<T>(n);
             for (int rep = 0; rep < 2; ++rep) {
                 y.up(hy);
@@ -1197,7 +1207,7 @@ template <typename T>
 static void profile_one(int n, int nbo, int reps) {
     const int d = 8, nrhs = 2048, sb = 512;
     auto hx = randv<T>((size_t)n * d);
-    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n)), y(n), tmp((size_t)sb * nrhs);
+    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n)), y(n), tmp((size_t)sb * nrhs + GPK_TRSV_CTRL_ELEMS);
     Dev<T> dsb((size_t)((n + sb - 1) / sb) * sb * sb), tmpm((size_t)((n + sb - 1) / sb) * sb * sb / 4 + 16), Bm((size_t)n * nrhs);
     Dev<int> info(1);
     X.up(hx);
@@ -1706,6 +1716,45 @@ static void perf_trsm(int n, int nrhs) {
     }
 }
 
+// one right-hand side: the per-block sweep (2 n / sb launches) against the single resident launch   --perf-trsv
+template <typename T>
+static void perf_trsv(int n, std::vector<int> sbs) {
+    auto hx = randv<T>((size_t)n * 8);
+    Dev<T> X(hx.size()), K((size_t)n * n), dinv(gpk_dinv_elems(n)), y(n);
+    Dev<int> info(1);
+    X.up(hx);
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    info.zero();
+    gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, 8, 0, X.p, n, 8, 0, 8, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+    gpk_potrf(DT<T>::v, K.p, n, n, 0, 1, dinv.p, info.p, 0, nullptr);
+    auto hy = randv<T>((size_t)n);
+    Timer tm;
+    for (int sb : sbs) {
+        Dev<T> dsb((size_t)((n + sb - 1) / sb) * sb * sb), tmpm((size_t)((n + sb - 1) / sb) * sb * sb / 4 + 16), tmp((size_t)sb + GPK_TRSV_CTRL_ELEMS);
+        gpk_trtri_merge(DT<T>::v, K.p, n, n, 0, 1, dinv.p, sb, dsb.p, tmpm.p, nullptr);
+        std::vector<T> ref;
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            gpk_tune(49, sweep);
+            for (int rep = 0; rep < 4; ++rep) {
+                y.up(hy);
+                tm.start();
+                gpk_trsv_lower(DT<T>::v, K.p, n, n, 0, dsb.p, sb, y.p, 1, 1, 0, tmp.p, 1, nullptr);
+                const float ms = tm.stop();
+                if (rep) printf("PERFTRSV %s n=%d sb=%d %s  %.3f ms  %.2f TB/s\n", DT<T>::name(), n, sb, sweep ? "one launch  " : "per-block   ", ms,
+                                0.5 * n * (double)n * sizeof(T) / ms * 1e-9);
+            }
+            auto got = y.down();
+            if (!sweep) ref = got;
+            else {
+                double num = 0, den = 0;
+                for (int i = 0; i < n; ++i) { num = std::max(num, std::fabs((double)got[i] - (double)ref[i])); den = std::max(den, std::fabs((double)ref[i])); }
+                printf("PERFTRSV %s n=%d sb=%d one launch vs per-block: max rel diff %.3e\n", DT<T>::name(), n, sb, num / den);
+            }
+        }
+        gpk_tune(49, 1);
+    }
+}
+
 int main(int argc, char** argv) {
     bool do_perf = false, only_perf = false;
     for (int i = 1; i + 2 < argc; ++i)     // --set KEY VALUE: tuning knobs (gpk_debug_set)
@@ -1785,6 +1834,7 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--perf-la-tail")) { perf_la_tail<double>({6144, 8192, 10240, 12288, 16384}); perf_la_tail<float>({8192, 12288, 16384, 32768}); return 0; }
         if (!strcmp(argv[i], "--perf-pipe")) { perf_pipe<double>(); perf_pipe<float>(); return 0; }
+        if (!strcmp(argv[i], "--perf-trsv")) { perf_trsv<double>(16384, {512, 1024, 2048}); perf_trsv<float>(32768, {256, 512, 1024}); return 0; }
         if (!strcmp(argv[i], "--perf-trsm")) { perf_trsm<double>(16384, 2048); perf_trsm<float>(32768, 2048); return 0; }
         if (!strcmp(argv[i], "--kmat")) {                      // only the kernel-matrix checks, both kernels
             for (int band = 1; band >= 0; --band) { gpk_tune(12, band); test_kmat<double>(); test_kmat<float>(); }

@@ -252,20 +252,27 @@ class Chol:
             return None
         return ops.get_backend().gemm(dsb[0, 0][: self.n, : self.n], b, a_kmajor=True, b_kmajor=False, tri_k_lower=True)
 
-    def solve_scaled(self, b, colscale, want_colss):
+    def solves_by_full_inverse(self, nrhs):
+        """Whether a solve against ``nrhs`` right-hand sides is ONE triangular GEMM with the explicitly inverted factor (``_solve_block``:
+        far more right-hand sides than unknowns) AND the backend can fold column statistics into it (:meth:`solve_scaled`)."""
+        if self.l.dim() != 2 or nrhs <= 8 or not hasattr(ops.get_backend(), "gemm_colscale"):
+            return False
+        sb, dsb = self._blocks(nrhs)          # (the merged inverse is computed here at the latest: the solve needs it anyway)
+        return dsb is not None and sb >= self.n
+
+    def solve_scaled(self, b, colscale, want_colss, b_kmajor=False):
         """``(L^{-1} b) diag(colscale)`` and (``want_colss``) the column sums of squares of ``L^{-1} b``, from ONE triangular GEMM with
         both folded into its store -- when the whole factor has been inverted (``_solve_block``: far more right-hand sides than
-        unknowns, the pseudo-point path).  ``None`` when that does not apply (the caller takes the separate passes)."""
-        if self.l.dim() != 2 or b.dim() != 2 or b.shape[-1] <= 8:
+        unknowns, the pseudo-point path).  ``None`` when that does not apply (the caller takes the separate passes).
+        ``b_kmajor``: ``b`` is handed over TRANSPOSED, (nrhs, n) -- both operands of the product k-contiguous."""
+        nrhs = b.shape[-2] if b_kmajor else b.shape[-1]
+        if b.dim() != 2 or not self.solves_by_full_inverse(nrhs):
             return None
-        be = ops.get_backend()
-        if not hasattr(be, "gemm_colscale"):
-            return None
-        sb, dsb = self._blocks(b.shape[-1])
+        sb, dsb = self._blocks(nrhs)
         if dsb is None or sb < self.n:
             return None
-        return be.gemm_colscale(dsb[0, 0][: self.n, : self.n], b, colscale, want_colss=want_colss, a_kmajor=True, b_kmajor=False,
-                                tri_k_lower=True)
+        return ops.get_backend().gemm_colscale(dsb[0, 0][: self.n, : self.n], b, colscale, want_colss=want_colss, a_kmajor=True,
+                                               b_kmajor=b_kmajor, tri_k_lower=True)
 
     def solve_(self, b):
         """``L^{-1} b``, overwriting ``b`` where possible (``b``: (..., n, nrhs), unit inner stride).

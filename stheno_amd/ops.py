@@ -278,7 +278,7 @@ class HipBackend:
         if n == 0 or nrhs == 0:
             return b
         if nrhs <= 8:
-            tmp = torch.empty((B, sb, nrhs), dtype=b.dtype, device=b.device)
+            tmp = torch.empty((B * sb * nrhs + 16,), dtype=b.dtype, device=b.device)     # (+ GPK_TRSV_CTRL_ELEMS: the single-launch sweep's control words)
             code = self.lib.gpk_trsv_lower(_dtype_id(l3), self._ptr(l3), n, _ld(l3), _bs(l3), self._ptr(dinv_sb), sb,
                                            self._ptr(b3), nrhs, _ld(b3), _bs(b3), self._ptr(tmp), B, self._stream())
             self._st(code, "gpk_trsv_lower")

@@ -15,7 +15,7 @@ runs ``oracle/gp_oracle.py`` -- the NumPy/SciPy restatement of Stheno's NumPy pa
 (``stheno/random.py:248-280`` for the log-density, ``stheno/model/observations.py:148-168``
 + mlkernels ``PosteriorMean/PosteriorKernel`` for the posterior) -- at the full size on the host,
 and writes ``tests/golden/cfg2_n16384.json``: the log-density, posterior mean / marginal variance at
-the first 16 test points, and checksums of the inputs (so that the GPU-side test can prove it fed the
+the first 16 test points, sums / extreme values / every 64th value of the posterior at ALL 2048 test points (round 5), and checksums of the inputs (so that the GPU-side test can prove it fed the
 same numbers).  Takes a few minutes and ~6 GB on 8 cores.  Re-run:
 
     python tests/golden/make_golden_fullsize.py [cfg2] [cfg3] [cfg5]
@@ -47,6 +47,16 @@ def checksum(a):
     a = np.ascontiguousarray(a, dtype="<f8")
     return {"sha256": hashlib.sha256(a.tobytes()).hexdigest(), "sum": float(a.sum()), "sum_abs": float(np.abs(a).sum()),
             "shape": list(a.shape)}
+
+
+def all_points(mean, var):
+    """Round 5: the posterior at ALL the test points -- plain sums (what a device-side check recomputes cheaply), the extreme values
+    and every 64th point -- next to the first N_TEST values the round-3/4 files held."""
+    def one(a):
+        a = np.asarray(a, dtype=np.float64).reshape(-1)
+        return {"n": int(a.size), "sum": float(a.sum()), "sum_abs": float(np.abs(a).sum()), "max_abs": float(np.abs(a).max()),
+                "sum_sq": float((a * a).sum()), "every_64th": [float(v) for v in a[::64]]}
+    return {"posterior_mean_all": one(mean), "posterior_var_all": one(var)}
 
 
 def kernel_matrix_blocked(terms, x, rows=2048):
@@ -112,10 +122,11 @@ def cfg3():
     logdet = O.logdet_chol(chol)
     quad = float(O.iqf_diag(chol, y)[0])
     lp = -(logdet + x.shape[0] * O.LOG_2_PI + quad) / 2
-    ks = O.kernel_matrix(terms, x, xs[:N_TEST])
+    ks = O.kernel_matrix(terms, x, xs)
     v = O.solve_lower(chol, ks)
-    mean = (v.T @ O.solve_lower(chol, y))[:, 0]
-    var = O.kernel_diag(terms, xs[:N_TEST]).reshape(-1) - np.sum(v * v, axis=0)
+    mean_all = (v.T @ O.solve_lower(chol, y))[:, 0]
+    var_all = O.kernel_diag(terms, xs).reshape(-1) - np.sum(v * v, axis=0)
+    mean, var = mean_all[:N_TEST], var_all[:N_TEST]
     dt = time.perf_counter() - t0
     out = {
         "config": "BASELINE.json configs[2]: EQ()+Linear(), N=32768, D=4, fp32 inputs (cast to fp64 for the oracle), noise 0.1, epsilon 1e-6",
@@ -126,6 +137,7 @@ def cfg3():
         "posterior_mean": [float(a) for a in mean], "posterior_var": [float(a) for a in var],
         "oracle_seconds": round(dt, 1),
     }
+    out.update(all_points(mean_all, var_all))
     with open(os.path.join(HERE, "cfg3_n32768.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out)[:400], "...", flush=True)
@@ -168,10 +180,11 @@ def cfg2():
     logdet = O.logdet_chol(chol)
     quad = float(O.iqf_diag(chol, y)[0])
     lp = -(logdet + x.shape[0] * O.LOG_2_PI + quad) / 2
-    ks = O.kernel_matrix(terms, x, xs[:N_TEST])
+    ks = O.kernel_matrix(terms, x, xs)
     v = O.solve_lower(chol, ks)
-    mean = (v.T @ O.solve_lower(chol, y))[:, 0]
-    var = O.kernel_diag(terms, xs[:N_TEST]).reshape(-1) - np.sum(v * v, axis=0)
+    mean_all = (v.T @ O.solve_lower(chol, y))[:, 0]
+    var_all = O.kernel_diag(terms, xs).reshape(-1) - np.sum(v * v, axis=0)
+    mean, var = mean_all[:N_TEST], var_all[:N_TEST]
     dt = time.perf_counter() - t0
     out = {
         "config": "BASELINE.json configs[1]: EQ(), N=16384, D=8, fp64, noise 0.1, epsilon 1e-12",
@@ -182,6 +195,7 @@ def cfg2():
         "posterior_mean": [float(a) for a in mean], "posterior_var": [float(a) for a in var],
         "oracle_seconds": round(dt, 1),
     }
+    out.update(all_points(mean_all, var_all))
     with open(os.path.join(HERE, "cfg2_n16384.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out)[:400], "...")
