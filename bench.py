@@ -66,6 +66,8 @@ WORKLOADS = {
                        dtype="f32", n=200000, d=8, m=4096),
 }
 TORCH_DTYPE = {"f64": torch.float64, "f32": torch.float32}
+DEFER_CHECKS = True          # (--no-deferred-checks: A/B switch, development)
+ORDER = "posterior-first"    # (--order: which of the step's two API calls comes first -- the same work either way)
 
 
 def make_inputs(name, device, rank=0, world=1, n_override=None):
@@ -111,12 +113,21 @@ def make_step(name, w, t):
             # `st.deferred_checks()` (public API): the factorisation's `info` word is read ONCE, when the block ends --
             # inside the step, so a failed factorisation still raises in it -- instead of in the middle of `logpdf`, where the host
             # read left the device idle for ~0.44 ms while Python came back to enqueue the posterior
-            with st.deferred_checks():
+            import contextlib
+
+            with (st.deferred_checks() if DEFER_CHECKS else contextlib.nullcontext()):
                 f = st.GP(kernel)
                 fdd = f(t["x"], NOISE)
-                lp = fdd.logpdf(t["y"])
-                post = f | (fdd, t["y"])
-                mean, var = post(t["xs"]).marginals()
+                if ORDER == "posterior-first":
+                    # condition + predict before anything has factorised K: K(x*, x) rides in the factorisation as rows under the kernel
+                    # matrix (gpk_potrf_rows) and the separate 2048-column triangular solve is gone; the log-density shares the factor
+                    post = f | (fdd, t["y"])
+                    mean, var = post(t["xs"]).marginals()
+                    lp = fdd.logpdf(t["y"])
+                else:
+                    lp = fdd.logpdf(t["y"])
+                    post = f | (fdd, t["y"])
+                    mean, var = post(t["xs"]).marginals()
             return lp, mean, var
     elif name == "batched_f32":
         from stheno_amd.dist import sharded_logpdf
@@ -419,11 +430,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="ONLY time the CPU baseline of a dense workload at its full N (minutes of host time, no GPU) and print it as JSON")
+    ap.add_argument("--order", default="posterior-first", choices=["posterior-first", "logpdf-first"],
+                    help="dense workloads: condition + predict, then the log-density (default: the posterior's solve rides in the factorisation) "
+                         "or the other way round (the factor exists before the posterior is asked for: separate 2048-column solve)")
+    ap.add_argument("--no-deferred-checks", action="store_true", help="development A/B: the info word is read where the factorisation is made")
     ap.add_argument("--no-batched-record", action="store_true", help="skip the `batched` sub-record (configs[3] sharded over the ranks)")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="GPU-less proof of the N-rank path: gloo, a stand-in step, the same launch / barrier / all-gather / JSON code")
     args = ap.parse_args()
 
+    global DEFER_CHECKS, ORDER
+    DEFER_CHECKS = not args.no_deferred_checks
+    ORDER = args.order
     if args.cpu_baseline_full:
         print(json.dumps(cpu_baseline(args.workload, full=True)), flush=True)
         return
@@ -547,7 +565,8 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
             "config": {"workload": w["desc"], "noise_variance": NOISE, "epsilon": st.B.epsilon,
                        "nan_scan": "every step (the library's per-tensor memo is cleared at the start of each step)",
-                       "info_check": "once per step, at the end of the step's st.deferred_checks() block (dense workloads)",
+                       "call_order": (ORDER if name in ("dense_f64", "sum_f32") else None),
+                       "info_check": ("once per step, at the end of the step's st.deferred_checks() block (dense workloads)" if DEFER_CHECKS else "where the factorisation is made"),
                        "parallelism": ("replicas only (%d independent evals in flight, one process per GPU)" % world) if name != "batched_f32"
                        else "GPs sharded over %d ranks, all-gather of log-densities" % world},
             "roofline": roofline,

@@ -125,6 +125,19 @@ int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* di
 int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
                        void* stream);
 
+/* Factorisation WITH ROWS UNDER THE MATRIX (round 5): `a` holds `rows` >= n rows of n columns -- the symmetric matrix (lower
+ * triangle read) in the first n, anything else below, typically K(x*, x) of the posterior.  The extra rows are carried through
+ * the factorisation like the rows below a diagonal block: every panel solve and every trailing update includes them, and they
+ * come out as  a[n:, :] L^{-T}  -- the TRANSPOSE of the whitened cross-covariance L^{-1} K(x, x*) that `gpk_trsm_lower` would
+ * have to compute afterwards.  Their flops ride in the factorisation's own GEMM launches and, in its chain-bound tail, on
+ * workgroups that would otherwise wait: the separate many-column solve (and its ~30 launches) disappears from the posterior path.
+ * nb = 0: pipelined panels (any n up to the look-ahead threshold; dinv_sb / ws unused);  nb > 0: look-ahead as gpk_potrf_la /
+ * gpk_potrf_la_split (sb = 0: sb = nb), `ws`: gpk_potrf_la_ws_elems(rows, nb).
+ * n must be a multiple of 128 when rows > n; `dinv`: gpk_dinv_elems(n) + 128 * 128 elements (one slot more: control words).
+ * Replaces `B.cholesky` + the `B.solve(L, K_zx)` of mlkernels' PosteriorKernel / PosteriorMean (observations.py:148-168) in one call. */
+int gpk_potrf_rows(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
+                   void* stream);
+
 /* Merge the 128-block inverses into inverses of sb x sb diagonal blocks
  * (sb = 128 * 2^k <= 4096); dinv_sb: [batch][ceil(n/sb)][sb][sb];
  * tmp: >= ceil(n/sb) * sb * sb / 4 elements.  Part of the blocked TRSM below. */
@@ -210,6 +223,12 @@ int gpk_logdet_chol(int dtype, const void* l, int64_t n, int64_t ld, int64_t sl,
 
 /* Number of row chunks (workspace sizing) used by gpk_colreduce for `rows` rows. */
 int64_t gpk_colreduce_chunks(int64_t rows);
+
+/* Row reductions of Z (rows x n, row-major, ld >= n):  out_dot[i] = sum_k Z[i][k] w[k]  (skipped if out_dot is NULL),
+ * out_ss[i] = sum_k Z[i][k]^2  (skipped if out_ss is NULL), one pass.  The posterior mean and marginal variance from the rows
+ * gpk_potrf_rows leaves under the factor (Z = K(x*, x) L^{-T}): the same quantities as gpk_colreduce on L^{-1} K(x, x*).
+ * Replaces the reductions inside mlkernels' PosteriorMean / PosteriorKernel.elwise (observations.py:148-168). */
+int gpk_rowreduce(int dtype, const void* z, int64_t rows, int64_t n, int64_t ld, const void* w, void* out_dot, void* out_ss, void* stream);
 
 /* Fused column reductions of V (rows x cols):
  *   out_dot[j] = sum_i V[i][j] w[i]   (skipped if out_dot or w is NULL)

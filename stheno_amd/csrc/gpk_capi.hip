@@ -27,6 +27,14 @@ static int update2(const gpk_update_t* upd, int nupd, double alpha, void* ctrl, 
     return gpk_gemm_persist_launch<T>(seg, nupd, (T)alpha, (unsigned*)ctrl, reserve, stream);
 }
 
+template <typename T>
+static int potrf_rows_any(T* a, int64_t n, int64_t rows, int64_t ld, T* dinv, T* dinv_sb, int nb, int sb, T* ws, int* info, hipStream_t stream) {
+    if (rows < n) return GPK_ERR_ARG(4);
+    if (n % GPK_DB != 0 && rows > n) return GPK_ERR_ARG(3);
+    if (nb > 0) return gpk_potrf_la_launch<T>(a, n, ld, dinv, dinv_sb, nb, ws, info, stream, sb, rows);
+    return gpk_potrf_rows_launch<T>(a, n, rows, ld, dinv, info, stream);
+}
+
 extern "C" {
 
 int gpk_version(void) { return 100; }
@@ -62,6 +70,11 @@ int64_t gpk_potrf_la_ws_elems(int64_t n, int nb) { return gpk_potrf_la_ws_elems_
 int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_nb, int nb, void* ws, int* info,
                  void* stream) {
     D1(dtype, gpk_potrf_la_launch<T>((T*)a, n, ld, (T*)dinv, (T*)dinv_nb, nb, (T*)ws, info, (hipStream_t)stream));
+}
+
+int gpk_potrf_rows(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
+                   void* stream) {
+    D1(dtype, potrf_rows_any<T>((T*)a, n, rows, ld, (T*)dinv, (T*)dinv_sb, nb, sb, (T*)ws, info, (hipStream_t)stream));
 }
 
 int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
@@ -154,6 +167,10 @@ int gpk_colreduce(int dtype, const void* v, int64_t rows, int64_t cols, int64_t 
                   void* stream) {
     D1(dtype, gpk_colreduce_launch<T>((const T*)v, rows, cols, ld, sv, (const T*)w, sw, (T*)out_dot,
                                       (T*)out_ss, (T*)ws, batch, (hipStream_t)stream));
+}
+
+int gpk_rowreduce(int dtype, const void* z, int64_t rows, int64_t n, int64_t ld, const void* w, void* out_dot, void* out_ss, void* stream) {
+    D1(dtype, gpk_rowreduce_launch<T>((const T*)z, rows, n, ld, (const T*)w, (T*)out_dot, (T*)out_ss, (hipStream_t)stream));
 }
 
 int gpk_tril(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* stream) {

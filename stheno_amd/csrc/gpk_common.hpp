@@ -167,7 +167,12 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
 int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb);
 template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
-                        hipStream_t stream, int sb = 0);     // sb: width of the explicit inverses (0 = nb); dinv_big: [ceil(n/sb)][sb][sb]
+                        hipStream_t stream, int sb = 0, int64_t rows = 0);     // sb: width of the explicit inverses (0 = nb); dinv_big: [ceil(n/sb)][sb][sb]
+                                                                                 // rows > n: rows under the matrix (gpk_potrf_la_rows in gpk.h)
+
+// One matrix with `rows - n` more rows under it (gpk_potrf_rows in gpk.h), the plain path: pipelined panels.
+template <typename T>
+int gpk_potrf_rows_launch(T* A, int64_t n, int64_t rows, int64_t ld, T* dinv, int* info, hipStream_t stream);
 
 void gpk_tune_gemm(int key, int64_t value);
 void gpk_tune_potrf(int key, int64_t value);
@@ -201,6 +206,8 @@ int64_t gpk_colreduce_nchunks_impl(int64_t rows);
 template <typename T>
 int gpk_colreduce_launch(const T* V, int64_t rows, int64_t cols, int64_t ld, int64_t sV, const T* w,
                          int64_t sw, T* odot, T* oss, T* ws, int64_t batch, hipStream_t stream);
+template <typename T>
+int gpk_rowreduce_launch(const T* Z, int64_t rows, int64_t n, int64_t ld, const T* w, T* odot, T* oss, hipStream_t stream);
 template <typename T>
 int gpk_tril_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream);
 template <typename T>

@@ -691,19 +691,19 @@ void gpk_helper_shutdown() {
 
 // ---- persistent launch: up to GPK_PERSIST_MAX_SEG k-major problems  C = Cin + alpha * A B^T  in one resident grid ----
 
-// tiles of a square lower-only problem of order M restricted to column groups (decode_striped); area: the elements of C they cover,
+// tiles of a lower-only problem (M >= N: the square part's lower triangle + every row below it) restricted to column groups (decode_striped); area: the elements of C they cover,
 // counted as the library counts a symmetric update (the diagonal tiles' upper halves are not useful work)
-static int64_t striped_tiles(int64_t M, int ts, int64_t grp, uint64_t mask, double* area) {
-    const int64_t tiles = gpk_cdiv(M, ts), W = grp / ts;
+static int64_t striped_tiles(int64_t M, int64_t N, int ts, int64_t grp, uint64_t mask, double* area) {
+    const int64_t tiles_m = gpk_cdiv(M, ts), tiles_n = gpk_cdiv(N, ts), W = grp / ts;
     int64_t n = 0;
     for (int g = 0; g < 64; ++g) {
         if (!((mask >> g) & 1u)) continue;
         const int64_t c0 = g * W;
-        if (c0 >= tiles) break;
-        const int64_t w = (W < tiles - c0) ? W : tiles - c0;
-        n += w * (w + 1) / 2 + (tiles - c0 - w) * w;
+        if (c0 >= tiles_n) break;
+        const int64_t w = (W < tiles_n - c0) ? W : tiles_n - c0;
+        n += w * (w + 1) / 2 + (tiles_m - c0 - w) * w;
         if (area != nullptr) {
-            const double rows = (double)(M - g * grp), cols = rows < (double)grp ? rows : (double)grp;
+            const double rows = (double)(M - g * grp), left = (double)(N - g * grp), cols = left < (double)grp ? left : (double)grp;
             *area += cols * rows - 0.5 * cols * cols;
         }
     }
@@ -726,8 +726,9 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         if (q.M <= 0 || q.N <= 0) continue;
         if (q.ldc >= GPK_C_LD_MAX || q.ldcin >= GPK_C_LD_MAX) return GPK_ERR_ARG(1);
         if (q.colmask != 0) {        // column groups of a square lower-only problem
-            if (!q.lower_only || q.M != q.N || q.tri_b || q.grp < 128 || q.grp % 128 != 0) return GPK_ERR_ARG(1);
-            t128 += striped_tiles(q.M, 128, q.grp, q.colmask, nullptr);
+            // (M > N: rows below the square part -- the look-ahead Cholesky carries the rows of K(x*, x) under the matrix it factorises)
+            if (!q.lower_only || q.M < q.N || q.tri_b || q.grp < 128 || q.grp % 128 != 0) return GPK_ERR_ARG(1);
+            t128 += striped_tiles(q.M, q.N, 128, q.grp, q.colmask, nullptr);
             continue;
         }
         const int64_t tm = gpk_cdiv(q.M, 128), tn = gpk_cdiv(q.N, 128);
@@ -766,7 +767,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
         if (g.pair_cols) nt = (int64_t)g.tiles_m * (g.tiles_n / 2);
         g.colmask = q.colmask; g.grp_tiles = q.colmask != 0 ? (int)(q.grp / ts) : 0;
         double area = 0;            // elements of C the segment updates (striped segments)
-        if (q.colmask != 0) nt = striped_tiles(q.M, ts, q.grp, q.colmask, &area);
+        if (q.colmask != 0) nt = striped_tiles(q.M, q.N, ts, q.grp, q.colmask, &area);
         if (nt == 0) continue;
         pa.first[live] = (int)total;
         pa.sig[live] = q.signal ? 1 : 0;

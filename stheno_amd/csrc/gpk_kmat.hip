@@ -20,7 +20,9 @@ enum { GPK_K_EQ = 0, GPK_K_MATERN12 = 1, GPK_K_MATERN32 = 2, GPK_K_MATERN52 = 3,
 
 GPK_KNOB(int, g_kmat_compact, 1);   // tuning knob (gpk_tune(34, v)): 1-D compact grid for the lower triangle of a square matrix
 GPK_KNOB(int, g_kmat_band, 1);      // tuning knob (gpk_tune(12, v)): 1 = row-band kernel, 0 = the one-tile-per-workgroup kernel
+GPK_KNOB(int, g_kmat_band_f64_sqrt, 1);   // tuning knob (gpk_tune(51, v)): fp64 kernels with a square root (Matern) take the row-band kernel too
 void gpk_tune_kmat(int key, int64_t value) {
+    if (key == 51) GPK_KNOB_SET(g_kmat_band_f64_sqrt = (int)value;);
     if (key == 12) GPK_KNOB_SET(g_kmat_band = (int)value;);
     if (key == 34) GPK_KNOB_SET(g_kmat_compact = (int)value;);
 }
@@ -66,8 +68,25 @@ template <>
 __device__ __forceinline__ float gpk_exp<float>(float x) { return expf(x); }
 template <typename T>
 __device__ __forceinline__ T gpk_sqrtk(T x);
+// sqrt of a squared distance times a positive constant (x >= 0, often exactly 0 on the diagonal): the hardware rsq estimate, two
+// coupled Goldschmidt steps and one residual correction (the scheme of sqrt_rsqrt in gpk_potrf.hip: ~1 ulp) -- 10 FMA-class
+// operations, no range scaling, no branch -- instead of the library sqrt.  Arguments below 1e-280 (0 included: rsq would overflow)
+// give 0: the kernel value moves by < 1e-140.  NaN stays NaN.
 template <>
-__device__ __forceinline__ double gpk_sqrtk<double>(double x) { return sqrt(x); }
+__device__ __forceinline__ double gpk_sqrtk<double>(double x) {
+    const bool tiny = x < 1e-280;
+    const double xc = tiny ? 1.0 : x;
+    const double y = __builtin_amdgcn_rsq(xc);
+    double g = xc * y, h = 0.5 * y;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    g = fma(fma(-g, g, xc), h, g);
+    return tiny ? 0.0 : g;
+}
 template <>
 __device__ __forceinline__ float gpk_sqrtk<float>(float x) { return sqrtf(x); }
 
@@ -456,9 +475,9 @@ int gpk_kmat_launch(const int* kinds, const double* variances, const double* inv
     int prog = PROG_GENERIC;
     if (nterms == 1 && kinds[0] >= GPK_K_EQ && kinds[0] <= GPK_K_MATERN52) prog = kinds[0];
     if (nterms == 2 && kinds[0] == GPK_K_EQ && kinds[1] == GPK_K_LINEAR) prog = PROG_EQ_LINEAR;
-    // (fp64 with a square root in the kernel is bound by the libm sqrt + exp either way; there the one-tile kernel
-    // measured 15 % faster: 0.53 vs 0.62 ms at N = 16384)
-    const bool band_ok = sizeof(T) == 4 || prog == PROG_EQ || prog == PROG_EQ_LINEAR;
+    // (round 2, with the library sqrt + exp: the one-tile kernel was 15 % faster for fp64 kernels with a square root -- 0.53 vs 0.62 ms at
+    // N = 16384 -- and kept them; round 5: with the branch-free exp of round 3 and the rsq-based sqrt above, knob 51 decides)
+    const bool band_ok = sizeof(T) == 4 || prog == PROG_EQ || prog == PROG_EQ_LINEAR || g_kmat_band_f64_sqrt;
     if (d <= 8 && g_kmat_band && band_ok) {
         const int64_t tiles_x = gpk_cdiv(m, 64 * VEC);
         int ct = CT_MAX;

@@ -766,9 +766,16 @@ __device__ __forceinline__ void pipe_worker(const PipeArgs<T>& p, char* smem, in
                 fill_left = false;
                 continue;
             }
-            int ti = 0;
-            while ((ti + 1) * (ti + 2) / 2 <= ft) ++ti;
-            gemm_tile<T, 128, true, true, EDGE, 1, D3_WAVES>(p.fill, ti, ft - ti * (ti + 1) / 2, 0, 0, smem);
+            int ti = 0, tj;
+            const int ftn = p.fill.tiles_n, ftri = ftn * (ftn + 1) / 2;
+            if (ft < ftri) {
+                while ((ti + 1) * (ti + 2) / 2 <= ft) ++ti;
+                tj = ft - ti * (ti + 1) / 2;
+            } else {                       // the tile rows under the square part (rows under the matrix)
+                ti = ftn + (ft - ftri) / ftn;
+                tj = (ft - ftri) % ftn;
+            }
+            gemm_tile<T, 128, true, true, EDGE, 1, D3_WAVES>(p.fill, ti, tj, 0, 0, smem);
             continue;
         }
         if (!panel_left) return;
@@ -882,6 +889,11 @@ struct PanelCtx {
     int max_wgs = 0;   // workgroups a persistent launch on `stream` may count on at once (0: every CU of the device; a CU-masked stream: its CUs)
     unsigned* wait_word = nullptr;   // the first diagonal block of the next panel is ready when *wait_word == wait_value (another
     unsigned wait_value = 0;         // kernel, on another stream, is still writing it when the panel's launch starts); nullptr: it is ready
+    // Round 5: rows > n -- the buffer holds `rows - n` more rows under the square matrix (K(x*, x) of the posterior): they are carried
+    // through the factorisation like the rows below a diagonal block (panel solves + trailing updates) and come out as
+    // K(x*, x) L^{-T}.  One matrix, pipelined panels only; `dinv` then needs one slot more than ceil(n / 128).  0: rows = n.
+    int64_t rows = 0;
+    int64_t nrows() const { return rows > n ? rows : n; }
 };
 
 // Factor the panel columns [c0, c0 + w) (rows c0..n), all updates from columns
@@ -963,8 +975,8 @@ template <typename T>
 int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, int64_t fill_k = 0) {
     *done = false;
     const int64_t ke = (c0 + w < x.n) ? c0 + w : x.n;
-    const int64_t m = x.n - c0;
-    const bool last = (ke == x.n);
+    const int64_t m = x.nrows() - c0;
+    const bool last = (ke == x.n) && x.nrows() == x.n;      // (rows under the matrix: its last diagonal block has rows to solve too)
     PipeShape sh;
     sh.npb = (int)gpk_cdiv(ke - c0, GPK_DB);
     sh.nd = last ? sh.npb - 1 : sh.npb;
@@ -1014,21 +1026,21 @@ int potrf_panel_pipe(const PanelCtx<T>& x, int64_t c0, int64_t w, bool* done, in
     pa.panel_wgs = (int)workers;
     bool fill_edge = false;
     if (fill_k > 0 && ke < x.n) {
-        const int64_t mf = x.n - ke;
+        const int64_t mf = x.n - ke, mr = x.nrows() - ke;        // columns / rows of the trailing matrix (mr > mf: rows under the matrix)
         GemmArgs<T>& g = pa.fill;
         const T* P = x.A + ke * x.ld + (c0 - fill_k);
         g.A = P; g.B = P; g.C = x.A + ke * x.ld + ke; g.Cin = g.C;
         g.lda = x.ld; g.ldb = x.ld; g.ldc = x.ld; g.ldcin = x.ld;
         g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
-        g.M = (int)mf; g.N = (int)mf; g.K = (int)fill_k;
+        g.M = (int)mr; g.N = (int)mf; g.K = (int)fill_k;
         g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
-        g.tiles_m = (int)gpk_cdiv(mf, 128); g.tiles_n = g.tiles_m;
+        g.tiles_m = (int)gpk_cdiv(mr, 128); g.tiles_n = (int)gpk_cdiv(mf, 128);
         g.lower_only = 1; g.tri_k = 0; g.tri_k_lo = 0; g.tri_k_lo_b = 0; g.pair_cols = 0; g.colmask = 0; g.grp_tiles = 0;
         g.split_from = INT32_MAX;
         g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = 0; g.xcd_tiles = 0;
         g.vec_ok = aligned ? 1 : 0;
-        fill_edge = !aligned || (mf % 128) || (fill_k % Traits<T>::BK) || g.lda >= GPK_PIPE_LD_MAX;
-        pa.fill_tiles = g.tiles_m * (g.tiles_m + 1) / 2;
+        fill_edge = !aligned || (mf % 128) || (mr % 128) || (fill_k % Traits<T>::BK) || g.lda >= GPK_PIPE_LD_MAX;
+        pa.fill_tiles = g.tiles_n * (g.tiles_n + 1) / 2 + (g.tiles_m - g.tiles_n) * g.tiles_n;     // lower triangle + the full tile rows under it
         // the panel is chain-bound: a third of the chip keeps its task list moving, the rest starts with the fill tiles
         workers = cus - 1;
         pa.panel_wgs = g_pipe_panel_wgs > 0 ? g_pipe_panel_wgs : (cus - 1) / 3;
@@ -1063,11 +1075,12 @@ __global__ void wait_word_kernel(unsigned* word, unsigned value) {
 
 template <typename T>
 int potrf_panel_any(const PanelCtx<T>& x, int64_t c0, int64_t w) {
-    if (g_pipe && x.batch == 1 && x.dinv != nullptr && x.n - c0 > GPK_DB) {
+    if (g_pipe && x.batch == 1 && x.dinv != nullptr && (x.n - c0 > GPK_DB || x.nrows() > x.n)) {
         bool done = false;
         const int st = potrf_panel_pipe<T>(x, c0, w, &done);
         if (st || done) return st;
     }
+    if (x.nrows() > x.n) return GPK_ERR_ARG(2);      // rows under the matrix: the pipelined panel or nothing
     if (x.wait_word != nullptr) {      // the paths below start from the diagonal block right away
         hipLaunchKernelGGL(wait_word_kernel, dim3(1), dim3(64), 0, x.stream, x.wait_word, x.wait_value);
         GPK_CHECK_LAUNCH();
@@ -1085,10 +1098,12 @@ void gpk_set_diag_prof(long long* dev_buf) { g_diag_prof = dev_buf; }
 
 template <typename T>
 static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
-                       int* info, int nbo, int info_base, hipStream_t stream) {
+                       int* info, int nbo, int info_base, hipStream_t stream, int64_t rows = 0) {
     if (n <= 0 || batch <= 0) return GPK_OK;
-    if (n > INT32_MAX) return GPK_ERR_ARG(2);
+    if (rows < n) rows = n;
+    if (rows > INT32_MAX) return GPK_ERR_ARG(2);
     if (ld < n) return GPK_ERR_ARG(3);
+    if (rows > n && (batch != 1 || dinv == nullptr || !g_pipe)) return GPK_ERR_ARG(2);
     // one matrix: the pipelined panel (potrf_panel_pipe) takes whole matrices up to 4096 as ONE panel; above, the trailing matrix is
     // big enough for the rank-nbo update GEMM to be worth its launch (measured: N = 8192 5.76 ms at 1024, 5.97 at 2048, 6.07 at 512)
     if (nbo <= 0) nbo = (batch == 1 && dinv != nullptr) ? (n <= 4096 ? 4096 : 1024) : ((n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256));
@@ -1099,6 +1114,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     const int64_t dstride = nblk * GPK_DB * GPK_DB;
 
     PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream, info_base};
+    ctx.rows = rows;
     // One matrix, pipelined panels: a panel's launch is chain-bound and leaves most of the chip idle, and all it needs of the
     // previous panel's rank-nbo update are its own columns.  So that update is split: the strip of the next panel's columns is a
     // GEMM launch of its own, the rest (the lower triangle right of the next panel) rides along in the next panel's launch as fill
@@ -1111,7 +1127,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
         if (owed > 0) {
             // the strip: columns [k0, k1), rows k0 .. n-1
             const T* P = A + k0 * ld + (k0 - owed);
-            int st = gpk_gemm_launch<T>(true, true, n - k0, k1 - k0, owed, T(-1), P, ld, bstride, P, ld, bstride, T(1), A + k0 * ld + k0, ld,
+            int st = gpk_gemm_launch<T>(true, true, rows - k0, k1 - k0, owed, T(-1), P, ld, bstride, P, ld, bstride, T(1), A + k0 * ld + k0, ld,
                                         bstride, batch, true, stream);
             if (st) return st;
             if (k1 < n && n - k0 > GPK_DB) {
@@ -1120,7 +1136,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
             }
             if (!done && k1 < n) {      // the panel did not take it along: the rest of the update as a launch of its own
                 const T* P2 = A + k1 * ld + (k0 - owed);
-                st = gpk_gemm_launch<T>(true, true, n - k1, n - k1, owed, T(-1), P2, ld, bstride, P2, ld, bstride, T(1), A + k1 * ld + k1, ld,
+                st = gpk_gemm_launch<T>(true, true, rows - k1, n - k1, owed, T(-1), P2, ld, bstride, P2, ld, bstride, T(1), A + k1 * ld + k1, ld,
                                         bstride, batch, true, stream);
                 if (st) return st;
             }
@@ -1135,7 +1151,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
                 owed = k1 - k0;
             } else {
                 const T* P = A + k1 * ld + k0;
-                int st = gpk_gemm_launch<T>(true, true, n - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, P, ld,
+                int st = gpk_gemm_launch<T>(true, true, rows - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, P, ld,
                                             bstride, T(1), A + k1 * ld + k1, ld, bstride, batch, true, stream);
                 if (st) return st;
             }
@@ -1272,13 +1288,15 @@ int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb) {
 
 template <typename T>
 static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* ws, int* info,
-                         hipStream_t stream);
+                         hipStream_t stream, int64_t rows);
 
 template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
-                        hipStream_t stream, int sb) {
+                        hipStream_t stream, int sb, int64_t rows) {
     if (n <= 0) return GPK_OK;
-    if (n > INT32_MAX) return GPK_ERR_ARG(2);
+    if (rows < n) rows = n;
+    if (rows > INT32_MAX) return GPK_ERR_ARG(2);
+    if (rows > n && n % GPK_DB != 0) return GPK_ERR_ARG(2);      // rows under the matrix: whole 128-blocks only
     if (ld < n) return GPK_ERR_ARG(3);
     if (nb < 256 || nb > 4096 || (nb & (nb - 1))) return GPK_ERR_ARG(6);
     if (sb <= 0) sb = nb;
@@ -1288,7 +1306,7 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     std::lock_guard<std::mutex> lock(g_la_mutex);
     LaDevice* dev = la_device();
     if (dev == nullptr) return GPK_ERR_LAUNCH;
-    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, stream);
+    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, stream, rows);
 
     // The legacy default stream (what torch's default stream is) synchronises implicitly with every BLOCKING
     // stream -- and the CU-masked helper stream is one (hipExtStreamCreateWithCUMask takes no flags): each
@@ -1302,21 +1320,23 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     hipEvent_t e_in = la_event(*dev, 0), e_out = la_event(*dev, 1);
     if (e_in == nullptr || e_out == nullptr) return GPK_ERR_LAUNCH;
     if (hipEventRecord(e_in, nullptr) != hipSuccess || hipStreamWaitEvent(dev->priv, e_in, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, dev->priv);
+    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, dev->priv, rows);
     // joined whatever `st` is: what was enqueued on the private stream before a failure still uses the caller's buffers
     if (hipEventRecord(e_out, dev->priv) != hipSuccess || hipStreamWaitEvent(nullptr, e_out, 0) != hipSuccess) return st ? st : GPK_ERR_LAUNCH;
     return st;
 }
 
+// rows > n: `rows - n` more rows under the square matrix (PanelCtx::rows): every panel solve and trailing update carries them.
 template <typename T>
 static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* ws, int* info,
-                         hipStream_t stream) {
+                         hipStream_t stream, int64_t rows) {
+    const int64_t R = rows;              // rows of the buffer (>= n)
     unsigned* ctrl = reinterpret_cast<unsigned*>(ws);                   // 64 elements reserved
     // n x nb, leading dimension nb + 16: with a power-of-two pitch the rows of a tile sit on a few memory channels and
     // the panel GEMM, which streams this buffer once, crawls (measured 2x)
     const int64_t ldt = nb + GPK_LA_PAD;
     T* Tp = ws + 64;
-    T* tmp = Tp + (n > nb ? n : nb) * ldt;
+    T* tmp = Tp + (R > nb ? R : nb) * ldt;
     const int64_t nblk = gpk_cdiv(n, nb);
     const int64_t per = (int64_t)sb * sb;      // one explicit inverse
     size_t ev = 2;                       // (events 0 and 1 belong to the default-stream stand-in)
@@ -1325,18 +1345,19 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     // (no explicit block inverse, no separate panel GEMM) is faster -- measured crossover ~5000 rows.
     auto finish_plain = [&](int64_t k) -> int {       // factor A[k:, k:] (all earlier panels applied) the plain way
         int s = potrf_plain<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB), info,
-                               0, (int)k, stream);
+                               0, (int)k, stream, R - k);
         if (s) return s;
         return gpk_trtri_merge_launch<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB),
                                          sb, dinv_big + (k / sb) * per, Tp, stream);   // the panel workspace is free by now
     };
-    const int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : 6144;
+    int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : 6144;
+    if (R > n && tail_rows < nb) tail_rows = nb;      // (rows under the matrix: the last column block's rows are solved by the plain tail)
     if (n <= tail_rows) return finish_plain(0);
 
     int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, 0, stream);
     if (st) return st;
     if (nblk > 1) {   // the first panel enters the workspace as it is
-        st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, n - nb, nb, 1, stream);
+        st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, R - nb, nb, 1, stream);
         if (st) return st;
     }
     // applied[c]: panels 0 .. applied[c] - 1 have been subtracted from column block c (columns c nb ..., the rows from its diagonal
@@ -1360,8 +1381,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         const int64_t kc = c_first * nb, ka = (int64_t)cg.from * nb;
         const T* P = A + kc * ld + ka;
         const uint64_t every = (nblk - c_first >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << (nblk - c_first)) - 1);
-        return GpkSeg<T>{n - kc, n - kc, k1 - ka, P, ld, P, ld, A + kc * ld + kc, ld, A + kc * ld + kc, ld, 1, 0, 0,
-                         cg.mask == every ? 0 : cg.mask, nb};
+        return GpkSeg<T>{R - kc, n - kc, k1 - ka, P, ld, P, ld, A + kc * ld + kc, ld, A + kc * ld + kc, ld, 1, 0, 0,
+                         (cg.mask == every && R == n) ? 0 : cg.mask, nb};
     };
     std::vector<ColGroup> groups;
     for (int64_t j = 0; j + 1 < nblk; ++j) {
@@ -1375,17 +1396,17 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             for (int64_t i = 0; i * sb < nb && st == GPK_OK; ++i) {
                 const int64_t c = i * sb;
                 if (i > 0)
-                    st = gpk_gemm_launch<T>(true, true, n - k1, sb, c, T(-1), A + k1 * ld + k0, ld, 0, A + (k0 + c) * ld + k0, ld, 0, T(1),
+                    st = gpk_gemm_launch<T>(true, true, R - k1, sb, c, T(-1), A + k1 * ld + k0, ld, 0, A + (k0 + c) * ld + k0, ld, 0, T(1),
                                             Tp + k1 * ldt + c, ldt, 0, 1, 0, stream);
                 if (st == GPK_OK)
-                    st = gpk_gemm_launch<T>(true, true, n - k1, sb, sb, T(1), Tp + k1 * ldt + c, ldt, 0, dinv_big + (k0 / sb + i) * per, sb, 0, T(0),
+                    st = gpk_gemm_launch<T>(true, true, R - k1, sb, sb, T(1), Tp + k1 * ldt + c, ldt, 0, dinv_big + (k0 / sb + i) * per, sb, 0, T(0),
                                             A + k1 * ld + k0 + c, ld, 0, 1, 8, stream);
             }
         } else if (g_la_ps_mode == 0) {
-            st = gpk_gemm_launch<T>(true, true, n - k1, nb, nb, T(1), Tp + k1 * ldt, ldt, 0, dinv_big + j * per, nb, 0, T(0),
+            st = gpk_gemm_launch<T>(true, true, R - k1, nb, nb, T(1), Tp + k1 * ldt, ldt, 0, dinv_big + j * per, nb, 0, T(0),
                                     A + k1 * ld + k0, ld, 0, 1, 8, stream);
         } else {
-            GpkSeg<T> ps{n - k1, nb, nb, Tp + k1 * ldt, ldt, dinv_big + j * per, nb, nullptr, 0, A + k1 * ld + k0, ld, 0, g_la_ps_mode};
+            GpkSeg<T> ps{R - k1, nb, nb, Tp + k1 * ldt, ldt, dinv_big + j * per, nb, nullptr, 0, A + k1 * ld + k0, ld, 0, g_la_ps_mode};
             st = gpk_gemm_persist_launch<T>(&ps, 1, T(1), ctrl, 0, stream);
         }
         if (st) return st;
@@ -1457,7 +1478,7 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
                 GpkSeg<T> seg[GPK_PERSIST_MAX_SEG];
                 int ns = 0;
                 if (fuse_diag) seg[ns++] = GpkSeg<T>{k2 - k1, k2 - k1, kd1, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0, 1};
-                const GpkSeg<T> strip{n - k2, k2 - k1, kd1, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
+                const GpkSeg<T> strip{R - k2, k2 - k1, kd1, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
                 // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
                 if (!g_la_strip_last) seg[ns++] = strip;
                 for (const ColGroup& cg : groups) seg[ns++] = col_segment(cg, j + 2, k1);
@@ -1485,14 +1506,21 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     return GPK_OK;
 }
 
-template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t, int);
-template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t, int);
+template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t, int, int64_t);
+template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t, int, int64_t);
 
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
                      int* info, int nbo, hipStream_t stream) {
     return potrf_plain<T>(A, n, ld, batch, bstride, dinv, info, nbo, 0, stream);
 }
+
+template <typename T>
+int gpk_potrf_rows_launch(T* A, int64_t n, int64_t rows, int64_t ld, T* dinv, int* info, hipStream_t stream) {
+    return potrf_plain<T>(A, n, ld, 1, 0, dinv, info, 0, 0, stream, rows);
+}
+template int gpk_potrf_rows_launch<double>(double*, int64_t, int64_t, int64_t, double*, int*, hipStream_t);
+template int gpk_potrf_rows_launch<float>(float*, int64_t, int64_t, int64_t, float*, int*, hipStream_t);
 
 template int gpk_potrf_launch<double>(double*, int64_t, int64_t, int64_t, int64_t, double*, int*,
                                       int, hipStream_t);

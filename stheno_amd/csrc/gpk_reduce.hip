@@ -251,6 +251,75 @@ int gpk_colreduce_launch(const T* V, int64_t rows, int64_t cols, int64_t ld, int
     return GPK_OK;
 }
 
+// Row reductions of Z (rows x n, row-major):  dot[i] = sum_k Z[i][k] w[k],  ss[i] = sum_k Z[i][k]^2  in one pass -- the posterior
+// mean and marginal variance from the TRANSPOSED whitened cross-covariance K(x*, x) L^{-T} that gpk_potrf_rows leaves under the
+// factor.  One wave per row, four 16-byte loads per lane in flight; fixed summation order.  HBM-bound: reads Z once.
+template <typename T>
+__global__ __launch_bounds__(256) void rowreduce_kernel(const T* __restrict__ Z, int64_t rows, int64_t n, int64_t ld, const T* __restrict__ w,
+                                                         T* __restrict__ odot, T* __restrict__ oss, int vec_ok) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* __restrict__ zr = Z + row * ld;
+    T dot = T(0), ss = T(0);
+    if (vec_ok) {
+        constexpr int U = 4;
+        for (int64_t k = (int64_t)lane * VEC; k < n; k += 64 * VEC * U) {
+            vec_t zv[U], wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t kk = k + (int64_t)u * 64 * VEC;
+                const bool ok = kk < n;
+                zv[u] = *reinterpret_cast<const vec_t*>(zr + (ok ? kk : 0));
+                if (w != nullptr) wv[u] = *reinterpret_cast<const vec_t*>(w + (ok ? kk : 0));
+                if (!ok) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) zv[u][v] = T(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    if (w != nullptr) dot += zv[u][v] * wv[u][v];
+                    ss += zv[u][v] * zv[u][v];
+                }
+        }
+    } else {
+        for (int64_t k = lane; k < n; k += 64) {
+            const T z = zr[k];
+            if (w != nullptr) dot += z * w[k];
+            ss += z * z;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dot += __shfl_xor(dot, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    if (lane == 0) {
+        if (odot != nullptr) odot[row] = dot;
+        if (oss != nullptr) oss[row] = ss;
+    }
+}
+
+template <typename T>
+int gpk_rowreduce_launch(const T* Z, int64_t rows, int64_t n, int64_t ld, const T* w, T* odot, T* oss, hipStream_t stream) {
+    if (rows <= 0) return GPK_OK;
+    if (n < 0 || ld < n) return GPK_ERR_ARG(3);
+    if (odot != nullptr && w == nullptr) return GPK_ERR_ARG(5);
+    constexpr int VEC = Traits<T>::VEC;
+    const int vec_ok = ((uintptr_t)Z % 16 == 0) && (ld % VEC == 0) && (n % VEC == 0) && (w == nullptr || (uintptr_t)w % 16 == 0);
+    hipLaunchKernelGGL((rowreduce_kernel<T>), dim3((unsigned)gpk_cdiv(rows, 4)), dim3(256), 0, stream, Z, rows, n, ld,
+                       (odot != nullptr) ? w : (const T*)nullptr, odot, oss, vec_ok);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+template int gpk_rowreduce_launch<double>(const double*, int64_t, int64_t, int64_t, const double*, double*, double*, hipStream_t);
+template int gpk_rowreduce_launch<float>(const float*, int64_t, int64_t, int64_t, const float*, float*, float*, hipStream_t);
+
 template <typename T>
 int gpk_tril_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream) {
     if (n <= 0 || batch <= 0) return GPK_OK;

@@ -18,7 +18,10 @@
 #include "gpk_common.hpp"
 
 GPK_KNOB(int, g_trsv_batched, 1);      // tuning knob (gpk_tune(17, v)): one-workgroup-per-matrix TRSV for batches of small factors
-GPK_KNOB(int, g_trsv_sweep, 1);        // tuning knob (gpk_tune(49, v)): the single-column solve of one factor as ONE resident launch (trsv_sweep_kernel)
+GPK_KNOB(int, g_trsv_sweep, 0);        // tuning knob (gpk_tune(49, v)): the single-column solve of one factor as ONE resident launch (trsv_sweep_kernel).
+                                       // OFF: measured SLOWER than the per-block sweep (profiles/r05_ab_trsv_sweep.log: fp64 N = 16384, 1024-blocks 0.584 vs
+                                       // 0.470 ms; fp32 N = 32768, 512-blocks 1.96 vs 1.15 ms) -- a grid barrier costs ~7 us (MI355X_MICROARCH.md, barrier-counter)
+                                       // against ~1.5 us for a dependent kernel boundary, and the sweep needs 2 n / sb of either
 GPK_KNOB(int64_t, g_trsv_sweep_from, 2048);   // tuning knob (gpk_tune(50, v)): ... from this order
 void gpk_tune_solve(int key, int64_t value) {
     if (key == 17) GPK_KNOB_SET(g_trsv_batched = (int)value;);

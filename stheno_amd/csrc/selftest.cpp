@@ -451,6 +451,7 @@ template <typename T>
 static void test_potrf() {
     // the single-launch sweep for one right-hand side (trsv_sweep_kernel): orders from 2048 take it by default; ragged last blocks,
     // every block width it serves, and (dev build) small orders with the threshold lowered
+    gpk_tune(49, 1);           // (off by default since it measured slower than the per-block sweep: profiles/r05_ab_trsv_sweep.log)
     test_potrf_case<T>(2500, 1, 0, 1, 0, 512);
     test_potrf_case<T>(4500, 1, 0, 1, 0, 1024);
     test_potrf_case<T>(2304, 1, 0, 1, 0, 256);
@@ -459,6 +460,7 @@ static void test_potrf() {
     test_potrf_case<T>(700, 1, 0, 1, 0, 256);
     test_potrf_case<T>(1664, 1, 256, 1, 0, 512);
     gpk_tune(50, 2048);
+    gpk_tune(49, 0);
     test_potrf_case<T>(10, 1, 0, 1, 3, 128);
     test_potrf_case<T>(100, 3, 0, 2, 0, 128);
     test_potrf_case<T>(128, 1, 0, 1, 130, 128);
@@ -579,6 +581,71 @@ static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_
         snprintf(nm, sizeof nm, "potrf_la_%s n%d nb%d dinv128", DT<T>::name(), n, nb);
         report(nm, nu / dn, DT<T>::eps * 1000);
     }
+}
+
+// factorisation with rows under the matrix (gpk_potrf_rows): the factor against the plain path's, the extra rows against E L^{-T}
+// by substitution on the host
+template <typename T>
+static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail, int agg = 2) {
+    const int64_t ld = n, rows = n + extra;
+    auto A = make_spd<T>(n, 1, ld);
+    auto E = randv<T>((size_t)extra * ld);
+    std::vector<T> full((size_t)rows * ld);
+    std::copy(A.begin(), A.end(), full.begin());
+    std::copy(E.begin(), E.end(), full.begin() + (size_t)n * ld);
+    const int wb = sb > 0 ? sb : (nb > 0 ? nb : 128);
+    const int nblk = (n + wb - 1) / wb;
+    Dev<T> dA(full.size()), dRef(A.size()), dinv((size_t)gpk_dinv_elems(n) + 128 * 128), dinv2((size_t)gpk_dinv_elems(n)), dbig((size_t)nblk * wb * wb),
+        ws((size_t)(nb > 0 ? gpk_potrf_la_ws_elems(rows, nb) : 16));
+    Dev<int> info(1), info2(1);
+    dA.up(full); dRef.up(A); info.zero(); info2.zero();
+    gpk_tune(9, tail); gpk_tune(47, agg);
+    const int st = gpk_potrf_rows(DT<T>::v, dA.p, n, rows, ld, dinv.p, dbig.p, nb, sb, ws.p, info.p, nullptr);
+    gpk_tune(9, 0); gpk_tune(47, 2);
+    const int st2 = gpk_potrf(DT<T>::v, dRef.p, n, ld, 0, 1, dinv2.p, info2.p, 0, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto G = dA.down(), R = dRef.down();
+    double num = 0, den = 0, znum = 0, zden = 0;
+    bool finite = true;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            const double g = G[(size_t)i * ld + j], r = R[(size_t)i * ld + j];
+            if (!std::isfinite(g)) finite = false;
+            num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
+        }
+    std::vector<double> z(n);
+    for (int e = 0; e < extra; ++e) {           // z L^T = E[e]:  z_j = (E[e][j] - sum_{k<j} z_k L[j][k]) / L[j][j]
+        for (int j = 0; j < n; ++j) {
+            double acc = E[(size_t)e * ld + j];
+            for (int k = 0; k < j; ++k) acc -= z[k] * (double)R[(size_t)j * ld + k];
+            z[j] = acc / (double)R[(size_t)j * ld + j];
+        }
+        for (int j = 0; j < n; ++j) {
+            const double g = G[(size_t)(n + e) * ld + j];
+            if (!std::isfinite(g)) finite = false;
+            znum = std::max(znum, std::fabs(g - z[j])); zden = std::max(zden, std::fabs(z[j]));
+        }
+    }
+    char nm[200];
+    snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d st%d/%d info%d: factor", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg, st, st2, info.down()[0]);
+    report(nm, (st || st2 || !finite || info.down()[0]) ? INFINITY : num / den, DT<T>::eps * 100);
+    snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d: rows = E L^-T", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg);
+    report(nm, (st || !finite) ? INFINITY : znum / zden, DT<T>::eps * 2000);
+}
+
+template <typename T>
+static void test_potrf_rows() {
+    test_potrf_rows_case<T>(128, 64, 0, 0, 0);             // one diagonal block + rows
+    test_potrf_rows_case<T>(640, 200, 0, 0, 0);            // one pipelined panel
+    test_potrf_rows_case<T>(1024, 300, 0, 0, 0);
+    test_potrf_rows_case<T>(2560, 333, 0, 0, 0);
+    test_potrf_rows_case<T>(5120, 260, 0, 0, 0);           // several panels (1024 wide), fill tiles with rows under the square part
+    test_potrf_rows_case<T>(3072, 300, 512, 0, 1024);      // look-ahead + plain tail
+    test_potrf_rows_case<T>(3072, 300, 512, 256, 1024);    // ... explicit inverses narrower than the outer blocks
+    test_potrf_rows_case<T>(4096, 520, 1024, 0, 2048, 1);
+    test_potrf_rows_case<T>(4096, 130, 256, 0, 512, 3);
+    test_potrf_rows_case<T>(3840, 1000, 256, 0, 100, 2);   // tail shorter than a block: raised to one block
+    test_potrf_rows_case<T>(2048, 77, 256, 0, 0);          // n <= the default tail: all plain
 }
 
 template <typename T>
@@ -1198,7 +1265,12 @@ static void perf_kmat() {
     perf_kmat_case<float>("cfg3 N=32768 D=4 EQ+Lin lower", 2, eql, 32768, 0, 4, 1, 1);
     perf_kmat_case<float>("cfg4 512xN=2048 D=3 EQ lower", 1, eq, 2048, 0, 3, 512, 1);
     perf_kmat_case<float>("cfg5 4096x200000 D=8 EQ", 1, eq, 4096, 200000, 8, 1, 0);
+    const int m32[1] = {GPK_K_MATERN32}, m12[1] = {GPK_K_MATERN12};
     perf_kmat_case<double>("N=16384 D=8 Matern52 lower", 1, m52, 16384, 0, 8, 1, 1);
+    perf_kmat_case<double>("N=16384 D=8 Matern32 lower", 1, m32, 16384, 0, 8, 1, 1);
+    perf_kmat_case<double>("N=16384 D=8 Matern12 lower", 1, m12, 16384, 0, 8, 1, 1);
+    perf_kmat_case<double>("N=16384 D=3 Matern52 lower", 1, m52, 16384, 0, 3, 1, 1);
+    perf_kmat_case<float>("N=32768 D=4 Matern52 lower", 1, m52, 32768, 0, 4, 1, 1);
     perf_kmat_case<float>("N=16384x2048 D=8 EQ (K_x*)", 1, eq, 16384, 2048, 8, 1, 0);
 }
 
@@ -1847,6 +1919,11 @@ int main(int argc, char** argv) {
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
             return g_fail ? 1 : 0;
         }
+        if (!strcmp(argv[i], "--rows")) {                      // only the factorisations with rows under the matrix
+            test_potrf_rows<double>(); test_potrf_rows<float>();
+            printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
+            return g_fail ? 1 : 0;
+        }
         if (!strcmp(argv[i], "--lookahead")) {                 // only the look-ahead / persistent-update checks
             test_lookahead<double>(); test_lookahead<float>();
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
@@ -1895,6 +1972,7 @@ int main(int argc, char** argv) {
         test_kmat<double>(); test_kmat<float>();
         test_potrf<double>(); test_potrf<float>();
         test_lookahead<double>(); test_lookahead<float>();
+        test_potrf_rows<double>(); test_potrf_rows<float>();
         test_misc<double>(); test_misc<float>();
         test_vjp_dense<double>(); test_vjp_dense<float>();
         printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);

@@ -762,6 +762,17 @@ def _cross(cache, k, z, x):
     return cache[key][0]
 
 
+class WhitenedT:
+    """``k(x, z) L^{-T}`` (ns, n): the TRANSPOSE of the whitened cross-covariance ``L^{-1} k(z, x)`` -- what the factorisation with
+    rows under the matrix leaves behind (``KernelDense.chol_with_rows``).  The consumers below take either form."""
+
+    def __init__(self, zt):
+        self.zt = zt
+
+    def plain(self):
+        return self.zt.transpose(-1, -2).contiguous()
+
+
 def _whiten(cache, K_z, k, z, x, own_cross=False):
     """``L^{-1} k(z, x)`` (memoised), ``L = chol(K_z)``.  ``own_cross``: nobody else will ask for ``k(z, x)`` itself (dense
     conditioning: ``K_z`` is the only matrix it is ever solved against) -- the cross matrix is then not kept and the blocked solve
@@ -769,6 +780,15 @@ def _whiten(cache, K_z, k, z, x, own_cross=False):
     key = ("v", id(K_z), id(k), id(z), id(x))
     if cache is not None and key in cache:
         return cache[key][0]
+    # Nothing factorised yet (conditioning, then prediction, no log-density in between): the cross-covariance rides in the
+    # factorisation as rows under the kernel matrix and comes out whitened, transposed -- no separate many-column solve.
+    if (own_cross and hasattr(K_z, "can_factor_with_rows") and k.terms() is not None and x.dim() == 2 and z.dim() == 2 and not x.requires_grad
+            and ("kzx", id(k), id(z), id(x)) not in (cache or {}) and z is getattr(K_z, "x", None) and K_z.can_factor_with_rows(x.shape[-2])):
+        _, zt = K_z.chol_with_rows(k, x)
+        v = WhitenedT(zt)
+        if cache is not None:
+            cache[key] = (v, K_z, k, z, x)
+        return v
     chol = K_z.chol()
     if own_cross and hasattr(chol, "solve_") and ("kzx", id(k), id(z), id(x)) not in (cache or {}):
         kzx = k.pairwise(z, x)
@@ -803,7 +823,11 @@ class PosteriorKernel(Kernel):
         # out -= vx^T vy   (operands stored (K, M) / (K, N): row index contiguous)
         if out.stride(-1) != 1 and out.shape[-1] > 1:
             out = out.contiguous()          # e.g. the transposed view a reversed cross-kernel hands back
-        ops.get_backend().gemm(vx, vy, a_kmajor=False, b_kmajor=False, alpha=-1.0, beta=1.0, out=out)
+        if isinstance(vx, WhitenedT) and isinstance(vy, WhitenedT):      # both transposed: the k-contiguous form of the same product
+            ops.get_backend().gemm(vx.zt, vy.zt, a_kmajor=True, b_kmajor=True, alpha=-1.0, beta=1.0, out=out)
+        else:
+            vx, vy = (v.plain() if isinstance(v, WhitenedT) else v for v in (vx, vy))
+            ops.get_backend().gemm(vx, vy, a_kmajor=False, b_kmajor=False, alpha=-1.0, beta=1.0, out=out)
         return _add_diag(out, diag_add, diag_vec) if sym else out
 
     def elwise(self, x, y=None, *, cache=None):
@@ -811,9 +835,13 @@ class PosteriorKernel(Kernel):
         out = self.k_ij.elwise(x)
         vx = _whiten(cache, self.K_z, self.k_zi, self.z, x, self.own_cross)
         if self.k_zi is self.k_zj:
-            _, ss = ops.get_backend().colreduce(vx, want_ss=True)
+            if isinstance(vx, WhitenedT):
+                _, ss = ops.get_backend().rowreduce(vx.zt, want_dot=False, want_ss=True)
+            else:
+                _, ss = ops.get_backend().colreduce(vx, want_ss=True)
             return out - ss[..., None]
         vy = _whiten(cache, self.K_z, self.k_zj, self.z, x, self.own_cross)
+        vx, vy = (v.plain() if isinstance(v, WhitenedT) else v for v in (vx, vy))
         return out - (vx * vy).sum(-2)[..., None]
 
 
@@ -868,8 +896,14 @@ class PosteriorMean(Mean):
 
     def __call__(self, x, cache=None):
         x = uprank(x)
-        v = _whiten(cache, self.K_z, self.k_zi, self.z, x, self.own_cross)
-        dot, _ = ops.get_backend().colreduce(v, self._whitened_residual(), want_dot=True, want_ss=False)
+        v = _whiten(cache, self.K_z, self.k_zi, self.z, x, self.own_cross)       # (first: it may be what factorises K_z)
+        w = self._whitened_residual()
+        if isinstance(v, WhitenedT):
+            if w.shape[-1] == 1:
+                dot, _ = ops.get_backend().rowreduce(v.zt, w, want_dot=True, want_ss=False)
+                return self.m_i(x) + dot[..., None]
+            v = v.plain()
+        dot, _ = ops.get_backend().colreduce(v, w, want_dot=True, want_ss=False)
         return self.m_i(x) + dot[..., None]
 
 

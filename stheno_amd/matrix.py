@@ -46,6 +46,12 @@ class _Config:
     potrf_lookahead_nb = {torch.float64: 1024, torch.float32: 1024}
     potrf_lookahead_inv = {torch.float64: 1024, torch.float32: 512}
     potrf_lookahead_wide_from = 11264
+    #: Posterior at `ns` new points when the observations' kernel matrix has not been factorised yet: from this order on (a multiple of
+    #: 128, one unbatched matrix, a kernel that is a sum of primitives) K(x*, x) is written UNDER the kernel matrix in one buffer and
+    #: carried through the factorisation (``gpk_potrf_rows``): it comes out as K(x*, x) L^{-T}, the transposed whitened cross-covariance,
+    #: and the separate many-column triangular solve disappears.  0 disables it.
+    posterior_rows_from = 2048
+    posterior_rows_min_points = 64
 
 
 config = _Config()
@@ -162,6 +168,7 @@ class Chol:
         self._clean = False
         self.lookahead_nb = 0
         self.lookahead_sb = 0
+        self.rows_under = 0
         self._residuals = {}
 
     @classmethod
@@ -192,6 +199,31 @@ class Chol:
             else:
                 c.check()
         return c
+
+    @classmethod
+    def factor_rows_(cls, buf, n):
+        """Factorise the leading ``n x n`` of ``buf`` (rows, n) IN PLACE, the rows under it riding along (``gpk_potrf_rows``): returns
+        ``(chol, zt)`` with ``zt = buf[n:]`` holding ``buf[n:] L^{-T}`` afterwards.  The factor is a view of ``buf``."""
+        be = ops.get_backend()
+        nb = sb = 0
+        if config.potrf_lookahead_from and n >= config.potrf_lookahead_from:
+            nb = config.potrf_lookahead_nb.get(buf.dtype, 0)
+            if nb > 512 and n < config.potrf_lookahead_wide_from:
+                nb = 512
+            sb = min(nb, config.potrf_lookahead_inv.get(buf.dtype, nb)) if nb else 0
+        dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb)
+        c = cls(buf[:n], dinv, info)
+        if nb:
+            c.lookahead_nb, c.lookahead_sb = nb, sb
+            if sb == _solve_block(n, 1, buf.dtype == torch.float64):
+                c._dinv_sb[sb] = dnb
+        c.rows_under = buf.shape[0] - n        # (which path ran; the tests ask)
+        if config.check_info:
+            if _deferred_state.pending is not None:
+                _deferred_state.pending.append(c)
+            else:
+                c.check()
+        return c, buf[n:]
 
     def check(self):
         if self._error is not None:
@@ -613,6 +645,31 @@ class KernelDense(Dense):
             self._chol = Chol.factor_(a)
             return self._chol
         return self._chol.vetted()
+
+    def can_factor_with_rows(self, ns):
+        """Whether :meth:`chol_with_rows` applies: nothing factorised or materialised yet, ONE matrix of an order the native path
+        takes (``config.posterior_rows_from``, a multiple of 128), diagonal noise, the HIP backend."""
+        if self._chol is not None or self._mat is not None or not config.posterior_rows_from:
+            return False
+        be = ops.get_backend()
+        if not hasattr(be, "potrf_rows_") or self.x.dim() != 2 or self.x.requires_grad:
+            return False
+        n = self.kernel.num_outputs(self.x)
+        if n != self.x.shape[-2] or n % 128 != 0 or n < config.posterior_rows_from or ns < config.posterior_rows_min_points or ns > 4 * n:
+            return False
+        return self._noise_parts()[2] is None
+
+    def chol_with_rows(self, k_cross, xs):
+        """The factor AND ``k_cross(xs, x) L^{-T}`` (ns, n) from one factorisation: the kernel matrix is built in the first ``n`` rows
+        of an (n + ns, n) buffer, the cross-covariance under it, and ``gpk_potrf_rows`` carries those rows through its panel solves
+        and trailing updates.  Replaces ``cholesky`` + ``solve(L, K_zx)`` of mlkernels' PosteriorKernel (observations.py:148-168)."""
+        n, ns = self.x.shape[-2], xs.shape[-2]
+        buf = torch.empty((n + ns, n), dtype=self.x.dtype, device=self.x.device)
+        _, dvec, _ = self._noise_parts()
+        self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n])
+        k_cross.pairwise(xs, self.x, out=buf[n:])
+        self._chol, zt = Chol.factor_rows_(buf, n)
+        return self._chol, zt
 
 
 class FactoredDense(Dense):

@@ -250,6 +250,46 @@ class HipBackend:
         return dinv, info
 
     @_on_operand_device
+    def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0):
+        """In-place lower Cholesky of the leading ``n x n`` of ``a`` (rows, n), rows > n, carrying the rows under it through the
+        factorisation (``gpk_potrf_rows``): they come out as ``a[n:] L^{-T}``.  ``n`` a multiple of 128.  Returns ``(dinv, info, dinv_sb or None)``."""
+        if a.dim() != 2 or a.stride(-1) != 1 or a.shape[0] <= a.shape[1] or a.shape[1] % 128 != 0:
+            raise ValueError("potrf_rows_ takes one (rows, n) matrix with rows > n, n a multiple of 128 and unit inner stride")
+        self._check(a)
+        rows, n = a.shape
+        dinv = torch.empty((1, n // 128 + 1, 128, 128), dtype=a.dtype, device=a.device)      # (one slot more: control words of the last panel)
+        info = torch.zeros((1,), dtype=torch.int32, device=a.device)
+        nb = int(lookahead_nb)
+        sb = (int(lookahead_sb) or nb) if nb else 0
+        dnb = ws = None
+        if nb:
+            dnb = torch.empty((1, (n + sb - 1) // sb, sb, sb), dtype=a.dtype, device=a.device)
+            ws = torch.empty((int(self.lib.gpk_potrf_la_ws_elems(rows, nb)),), dtype=a.dtype, device=a.device)
+        code = self.lib.gpk_potrf_rows(_dtype_id(a), self._ptr(a), n, rows, a.stride(0), self._ptr(dinv), self._ptr(dnb) if nb else None, nb,
+                                       sb if sb != nb else 0, self._ptr(ws) if nb else None, self._ptr(info), self._stream())
+        self._st(code, "gpk_potrf_rows")
+        return dinv[:, : n // 128], info, dnb
+
+    @_on_operand_device
+    def rowreduce(self, z, w=None, *, want_dot=True, want_ss=False):
+        """Row reductions of ``z`` (rows, n): ``dot[i] = sum_k z[i, k] w[k]`` and / or ``ss[i] = sum_k z[i, k]^2`` in one pass
+        (``gpk_rowreduce``) -- the posterior mean and marginal variance from the TRANSPOSED whitened cross-covariance."""
+        if z.dim() != 2 or z.stride(-1) != 1:
+            raise ValueError("rowreduce takes one matrix with unit inner stride")
+        self._check(z, w)
+        rows, n = z.shape
+        dot = torch.empty((rows,), dtype=z.dtype, device=z.device) if (want_dot and w is not None) else None
+        ss = torch.empty((rows,), dtype=z.dtype, device=z.device) if want_ss else None
+        if w is not None:
+            w = w.reshape(-1).contiguous()
+            if w.shape[0] != n:
+                raise ValueError("rowreduce: the vector has %d entries, the rows %d" % (w.shape[0], n))
+        code = self.lib.gpk_rowreduce(_dtype_id(z), self._ptr(z), rows, n, z.stride(0), self._ptr(w) if dot is not None else None,
+                                      self._ptr(dot) if dot is not None else None, self._ptr(ss) if ss is not None else None, self._stream())
+        self._st(code, "gpk_rowreduce")
+        return dot, ss
+
+    @_on_operand_device
     def trtri_merge(self, l, dinv, sb):
         l3, _ = _as3(l)
         self._check(l3, dinv)
