@@ -916,21 +916,29 @@ def _call_mean(mean, x, cache):
 
 def mean_var(mean, kernel, x):
     """Mean and variance sharing the cross-kernel evaluations."""
+    from .matrix import deferred_checks
+
     cache = {}
     x = uprank(x)
-    m = _call_mean(mean, x, cache)
-    if _accepts_cache(kernel):
-        var = Dense(kernel.pairwise(x, None, cache=cache))
-    else:
-        var = KernelDense(kernel, x, None)
+    # (a posterior evaluated before anything factorised its observations factorises here: the `info` word is read when the
+    # reductions / products that depend on the factor are queued behind it, not in front of them -- as `Normal.logpdf` does)
+    with deferred_checks():
+        m = _call_mean(mean, x, cache)
+        if _accepts_cache(kernel):
+            var = Dense(kernel.pairwise(x, None, cache=cache))
+        else:
+            var = KernelDense(kernel, x, None)
     return m, var
 
 
 def mean_var_diag(mean, kernel, x):
     """Mean and marginal variances without forming the covariance
     (``tests/model/test_gp.py:201-211``)."""
+    from .matrix import deferred_checks
+
     cache = {}
     x = uprank(x)
-    m = _call_mean(mean, x, cache)
-    vd = kernel.elwise(x, cache=cache) if _accepts_cache(kernel) else kernel.elwise(x)
+    with deferred_checks():          # (see mean_var)
+        m = _call_mean(mean, x, cache)
+        vd = kernel.elwise(x, cache=cache) if _accepts_cache(kernel) else kernel.elwise(x)
     return m, vd
