@@ -962,6 +962,7 @@ GPK_KNOB(int, g_fused_step, 1);              // tuning knob (gpk_tune(32, v)): s
 
 GPK_KNOB(int, g_pipe, 1);                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
 int g_pipe_cus = 0;                // CUs of the current device (queried once)
+GPK_KNOB(int64_t, g_plain_nbo, 1024);        // tuning knob (gpk_tune(52, v)): panel width of the pipelined plain path for single matrices above 4096
 GPK_KNOB(int, g_pipe_fill, 1);               // tuning knob (gpk_tune(38, v)): the trailing update right of the NEXT panel rides along in that panel's launch
 GPK_KNOB(int, g_pipe_panel_wgs, 0);          // tuning knob (gpk_tune(39, v)): workgroups that take panel tasks first when a launch carries fill tiles (0: a third of the CUs)
 
@@ -1106,7 +1107,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     if (rows > n && (batch != 1 || dinv == nullptr || !g_pipe)) return GPK_ERR_ARG(2);
     // one matrix: the pipelined panel (potrf_panel_pipe) takes whole matrices up to 4096 as ONE panel; above, the trailing matrix is
     // big enough for the rank-nbo update GEMM to be worth its launch (measured: N = 8192 5.76 ms at 1024, 5.97 at 2048, 6.07 at 512)
-    if (nbo <= 0) nbo = (batch == 1 && dinv != nullptr) ? (n <= 4096 ? 4096 : 1024) : ((n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256));
+    if (nbo <= 0) nbo = (batch == 1 && dinv != nullptr) ? (n <= 4096 ? 4096 : (int)g_plain_nbo) : ((n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256));
     if (nbo < GPK_DB || (nbo & (nbo - 1))) return GPK_ERR_ARG(9);   // 128 * 2^k
     if (info == nullptr) return GPK_ERR_ARG(7);
     if (dinv == nullptr && n > GPK_DB) return GPK_ERR_ARG(6);
@@ -1277,6 +1278,7 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 41) GPK_KNOB_SET(g_la_fuse_diag_nb = (int)value;);
     if (key == 47) GPK_KNOB_SET(g_la_agg = (int)value;);
     if (key == 48) GPK_KNOB_SET(g_la_agg_min_rows = value;);
+    if (key == 52) GPK_KNOB_SET(g_plain_nbo = value;);
     if (key == 38) GPK_KNOB_SET(g_pipe_fill = (int)value;);
     if (key == 39) GPK_KNOB_SET(g_pipe_panel_wgs = (int)value;);
 }

@@ -1176,6 +1176,38 @@ static void perf_agg(int n, int nb, int sb, int rounds, const std::vector<int>& 
     gpk_tune(47, 2); gpk_tune(9, 0);
 }
 
+// factorisation with rows under the matrix, timed against the factorisation alone + the separate solve:  --perf-rows f64|f32 N EXTRA NB SB ROUNDS
+template <typename T>
+static void perf_rows(int n, int extra, int nb, int sb, int rounds) {
+    const int d = 8;
+    const int64_t rows = (int64_t)n + extra;
+    auto hx = randv<T>((size_t)n * d);
+    const int wb = sb > 0 ? sb : nb;
+    Dev<T> X(hx.size()), K((size_t)rows * n), dinv((size_t)gpk_dinv_elems(n) + 128 * 128), E((size_t)extra * n);
+    Dev<T> dbig((size_t)((n + wb - 1) / wb) * wb * wb), ws((size_t)gpk_potrf_la_ws_elems(rows, nb));
+    Dev<int> info(1);
+    X.up(hx);
+    E.up(randv<T>((size_t)extra * n, 0.01));
+    int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+    hipStream_t st;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    for (int r = 0; r <= rounds; ++r)
+        for (int with_rows = 0; with_rows < 2; ++with_rows) {
+            HIPCHK(hipMemsetAsync(info.p, 0, sizeof(int), st));
+            gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, 0, X.p, n, d, 0, d, K.p, n, 0, 1, 1, 1, 0.1, nullptr, 0, 0, st);
+            HIPCHK(hipMemcpyAsync(K.p + (size_t)n * n, E.p, sizeof(T) * (size_t)extra * n, hipMemcpyDeviceToDevice, st));
+            hipEventRecord(a, st);
+            gpk_potrf_rows(DT<T>::v, K.p, n, with_rows ? rows : n, n, dinv.p, dbig.p, nb, (sb > 0 && sb < nb) ? sb : 0, ws.p, info.p, st);
+            hipEventRecord(b, st);
+            HIPCHK(hipStreamSynchronize(st));
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (r > 0) printf("PERFROWS potrf_%s n=%d +%d rows nb=%d sb=%d %s round %d  %.3f ms  info=%d\n", DT<T>::name(), n, extra, nb, wb,
+                              with_rows ? "with the rows " : "matrix alone  ", r, ms, info.down()[0]);
+        }
+}
+
 // shader clock and k-loop pace of chosen trailing updates INSIDE a look-ahead factorisation:  --la-clock f64|f32 N NB
 template <typename T>
 static void la_clock(int n, int nb, int warm = 0) {
@@ -1944,6 +1976,11 @@ int main(int argc, char** argv) {
             for (int q = i + 7; q < argc && argv[q][0] != '-'; ++q) ml.push_back(atoi(argv[q]));
             if (ml.empty()) ml = {1, 2};
             if (!strcmp(argv[i + 1], "f64")) perf_agg<double>(n, nb, sb, rounds, ml, tail); else perf_agg<float>(n, nb, sb, rounds, ml, tail);
+            return 0;
+        }
+        if (!strcmp(argv[i], "--perf-rows") && i + 6 < argc) {    // --perf-rows f64|f32 N EXTRA NB SB ROUNDS
+            const int n = atoi(argv[i + 2]), extra = atoi(argv[i + 3]), nb = atoi(argv[i + 4]), sb = atoi(argv[i + 5]), rounds = atoi(argv[i + 6]);
+            if (!strcmp(argv[i + 1], "f64")) perf_rows<double>(n, extra, nb, sb, rounds); else perf_rows<float>(n, extra, nb, sb, rounds);
             return 0;
         }
         if (!strcmp(argv[i], "--la-clock") && i + 3 < argc) {
