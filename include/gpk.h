@@ -125,16 +125,6 @@ int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* di
 int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
                        void* stream);
 
-/* Kernel matrix AND factorisation of a batch in one call (round 5):  a[b] <- chol( k(x[b], x[b]) + diag_add I ),  b < batch.
- * Arguments as gpk_kmat (symmetric case, lower triangle) followed by those of gpk_potrf.  For ONE EQ term, d <= 8 and batch > 1 only
- * the columns of the first panel are built as a kernel matrix; every entry right of them is EVALUATED inside the first trailing update
- * of the factorisation (same arithmetic as gpk_kmat, entry for entry) -- it is never written as a kernel matrix nor read back (cfg4:
- * 56 % of 4.3 GB each way).  Any other kernel, and a single matrix, builds the whole matrix and factorises it: gpk_kmat + gpk_potrf.
- * Replaces `B.cholesky(B.reg(k(x) + noise))`: stheno/model/fdd.py:79 + stheno/random.py:274-276 (batched: tests/model/test_cases.py:134-155). */
-int gpk_kmat_potrf(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms, const void* x, int64_t n,
-                   int64_t ldx, int64_t sx, int d, double diag_add, void* a, int64_t ld, int64_t sa, int64_t batch, void* dinv, int* info,
-                   int nbo, void* stream);
-
 /* Factorisation WITH ROWS UNDER THE MATRIX (round 5): `a` holds `rows` >= n rows of n columns -- the symmetric matrix (lower
  * triangle read) in the first n, anything else below, typically K(x*, x) of the posterior.  The extra rows are carried through
  * the factorisation like the rows below a diagonal block: every panel solve and every trailing update includes them, and they

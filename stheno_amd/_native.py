@@ -42,8 +42,6 @@ SIGNATURES = {
     "gpk_potrf_la_ws_elems": (_c_i64, [_c_i64, _c_int]),
     "gpk_potrf_la": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     "gpk_potrf_la_split": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr]),
-    "gpk_kmat_potrf": (_c_int, [_c_int, _p_int, _p_dbl, _p_dbl, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_dbl, _c_ptr, _c_i64, _c_i64, _c_i64,
-                                _c_ptr, _c_ptr, _c_int, _c_ptr]),
     "gpk_potrf_rows": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     "gpk_gemm_update2": (_c_int, [_c_int, _c_ptr, _c_int, _c_dbl, _c_ptr, _c_int, _c_ptr]),
     "gpk_tune": (None, [_c_int, _c_i64]),

@@ -72,14 +72,6 @@ int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* di
     D1(dtype, gpk_potrf_la_launch<T>((T*)a, n, ld, (T*)dinv, (T*)dinv_nb, nb, (T*)ws, info, (hipStream_t)stream));
 }
 
-int gpk_kmat_potrf(int dtype, const int* kinds, const double* variances, const double* inv_ls, int nterms, const void* x, int64_t n,
-                   int64_t ldx, int64_t sx, int d, double diag_add, void* a, int64_t ld, int64_t sa, int64_t batch, void* dinv, int* info,
-                   int nbo, void* stream) {
-    if (kinds == nullptr || variances == nullptr || inv_ls == nullptr || nterms < 1) return GPK_ERR_ARG(2);
-    D1(dtype, gpk_kmat_potrf_launch<T>(kinds, variances, inv_ls, nterms, (const T*)x, n, ldx, sx, d, diag_add, (T*)a, ld, sa, batch, (T*)dinv,
-                                       info, nbo, (hipStream_t)stream));
-}
-
 int gpk_potrf_rows(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
                    void* stream) {
     D1(dtype, potrf_rows_any<T>((T*)a, n, rows, ld, (T*)dinv, (T*)dinv_sb, nb, sb, (T*)ws, info, (hipStream_t)stream));

@@ -105,17 +105,6 @@ int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T
                     T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, int flags,
                     hipStream_t stream);
 
-// C is not read but EVALUATED: C[m][n] = var exp(-0.5 c |x_m - x_n|^2) (+ diag where m == n), the EQ kernel matrix of the points
-// x + batch * sx + i * ldx (d <= 8 coordinates) as gpk_kmat builds it (gemm_tile, CGEN).  Both operands k-contiguous, 128-tiles only.
-template <typename T>
-struct GpkGen {
-    const T* x;
-    int64_t ldx, sx;
-    int d;
-    T var, c, diag;
-};
-bool gpk_gemm_gen_applicable(int64_t M, int64_t N, int64_t batch, bool lower);      // would such a launch take the 128-tile kernel?
-
 // Same with a second batch level (blockIdx.z) -- used to batch over regularly strided
 // sub-blocks of one matrix.
 template <typename T>
@@ -123,8 +112,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
                      const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
                      int64_t batch, int64_t batch2, int flags, hipStream_t stream,
-                     const T* colscale = nullptr, T* colss = nullptr, int64_t ldss = 0,      // fused column scaling / sums of squares (gpk_gemm_colscale)
-                     const GpkGen<T>* gen = nullptr);
+                     const T* colscale = nullptr, T* colss = nullptr, int64_t ldss = 0);     // fused column scaling / sums of squares (gpk_gemm_colscale)
 
 // Persistent two-problem update (see gemm_persist_kernel in gpk_gemm.hip): each segment is
 //   C[m][n] = Cin[m][n] + alpha * sum_k A[m][k] B[n][k]     (A: M x K, B: N x K, both k contiguous)
@@ -182,12 +170,6 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
                         hipStream_t stream, int sb = 0, int64_t rows = 0);     // sb: width of the explicit inverses (0 = nb); dinv_big: [ceil(n/sb)][sb][sb]
                                                                                  // rows > n: rows under the matrix (gpk_potrf_la_rows in gpk.h)
 
-// Kernel matrix (one EQ term) + factorisation of a batch, the part right of the first panel evaluated inside the first trailing
-// update (gpk_kmat_potrf in gpk.h).
-template <typename T>
-int gpk_kmat_potrf_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms, const T* X, int64_t n, int64_t ldx,
-                          int64_t sX, int d, double diag_add, T* A, int64_t ld, int64_t sA, int64_t batch, T* dinv, int* info, int nbo,
-                          hipStream_t stream);
 // One matrix with `rows - n` more rows under it (gpk_potrf_rows in gpk.h), the plain path: pipelined panels.
 template <typename T>
 int gpk_potrf_rows_launch(T* A, int64_t n, int64_t rows, int64_t ld, T* dinv, int* info, hipStream_t stream);

@@ -134,25 +134,6 @@ __global__ __launch_bounds__(256, (TS == 128 || NCT == 2 ? 2 : 4)) void gemm_ker
     gemm_tile<T, TS, A_KMAJ, B_KMAJ, EDGE, NCT, 4, false, PIPE>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
 }
 
-// The 128-tile, both operands k-contiguous, whose C tile is EVALUATED from the inputs instead of read (gemm_tile, CGEN): the first
-// trailing update of a batched factorisation made by gpk_kmat_potrf -- the part of the kernel matrix right of the first panel is never
-// written to memory as a kernel matrix, nor read back.
-template <typename T, bool EDGE>
-__global__ __launch_bounds__(256, 2) void gemm_cgen_kernel(GemmArgs<T> p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * op_bytes(128)];
-    int ti, tj;
-    if (p.xcd_batch > 0) {
-        const int L = (int)blockIdx.x, s = L >> 3;
-        const int m = (s / p.xcd_tiles) * 8 + (L & 7);
-        if (m >= p.xcd_batch) return;
-        if (!decode_tile(p, s % p.xcd_tiles, ti, tj)) return;
-        gemm_tile<T, 128, true, true, EDGE, 1, 4, false, GPK_GEMM_PIPE, true>(p, ti, tj, m, 0, smem);
-        return;
-    }
-    if (!decode_tile(p, (int)blockIdx.x, ti, tj)) return;
-    gemm_tile<T, 128, true, true, EDGE, 1, 4, false, GPK_GEMM_PIPE, true>(p, ti, tj, blockIdx.y, blockIdx.z, smem);
-}
-
 // The panel solve of the blocked Cholesky,  P <- P inv(L_cc)^T  (both operands k-contiguous, one workgroup owns all 128 columns of its
 // rows: in place), with the zero half of the triangular operand skipped fragment by fragment (gemm_tile, TRIB).
 template <typename T, int TS, bool EDGE, int NCT>
@@ -463,11 +444,8 @@ template <typename T>
 int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                      const T* A, int64_t lda, int64_t sA, int64_t sA2, const T* B, int64_t ldb,
                      int64_t sB, int64_t sB2, T beta, T* C, int64_t ldc, int64_t sC, int64_t sC2,
-                     int64_t batch, int64_t batch2, int flags, hipStream_t stream, const T* colscale, T* colss, int64_t ldss, const GpkGen<T>* gen) {
+                     int64_t batch, int64_t batch2, int flags, hipStream_t stream, const T* colscale, T* colss, int64_t ldss) {
     const bool lower_only = (flags & 1) != 0;
-    if (gen != nullptr && (!a_kmaj || !b_kmaj || beta == T(0) || colscale != nullptr || colss != nullptr || (flags & ~1) != 0 || batch2 != 1 ||
-                           gen->x == nullptr || gen->d < 1 || gen->d > 8 || (const void*)A == (const void*)C || (const void*)B == (const void*)C))
-        return GPK_ERR_ARG(18);
     const bool fused_cols = colscale != nullptr || colss != nullptr;      // (gpk_gemm_colscale: the 128-tile kernels' epilogue)
     if (fused_cols && (batch != 1 || batch2 != 1 || lower_only || (const void*)A == (const void*)C || (const void*)B == (const void*)C))
         return GPK_ERR_ARG(17);
@@ -497,7 +475,6 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
         const int64_t tm = gpk_cdiv(M, 128), tn = gpk_cdiv(N, 128);
         const int64_t t128 = (lower_only && tm == tn ? tm * (tm + 1) / 2 : tm * tn) * batch * batch2;
         if (t128 < g_small_tile_below && !fused_cols) ts = 64;
-        if (gen != nullptr && ts != 128) return GPK_ERR_ARG(18);        // (gpk_gemm_gen_applicable says so beforehand)
         // In-place use (C aliases the A operand: the panel TRSM  P <- P inv(L_cc)^T  of the Cholesky):
         // every workgroup reads the full K range of its rows of A and then overwrites a column slice
         // of them, so ONE workgroup must own all N columns of a row tile -- with two column tiles a
@@ -539,11 +516,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     g.split_from = INT32_MAX;
     g.colscale = colscale; g.colss = colss; g.ldss = ldss;
     g.xcd_batch = 0; g.xcd_tiles = 0;
-    if (gen != nullptr) {
-        g.gen_x = gen->x; g.gen_ldx = gen->ldx; g.gen_sx = gen->sx; g.gen_d = gen->d;
-        g.gen_var = gen->var; g.gen_c = gen->c; g.gen_diag = gen->diag;
-    }
-    if (g_split_tail && gen == nullptr && !fused_cols && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && (flags & (2 | 4 | 8)) == 0 &&
+    if (g_split_tail && !fused_cols && ts == 128 && nct == 1 && batch == 1 && batch2 == 1 && (flags & (2 | 4 | 8)) == 0 &&
         (const void*)A != (const void*)C && (const void*)B != (const void*)C) {      // (in-place: one workgroup must own all columns of its rows)
         const int64_t slots = (int64_t)device_cus() * 2;
         const int64_t rem = total % slots;
@@ -589,16 +562,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
                                                            : (sizeof(T) == 8 ? 8 : 0) + (a_kmaj ? 4 : 0) + (b_kmaj ? 2 : 0) + (edge ? 1 : 0) + (ts == 64 ? 16 : 0);
         slot = g_prof.begin(code, fl, stream);
     }
-    if (gen != nullptr) {
-        if (edge) {
-            // (the fp64 kernel with bounds checks holds two k loops at 256 registers: the evaluation on top of them spills 500 bytes --
-            // ragged fp64 problems are not offered this path, gpk_kmat_potrf builds their kernel matrix the ordinary way)
-            if constexpr (sizeof(T) == 8) return GPK_ERR_ARG(18);
-            else hipLaunchKernelGGL((gemm_cgen_kernel<T, true>), grid, dim3(256), 0, stream, g);
-        } else {
-            hipLaunchKernelGGL((gemm_cgen_kernel<T, false>), grid, dim3(256), 0, stream, g);
-        }
-    } else if (trib && nct == 2) {
+    if (trib && nct == 2) {
         if (edge) hipLaunchKernelGGL((gemm_trib_kernel<T, 64, true, 2>), grid, dim3(256), 0, stream, g);
         else hipLaunchKernelGGL((gemm_trib_kernel<T, 64, false, 2>), grid, dim3(256), 0, stream, g);
     } else if (trib && ts == 128 && nct == 1) {
@@ -630,18 +594,13 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
     return GPK_OK;
 }
 
-bool gpk_gemm_gen_applicable(int64_t M, int64_t N, int64_t batch, bool lower) {
-    const int64_t tm = gpk_cdiv(M, 128), tn = gpk_cdiv(N, 128);
-    return (lower && tm == tn ? tm * (tm + 1) / 2 : tm * tn) * batch >= g_small_tile_below;
-}
-
 template <typename T>
 int gpk_gemm_launch(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, T alpha,
                     const T* A, int64_t lda, int64_t sA, const T* B, int64_t ldb, int64_t sB,
                     T beta, T* C, int64_t ldc, int64_t sC, int64_t batch, int flags,
                     hipStream_t stream) {
     return gpk_gemm_launch2<T>(a_kmaj, b_kmaj, M, N, K, alpha, A, lda, sA, 0, B, ldb, sB, 0, beta, C,
-                               ldc, sC, 0, batch, 1, flags, stream, nullptr, nullptr, 0, nullptr);
+                               ldc, sC, 0, batch, 1, flags, stream, nullptr, nullptr, 0);
 }
 
 // ---- the library's helper stream: confined (CU mask) to one CU per XCD, whose identities the persistent
@@ -1029,7 +988,7 @@ template int gpk_panel_step_launch<float>(float*, int64_t, int64_t, int64_t, con
 #define GPK_INST(T)                                                                                  \
     template int gpk_gemm_launch2<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,    \
                                      int64_t, int64_t, const T*, int64_t, int64_t, int64_t, T, T*,   \
-                                     int64_t, int64_t, int64_t, int64_t, int64_t, int, hipStream_t, const T*, T*, int64_t, const GpkGen<T>*); \
+                                     int64_t, int64_t, int64_t, int64_t, int64_t, int, hipStream_t, const T*, T*, int64_t); \
     template int gpk_gemm_launch<T>(bool, bool, int64_t, int64_t, int64_t, T, const T*, int64_t,     \
                                     int64_t, const T*, int64_t, int64_t, T, T*, int64_t, int64_t,    \
                                     int64_t, int, hipStream_t);                                      \

@@ -5,7 +5,6 @@
 // factorisation, whose worker workgroups run panel solves and rank-128 updates as tasks).
 #pragma once
 #include "gpk_common.hpp"
-#include "gpk_kmat_eval.hpp"
 #include <type_traits>
 
 // The k loop of the 128-tile: 0 = one chunk of global loads in flight, MFMA phase, write phase, barrier (rounds 1-3);
@@ -53,13 +52,6 @@ struct GemmArgs {
     int xcd_tiles;    //   tiles per matrix of such a launch
     unsigned long long colmask;   // persistent kernel, square lower-only segments: only the column groups named here (0: all) --
     int grp_tiles;                //   group g = tile columns [g grp_tiles, (g + 1) grp_tiles), rows from its first column's tile down
-    // CGEN kernels only (gemm_tile, CGEN): the C tile is not READ, it is EVALUATED -- C[m][n] = gen_var exp(-0.5 gen_c |x_m - x_n|^2)
-    // (+ gen_diag where m == n), x = gen_x + batch * gen_sx, point i at x + i * gen_ldx, gen_d <= 8 coordinates: the EQ kernel matrix
-    // as gpk_kmat builds it, entry for entry.  The first trailing update of a batched factorisation (gpk_kmat_potrf).
-    const T* gen_x;
-    int64_t gen_ldx, gen_sx;
-    int gen_d;
-    T gen_var, gen_c, gen_diag;
     int split_from;   // plain launches of 128-tiles: block indices from here on are QUARTER tiles (64 x 64) of the tiles split_from,
                       // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };
@@ -184,7 +176,7 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 // TRIB: the B operand (N x K) is LOWER TRIANGULAR and the tile starts at column 0 of it (the panel solve P inv(L_cc)^T of the
 // Cholesky): a 16-column fragment at columns j0.. only needs k < j0 + 16, the MFMAs beyond are skipped per fragment and per group of
 // k values -- 7/16 of the multiply-adds of a 128-column solve (the k loop itself still streams all of the operands).
-template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false, int PIPE = GPK_GEMM_PIPE, bool CGEN = false>
+template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false, int PIPE = GPK_GEMM_PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
                                           long long* prof = nullptr, const T* pf_c = nullptr, int64_t pf_ld = 0,
                                           unsigned* claim_ctr = nullptr, int* claimed = nullptr) {
@@ -241,52 +233,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     };
 
     acc_t acc[NCW][FRM][FR];
-    if constexpr (CGEN) {
-        // The tile's C values are evaluated from the inputs instead of loaded: the coordinates of the tile's TS row points and TS column
-        // points are staged in LDS (free until the k loop's first write), every lane evaluates its 64 entries with the arithmetic of
-        // kmat_band_kernel (direct differences summed over the coordinates in order, v0 * exp(-0.5 c r^2): the same bits).
-        static_assert(NCT == 1 && !HALFW && TS * 8 * 2 * (int)sizeof(T) <= 2 * (1 + NCT) * OPB, "coordinates of the tile's points fit the operand stages");
-        T* gx = reinterpret_cast<T*>(smem);                 // [2][TS][8]: rows, then columns
-        const T* __restrict__ X = p.gen_x + b * p.gen_sx;
-        for (int idx = tid; idx < 2 * TS * 8; idx += NT) {
-            const int which = idx / (TS * 8), r = (idx >> 3) % TS, j = idx & 7;
-            const int g = (which ? n0 : m0) + r;
-            gx[idx] = (j < p.gen_d && g < (which ? p.N : p.M)) ? X[(int64_t)g * p.gen_ldx + j] : T(0);
-        }
-        __syncthreads();
-        const T h = T(-0.5) * p.gen_c;
-        // (row by row, the schedule pinned: left to itself the compiler hoists all 160 coordinate reads to the top and spills 600+ registers)
-        T yc[FR][8];
 #pragma unroll
-        for (int fj = 0; fj < FR; ++fj)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) yc[fj][j] = gx[TS * 8 + (wn * WT + fj * 16 + lr) * 8 + j];
-#pragma unroll
-        for (int fi = 0; fi < FRM; ++fi)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rl = wm * WTM + fi * 16 + Traits<T>::crow(lane, i);
-                T xr[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xr[j] = gx[rl * 8 + j];
-#pragma unroll
-                for (int fj = 0; fj < FR; ++fj) {
-                    T r2 = T(0);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const T df = xr[j] - yc[fj][j];
-                        r2 += df * df;
-                    }
-                    T val = p.gen_var * gpk_exp_neg(h * r2);
-                    if (m0 + rl == n0 + wn * WT + fj * 16 + lr) val += p.gen_diag;
-                    acc[0][fi][fj][i] = val * p.beta_over_alpha;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        __syncthreads();            // (every wave has read the coordinates: the k loop's first chunk may overwrite them)
-    }
-#pragma unroll
-    for (int c = 0; c < (CGEN ? 0 : NCW); ++c) {
+    for (int c = 0; c < NCW; ++c) {
         if (p.has_beta) {
 #pragma unroll
             for (int fi = 0; fi < FRM; ++fi)

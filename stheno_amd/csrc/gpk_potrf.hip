@@ -962,7 +962,6 @@ GPK_KNOB(int, g_fused_step, 1);              // tuning knob (gpk_tune(32, v)): s
 
 GPK_KNOB(int, g_pipe, 1);                    // tuning knob (gpk_tune(37, v)): single matrices take potrf_panel_pipe (one launch per panel) where it applies
 int g_pipe_cus = 0;                // CUs of the current device (queried once)
-GPK_KNOB(int, g_kmat_in_update, 1);          // tuning knob (gpk_tune(53, v)): gpk_kmat_potrf evaluates the kernel matrix right of the first panel inside the first trailing update
 GPK_KNOB(int64_t, g_plain_nbo, 1024);        // tuning knob (gpk_tune(52, v)): panel width of the pipelined plain path for single matrices above 4096
 GPK_KNOB(int, g_pipe_fill, 1);               // tuning knob (gpk_tune(38, v)): the trailing update right of the NEXT panel rides along in that panel's launch
 GPK_KNOB(int, g_pipe_panel_wgs, 0);          // tuning knob (gpk_tune(39, v)): workgroups that take panel tasks first when a launch carries fill tiles (0: a third of the CUs)
@@ -1100,7 +1099,7 @@ void gpk_set_diag_prof(long long* dev_buf) { g_diag_prof = dev_buf; }
 
 template <typename T>
 static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
-                       int* info, int nbo, int info_base, hipStream_t stream, int64_t rows = 0, const GpkGen<T>* gen0 = nullptr) {
+                       int* info, int nbo, int info_base, hipStream_t stream, int64_t rows = 0) {
     if (n <= 0 || batch <= 0) return GPK_OK;
     if (rows < n) rows = n;
     if (rows > INT32_MAX) return GPK_ERR_ARG(2);
@@ -1153,12 +1152,8 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
                 owed = k1 - k0;
             } else {
                 const T* P = A + k1 * ld + k0;
-                // (gen0: the trailing matrix behind the FIRST panel has never been written -- this update evaluates it, gpk_kmat_potrf)
-                int st = (k0 == 0 && gen0 != nullptr)
-                             ? gpk_gemm_launch2<T>(true, true, rows - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, 0, P, ld, bstride, 0, T(1),
-                                                   A + k1 * ld + k1, ld, bstride, 0, batch, 1, 1, stream, nullptr, nullptr, 0, gen0)
-                             : gpk_gemm_launch<T>(true, true, rows - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, P, ld,
-                                                  bstride, T(1), A + k1 * ld + k1, ld, bstride, batch, true, stream);
+                int st = gpk_gemm_launch<T>(true, true, rows - k1, n - k1, k1 - k0, T(-1), P, ld, bstride, P, ld,
+                                            bstride, T(1), A + k1 * ld + k1, ld, bstride, batch, true, stream);
                 if (st) return st;
             }
         }
@@ -1284,7 +1279,6 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 47) GPK_KNOB_SET(g_la_agg = (int)value;);
     if (key == 48) GPK_KNOB_SET(g_la_agg_min_rows = value;);
     if (key == 52) GPK_KNOB_SET(g_plain_nbo = value;);
-    if (key == 53) GPK_KNOB_SET(g_kmat_in_update = (int)value;);
     if (key == 38) GPK_KNOB_SET(g_pipe_fill = (int)value;);
     if (key == 39) GPK_KNOB_SET(g_pipe_panel_wgs = (int)value;);
 }
@@ -1522,43 +1516,6 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
                      int* info, int nbo, hipStream_t stream) {
     return potrf_plain<T>(A, n, ld, batch, bstride, dinv, info, nbo, 0, stream);
 }
-
-// Kernel matrix + factorisation of a BATCH in one call: only the columns of the first panel are built as a kernel matrix; everything
-// right of them is evaluated inside the first trailing update (gemm_cgen_kernel) -- cfg4: 56 % of the lower triangles' 4.3 GB are
-// neither written by a kernel-matrix launch nor read back by the update.  One EQ term, d <= 8, scalar diagonal term; anything else
-// (and single matrices, whose updates ride in the pipelined panels) builds the whole matrix and factorises it as before.
-template <typename T>
-int gpk_kmat_potrf_launch(const int* kinds, const double* variances, const double* inv_ls, int nterms, const T* X, int64_t n, int64_t ldx,
-                          int64_t sX, int d, double diag_add, T* A, int64_t ld, int64_t sA, int64_t batch, T* dinv, int* info, int nbo,
-                          hipStream_t stream) {
-    if (n <= 0 || batch <= 0) return GPK_OK;
-    if (ld < n) return GPK_ERR_ARG(3);
-    int w = nbo;
-    if (w <= 0) w = (batch == 1 && dinv != nullptr) ? (n <= 4096 ? 4096 : (int)g_plain_nbo) : ((n >= 8192) ? 1024 : (n >= 2048 ? 512 : 256));     // (potrf_plain's rule)
-    constexpr int VEC = Traits<T>::VEC;
-    const bool whole = ((n - w) % 128 == 0) && (ld % VEC == 0) && ((uintptr_t)A % 16 == 0) && (sA % VEC == 0);
-    const bool fuse = g_kmat_in_update && nterms == 1 && kinds[0] == 0 /* EQ */ && d >= 1 && d <= 8 && batch > 1 && n > w && (w % 128 == 0) &&
-                      gpk_gemm_gen_applicable(n - w, n - w, batch, true) && (sizeof(T) == 4 || whole);
-    if (!fuse) {
-        const int st = gpk_kmat_launch<T>(kinds, variances, inv_ls, nterms, X, n, ldx, sX, X, n, ldx, sX, d, A, ld, sA, batch, 1, 1, diag_add,
-                                          (const T*)nullptr, 0, 0, stream);
-        if (st) return st;
-        return potrf_plain<T>(A, n, ld, batch, sA, dinv, info, nbo, 0, stream);
-    }
-    // the first panel's columns: the symmetric block on top (lower triangle, diagonal term added), the rectangle under it
-    int st = gpk_kmat_launch<T>(kinds, variances, inv_ls, nterms, X, w, ldx, sX, X, w, ldx, sX, d, A, ld, sA, batch, 1, 1, diag_add,
-                                (const T*)nullptr, 0, 0, stream);
-    if (st) return st;
-    st = gpk_kmat_launch<T>(kinds, variances, inv_ls, nterms, X + (int64_t)w * ldx, n - w, ldx, sX, X, w, ldx, sX, d, A + (int64_t)w * ld, ld, sA,
-                            batch, 0, 0, 0.0, (const T*)nullptr, 0, 0, stream);
-    if (st) return st;
-    const GpkGen<T> gen{X + (int64_t)w * ldx, ldx, sX, d, (T)variances[0], (T)(inv_ls[0] * inv_ls[0]), (T)diag_add};
-    return potrf_plain<T>(A, n, ld, batch, sA, dinv, info, w, 0, stream, 0, &gen);
-}
-template int gpk_kmat_potrf_launch<double>(const int*, const double*, const double*, int, const double*, int64_t, int64_t, int64_t, int, double,
-                                           double*, int64_t, int64_t, int64_t, double*, int*, int, hipStream_t);
-template int gpk_kmat_potrf_launch<float>(const int*, const double*, const double*, int, const float*, int64_t, int64_t, int64_t, int, double,
-                                          float*, int64_t, int64_t, int64_t, float*, int*, int, hipStream_t);
 
 template <typename T>
 int gpk_potrf_rows_launch(T* A, int64_t n, int64_t rows, int64_t ld, T* dinv, int* info, hipStream_t stream) {

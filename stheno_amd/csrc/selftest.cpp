@@ -633,57 +633,6 @@ static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail,
     report(nm, (st || !finite) ? INFINITY : znum / zden, DT<T>::eps * 2000);
 }
 
-// kernel matrix + factorisation of a batch in one call (gpk_kmat_potrf): the factors against gpk_kmat + gpk_potrf -- the same arithmetic
-// entry for entry, so the same bits are expected (reported against 10 eps)
-template <typename T>
-static void test_kmat_potrf_case(int n, int batch, int d, int ldpad, int kind = GPK_K_EQ) {
-    const int64_t ld = n + ldpad, sA = (int64_t)n * ld;
-    auto hx = randv<T>((size_t)batch * n * d);
-    Dev<T> X(hx.size()), A((size_t)batch * sA), Rf((size_t)batch * sA), dinv((size_t)batch * gpk_dinv_elems(n)), dinv2((size_t)batch * gpk_dinv_elems(n));
-    Dev<int> info(batch), info2(batch);
-    X.up(hx); info.zero(); info2.zero();
-    A.up(std::vector<T>((size_t)batch * sA, (T)3)); Rf.up(std::vector<T>((size_t)batch * sA, (T)3));
-    double var = 1.3, il = 0.9;
-    const int st = gpk_kmat_potrf(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, d, 0.1, A.p, ld, sA, batch, dinv.p, info.p, 0, nullptr);
-    const int s1 = gpk_kmat(DT<T>::v, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, X.p, n, d, (int64_t)n * d, d, Rf.p, ld, sA, batch, 1, 1, 0.1, nullptr, 0, 0, nullptr);
-    const int s2 = gpk_potrf(DT<T>::v, Rf.p, n, ld, sA, batch, dinv2.p, info2.p, 0, nullptr);
-    HIPCHK(hipDeviceSynchronize());
-    auto G = A.down(), R = Rf.down();
-    double num = 0, den = 0;
-    bool finite = true;
-    for (int b = 0; b < batch; ++b)
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j <= i; ++j) {
-                const double g = G[(size_t)b * sA + (size_t)i * ld + j], r = R[(size_t)b * sA + (size_t)i * ld + j];
-                if (!std::isfinite(g)) finite = false;
-                num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
-            }
-    int bad = 0;
-    for (int v : info.down()) bad += v != 0;
-    auto d1 = dinv.down(), d2 = dinv2.down();
-    double dd = 0;
-    for (size_t i = 0; i < d1.size(); ++i) dd = std::max(dd, std::fabs((double)d1[i] - (double)d2[i]));
-    char nm[200];
-    snprintf(nm, sizeof nm, "kmat_potrf_%s n%d batch%d d%d ldpad%d kind%d st%d/%d/%d info%d: factor vs kmat + potrf", DT<T>::name(), n, batch, d, ldpad, kind, st, s1, s2, bad);
-    report(nm, (st || s1 || s2 || !finite || bad) ? INFINITY : num / den, DT<T>::eps * 10);
-    snprintf(nm, sizeof nm, "kmat_potrf_%s n%d batch%d: block inverses", DT<T>::name(), n, batch);
-    report(nm, dd, DT<T>::eps * 1000);
-}
-
-template <typename T>
-static void test_kmat_potrf() {
-    gpk_tune(1, 0);                                 // the 128-tile kernels whatever the batch (the fused update needs them)
-    test_kmat_potrf_case<T>(1024, 3, 3, 0);         // nbo 256: first trailing update 768^2 per matrix
-    test_kmat_potrf_case<T>(2048, 4, 8, 0);         // nbo 512
-    test_kmat_potrf_case<T>(640, 5, 1, 0);
-    if (sizeof(T) == 4) test_kmat_potrf_case<T>(1000, 3, 2, 8);      // ragged (fp32 only: bounds-checked kernel)
-    test_kmat_potrf_case<T>(1000, 3, 2, 8);         // fp64 ragged: falls back to kmat + potrf inside the call
-    test_kmat_potrf_case<T>(1024, 2, 3, 0, GPK_K_MATERN52);   // another kernel: falls back
-    test_kmat_potrf_case<T>(200, 6, 3, 0);          // one panel: nothing to fuse
-    gpk_tune(1, 512);
-    test_kmat_potrf_case<T>(512, 64, 3, 0);         // the library's own tile choice (enough 128-tiles)
-}
-
 template <typename T>
 static void test_potrf_rows() {
     test_potrf_rows_case<T>(128, 64, 0, 0, 0);             // one diagonal block + rows
@@ -1932,16 +1881,6 @@ int main(int argc, char** argv) {
                 const float ms = tm.stop();
                 if (rep) printf("BATCHED potrf_f32 512x2048 nbo=%d  %.3f ms  %.2f TFLOP/s\n", nbo, ms, batch * (double)n * n * n / 3.0 / ms * 1e-9);
             }
-            for (int fused = 0; fused < 2; ++fused)
-                for (int rep = 0; rep < 3; ++rep) {
-                    info.zero();
-                    gpk_tune(53, fused);
-                    tm.start();
-                    gpk_kmat_potrf(GPK_F32, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, d, 0.1, K.p, n, (int64_t)n * n, batch, dinv.p, info.p, nbo, nullptr);
-                    const float ms = tm.stop();
-                    if (rep) printf("BATCHED kmat+potrf_f32 512x2048 nbo=%d %s  %.3f ms\n", nbo, fused ? "kernel matrix evaluated in the first update" : "kmat launch + potrf                        ", ms);
-                }
-            gpk_tune(53, 1);
             // the forward solve of one right-hand side per matrix (the quadratic form of the log-density)
             auto hy = randv<float>((size_t)batch * n);
             Dev<float> Y(hy.size());
@@ -2014,7 +1953,6 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--rows")) {                      // only the factorisations with rows under the matrix
             test_potrf_rows<double>(); test_potrf_rows<float>();
-            test_kmat_potrf<double>(); test_kmat_potrf<float>();
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
             return g_fail ? 1 : 0;
         }
@@ -2072,7 +2010,6 @@ int main(int argc, char** argv) {
         test_potrf<double>(); test_potrf<float>();
         test_lookahead<double>(); test_lookahead<float>();
         test_potrf_rows<double>(); test_potrf_rows<float>();
-        test_kmat_potrf<double>(); test_kmat_potrf<float>();
         test_misc<double>(); test_misc<float>();
         test_vjp_dense<double>(); test_vjp_dense<float>();
         printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);

@@ -463,8 +463,6 @@ class Zero(AbstractMatrix):
 class Diagonal(AbstractMatrix):
     """Diagonal matrix given by its diagonal (..., n)."""
 
-    constant = None       # the value of every diagonal entry as a Python number, when whoever built the matrix knew it (else None)
-
     def __init__(self, diag):
         self._diag = diag
 
@@ -643,40 +641,10 @@ class KernelDense(Dense):
         if self._chol is None:
             if self._mat is not None:
                 return super().chol()
-            c = self._chol_batched_fused()
-            if c is None:
-                a = self._build(lower=True, jitter=config.epsilon)
-                c = Chol.factor_(a)
-            self._chol = c
+            a = self._build(lower=True, jitter=config.epsilon)
+            self._chol = Chol.factor_(a)
             return self._chol
         return self._chol.vetted()
-
-    def _chol_batched_fused(self):
-        """A BATCH of kernel matrices of one EQ term with a constant diagonal term, factorised by ``gpk_kmat_potrf``: only the first
-        panel's columns are ever built as a kernel matrix, the rest is evaluated inside the first trailing update.  ``None``: does not apply."""
-        be = ops.get_backend()
-        x, noise = self.x, self.noise
-        if not hasattr(be, "kmat_potrf_") or not torch.is_tensor(x) or x.dim() != 3 or x.shape[0] < 2 or x.shape[-1] > 8 or x.requires_grad:
-            return None
-        if self.kernel.num_outputs(x) != x.shape[-2]:
-            return None
-        terms = self.kernel.terms()
-        if terms is None or len(terms) != 1 or terms[0][0] != "eq":
-            return None
-        if noise is None or isinstance(noise, Zero):
-            diag = 0.0
-        elif isinstance(noise, Diagonal) and noise.constant is not None:
-            diag = float(noise.constant)
-        else:
-            return None
-        a, dinv, info = be.kmat_potrf_(ops.KTerms(terms), x, diag + config.epsilon, config.potrf_nbo)
-        c = Chol(a, dinv, info)
-        if config.check_info:
-            if _deferred_state.pending is not None:
-                _deferred_state.pending.append(c)
-            else:
-                c.check()
-        return c
 
     def can_factor_with_rows(self, ns):
         """Whether :meth:`chol_with_rows` applies: nothing factorised or materialised yet, ONE matrix of an order the native path

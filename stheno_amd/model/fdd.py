@@ -15,17 +15,13 @@ def _noise_as_matrix(noise, x, n):
         return Zero(x.dtype, n, n, device=x.device, batch=tuple(x.shape[:-2]))
     if isinstance(noise, AbstractMatrix):
         return noise
-    known = None          # the noise as a Python number, when the caller gave one (no device read needed to learn it)
     if isinstance(noise, (int, float)) and not isinstance(noise, bool):
-        known = float(noise)
         noise = torch.full((), float(noise), dtype=x.dtype, device=x.device)      # (a fill on the device: no host-to-device copy to wait for)
     if not torch.is_tensor(noise):
         noise = torch.as_tensor(noise, dtype=x.dtype, device=x.device)
     noise = noise.to(dtype=x.dtype, device=x.device)
     if noise.dim() == 0:
-        d = Diagonal(noise.expand(tuple(x.shape[:-2]) + (n,)).contiguous())
-        d.constant = known        # (`KernelDense.chol` hands a constant diagonal to the fused kernel-matrix + factorisation call as a scalar)
-        return d
+        return Diagonal(noise.expand(tuple(x.shape[:-2]) + (n,)).contiguous())
     if noise.dim() == 1 or (x.dim() > 2 and noise.dim() == x.dim() - 1):
         return Diagonal(noise)
     return Dense(noise)

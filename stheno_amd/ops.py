@@ -250,24 +250,6 @@ class HipBackend:
         return dinv, info
 
     @_on_operand_device
-    def kmat_potrf_(self, terms, x, diag_add, nbo=0):
-        """Lower Cholesky factors of the batch ``k(x[b], x[b]) + diag_add I`` (x: (B, n, d)) without the kernel matrices ever being
-        resident in full (``gpk_kmat_potrf``).  Returns ``(l, dinv, info)``; the strict upper triangles of ``l`` are unspecified."""
-        x3, bshape = _as3(x)
-        self._check(x3)
-        B, n, d = x3.shape
-        a = _alloc(bshape, n, n, x.dtype, x.device)
-        a3, _ = _as3_out(a)
-        nblk = (max(n, 1) + 127) // 128
-        dinv = torch.empty((B, nblk, 128, 128), dtype=x.dtype, device=x.device)
-        info = torch.zeros((B,), dtype=torch.int32, device=x.device)
-        kinds, var, ils, nt = terms.c_arrays()
-        code = self.lib.gpk_kmat_potrf(_dtype_id(x3), kinds, var, ils, nt, self._ptr(x3), n, _ld(x3), _bs(x3), d, float(diag_add),
-                                       self._ptr(a3), _ld(a3), _bs(a3), B, self._ptr(dinv), self._ptr(info), int(nbo), self._stream())
-        self._st(code, "gpk_kmat_potrf")
-        return a, dinv, info
-
-    @_on_operand_device
     def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0):
         """In-place lower Cholesky of the leading ``n x n`` of ``a`` (rows, n), rows > n, carrying the rows under it through the
         factorisation (``gpk_potrf_rows``): they come out as ``a[n:] L^{-T}``.  ``n`` a multiple of 128.  Returns ``(dinv, info, dinv_sb or None)``."""

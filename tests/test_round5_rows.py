@@ -138,28 +138,3 @@ def test_config2_full_size_golden_posterior_first():
         assert abs(got.sum() - ref["sum"]) <= 1e-6 * ref["sum_abs"]
         assert np.max(np.abs(got[::64] - np.array(ref["every_64th"]))) <= 1e-6 * ref["max_abs"]
         assert abs(np.abs(got).max() - ref["max_abs"]) <= 1e-6 * ref["max_abs"]
-
-
-def test_batched_kernel_matrix_evaluated_inside_the_first_update():
-    """``gpk_kmat_potrf`` (cfg4's path): a batch of EQ kernel matrices with scalar noise is factorised without the part right of the first
-    panel ever being written as a kernel matrix; log-densities against the oracle (fp32 1e-3, fp64 1e-6) and against the same batch
-    with a per-point noise VECTOR of the same value, which takes the ordinary kernel-matrix launch."""
-    rng = np.random.default_rng(11)
-    for dtype, tol, eps in ((np.float32, 1e-3, 1e-6), (np.float64, 1e-6, 1e-12)):
-        b, n, d = 6, 1024, 3
-        x = rng.standard_normal((b, n, d)).astype(dtype)
-        y = rng.standard_normal((b, n, 1)).astype(dtype)
-        eps0 = B.epsilon
-        try:
-            B.epsilon = eps
-            tx, ty = torch.as_tensor(x, device=DEV), torch.as_tensor(y, device=DEV)
-            f = st.GP(st.EQ())
-            fdd = f(tx, NOISE)
-            lp = fdd.logpdf(ty).cpu().numpy()
-            assert type(fdd.var.noise).__name__ == "Diagonal" and fdd.var.noise.constant == NOISE
-            ref = O.gp_logpdf_batched([("eq", 1.0, 1.0)], x.astype(np.float64), NOISE, y.astype(np.float64), eps=eps)
-            assert lp.shape == (b,) and np.max(np.abs(lp - ref) / np.abs(ref)) <= tol, (dtype, lp, ref)
-            lp_vec = f(tx, torch.full((b, n), NOISE, dtype=tx.dtype, device=DEV)).logpdf(ty).cpu().numpy()
-            assert np.max(np.abs(lp - lp_vec) / np.abs(lp_vec)) <= (1e-6 if dtype == np.float32 else 1e-12)
-        finally:
-            B.epsilon = eps0
