@@ -5,9 +5,11 @@ Cholesky trailing-update GEMM priced against the fp64 MFMA peak.
 
 One STEP = one eval of ``configs[1]``:  from ``x`` (N x D, resident in HBM) build
 ``K + sigma^2 I`` (lower triangle, jitter fused), Cholesky-factorise it in place,
-``f(x, noise).logpdf(y)``, condition ``f | (f(x, noise), y)`` (re-using the factor), and
-the posterior mean + marginal variance at N* = 2048 test points -- through the public
-``stheno_amd`` API, i.e. through libgpk.so.  Nothing is carried from one step to the next: the
+condition ``f | (f(x, noise), y)``, the posterior mean + marginal variance at N* = 2048 test points, and
+``f(x, noise).logpdf(y)`` (re-using the factor) -- through the public ``stheno_amd`` API, i.e. through libgpk.so.
+Call order (``--order``): the posterior first (default) -- nothing has factorised K when it is asked for, so K(x*, x) rides through the
+factorisation as rows under the matrix (``gpk_potrf_rows``) and there is no separate 2048-column solve -- or the log-density first (the
+factor exists when the posterior is asked for: the blocked solve of rounds 1-4).  Same quantities, same flops, one factorisation either way.  Nothing is carried from one step to the next: the
 kernel matrix, the factor and the solves are rebuilt, and the one thing the library remembers about
 a data tensor between calls -- the NaN scan of ``y`` (``matrix.any_missing``) -- is forgotten at the
 start of every step, so each step pays for its scan like a first call.
