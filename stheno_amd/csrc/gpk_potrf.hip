@@ -183,16 +183,29 @@ __device__ __forceinline__ int panel_waves(int s) { return s == 0 ? 3 : (s <= 3 
 // s + 3 pw + g (idle past tile 7).  Wave 0 writes the diagonal tile, the reciprocal pivots and reports a non-positive pivot.
 // (Writing the finished columns to global memory from here, out of the registers they sit in, was measured: +1.3k cycles per
 // micro-step on the critical wave.  A wave with nothing else to do stores them one step later: store_l_columns.)
+// Round 5: the rows are READ (panel_load) in front of a workgroup barrier and factorised (panel_chol) behind it.  Every panel wave repeats
+// the diagonal tile's arithmetic on its lanes 0..15 and so reads the diagonal tile's rows -- which wave 0 OVERWRITES with the factor
+// when it is done.  With the loads inside this function the compiler sank those of the later columns towards their first use, several
+// pivots into the loop; a panel wave that fell behind wave 0 by more than that (its SIMD shared with another kernel's waves: 8 concurrent
+// streams of batched factorisations, one block in ~1e5) then read factorised values for columns 8..15 and produced a wrong factor from
+// local row 80, column 24 on (scripts/dev_stream_race.py).  Nothing in a single stream ever separated the waves that far.
 template <typename T>
-__device__ __forceinline__ void panel_chol(T* __restrict__ S, T* __restrict__ rdiag, int s, int pw, int lane, int* info, int off) {
+__device__ __forceinline__ void panel_load(const T* __restrict__ S, int s, int pw, int lane, T (&a)[16]) {
+    const int lr = lane & 15, g = lane >> 4;
+    const int c0 = 16 * s;
+    const int tile = (g == 0) ? s : s + 3 * pw + g;
+    const int row = 16 * (tile < 8 ? tile : s) + lr;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = S[row * LDP + c0 + c];
+}
+
+template <typename T>
+__device__ __forceinline__ void panel_chol(T* __restrict__ S, T* __restrict__ rdiag, int s, int pw, int lane, int* info, int off, T (&a)[16]) {
     const int lr = lane & 15, g = lane >> 4;
     const int c0 = 16 * s;
     const int tile = (g == 0) ? s : s + 3 * pw + g;
     const bool live = tile < 8;
     const int row = 16 * (live ? tile : s) + lr;
-    T a[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = S[row * LDP + c0 + c];
     int bad = 0;
     T myr = T(0);
 #pragma unroll
@@ -526,7 +539,10 @@ __device__ __forceinline__ void diag3_block(T* __restrict__ S, T* __restrict__ r
     //      block in the shadow of the panel factorisations ----
     {
         const int np = panel_waves(0);
-        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane_fixed, info, info_off);
+        T pa[16];
+        if (wave < np) panel_load<T>(S, 0, wave, lane_fixed, pa);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every panel wave holds its rows: wave 0 may overwrite the diagonal tile (see panel_load)
+        if (wave < np) panel_chol<T>(S, rdiag, 0, wave, lane_fixed, info, info_off, pa);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (LDS only, here and below: global stores are in flight and nobody waits for them)
     if (prof) prof[2] = (long long)__builtin_readcyclecounter();
@@ -543,8 +559,11 @@ __device__ __forceinline__ void diag3_block(T* __restrict__ S, T* __restrict__ r
         if (prof) prof[21 + s] = (long long)__builtin_readcyclecounter();
         // panel s+1 on its waves  ||  (U2) column s applied to the remaining tiles on the others, then their share of the inverse
         const int np = panel_waves(s + 1);
+        T pa[16];
+        if (wave < np) panel_load<T>(S, s + 1, wave, lane, pa);
+        if (np > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (see panel_load; one panel wave: nobody else reads the diagonal tile's rows)
         if (wave < np) {
-            panel_chol<T>(S, rdiag, s + 1, wave, lane, info, info_off);
+            panel_chol<T>(S, rdiag, s + 1, wave, lane, info, info_off, pa);
         } else {
             rank16_update<T>(S, c0, 1, s, (6 - s) * (7 - s) / 2, wave - np, D3_WAVES - np, lane, lr, kq);
             // Steps 0 and 1 are bound by their 21 / 15 trailing tiles, not by the panel: the inverse starts in step 2 (diagonal tiles
