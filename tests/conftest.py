@@ -80,6 +80,28 @@ class OracleBackend:
         a.copy_(self._t(flat.reshape(arr.shape), a))
         return None, info
 
+    def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0):
+        """Stand-in for ``HipBackend.potrf_rows_`` (``gpk_potrf_rows``): the leading n x n of ``a`` (rows, n) is factorised in place,
+        the rows under it become ``a[n:] L^{-T}`` -- so that the host logic of the posterior-first path runs on the GPU-less box."""
+        arr = _np(a).copy()
+        rows, n = arr.shape
+        info = torch.zeros((1,), dtype=torch.int32)
+        sym = np.tril(arr[:n]) + np.tril(arr[:n], -1).T
+        try:
+            L = np.linalg.cholesky(sym)
+            arr[:n] = L
+            arr[n:] = O.solve_lower(L, arr[n:].T).T
+        except np.linalg.LinAlgError:
+            info[0] = 1
+            arr[:] = np.nan
+        a.copy_(self._t(arr, a))
+        return None, info, None
+
+    def rowreduce(self, z, w=None, *, want_dot=True, want_ss=False):
+        dot = (z * w.reshape(1, -1)).sum(-1) if (want_dot and w is not None) else None
+        ss = (z * z).sum(-1) if want_ss else None
+        return dot, ss
+
     def trtri_merge(self, l, dinv, sb):
         return None
 

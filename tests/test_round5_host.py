@@ -1,0 +1,92 @@
+"""Round 5, host logic on the GPU-less box: the posterior evaluated BEFORE anything factorised the observations' kernel matrix takes the
+factorisation with rows under the matrix (``KernelDense.chol_with_rows`` -> ``_whiten`` -> ``WhitenedT`` -> row reductions / the
+k-contiguous product), here over the test-only oracle backend's stand-in for ``gpk_potrf_rows``.  Against the oracle's direct formulas
+(``stheno/model/observations.py:148-168``) and against the log-density-first order; the MI355X versions are in ``test_round5_rows.py``."""
+import numpy as np
+import pytest
+import torch
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+from stheno_amd import B, matrix, ops
+
+from .conftest import OracleBackend
+
+
+@pytest.fixture()
+def oracle_backend():
+    prev = ops.set_backend(OracleBackend())
+    old = (matrix.config.posterior_rows_from, matrix.config.posterior_rows_min_points)
+    matrix.config.posterior_rows_from, matrix.config.posterior_rows_min_points = 128, 8
+    yield
+    matrix.config.posterior_rows_from, matrix.config.posterior_rows_min_points = old
+    ops.set_backend(prev)
+
+
+def _rel(a, ref):
+    a, ref = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(ref, dtype=np.float64).reshape(-1)
+    return float(np.max(np.abs(a - ref)) / np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("kind", ["eq", "eq+linear", "scaled"])
+def test_posterior_first_takes_the_rows_path_and_matches_the_oracle(oracle_backend, kind):
+    rng = np.random.default_rng(1)
+    n, ns, d = 256, 24, 2
+    x, xs = rng.standard_normal((n, d)), rng.standard_normal((ns, d))
+    y = np.sin(x.sum(-1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
+    kernel = {"eq": st.EQ(), "eq+linear": st.EQ() + st.Linear(), "scaled": 2.0 * st.EQ().stretch(0.7)}[kind]
+    terms = {"eq": [("eq", 1.0, 1.0)], "eq+linear": [("eq", 1.0, 1.0), ("linear", 1.0, 1.0)], "scaled": [("eq", 2.0, 0.7)]}[kind]
+    tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
+    f = st.GP(kernel)
+    fdd = f(tx, 0.1)
+    post = f | (fdd, ty)
+    mean, var = post(txs).marginals()
+    chol = fdd.var.chol()
+    assert chol.rows_under == ns
+    lp = float(fdd.logpdf(ty))
+    assert fdd.var.chol() is chol
+    ref_mean, ref_cov, ref_var = O.gp_posterior(terms, x, 0.1, y, xs, full_cov=True)
+    assert abs(lp - O.gp_logpdf(terms, x, 0.1, y)) <= 1e-9 * abs(lp)
+    assert _rel(mean.numpy(), ref_mean) <= 1e-9 and _rel(var.numpy(), ref_var) <= 1e-9
+    # the full covariance through Z Z^T, and a covariance between two different input sets (one whitened transposed, one not)
+    f2 = st.GP(kernel)
+    fdd2 = f2(tx, 0.1)
+    post2 = f2 | (fdd2, ty)
+    assert _rel(B.dense(post2(txs).var).numpy(), ref_cov) <= 1e-9
+    assert fdd2.var.chol().rows_under == ns
+    kxy = post2.kernel.pairwise(txs, txs[:7])
+    assert _rel(kxy.numpy(), ref_cov[:, :7]) <= 1e-9
+    # the other order: the factor exists before the posterior is asked for
+    f3 = st.GP(kernel)
+    fdd3 = f3(tx, 0.1)
+    fdd3.logpdf(ty)
+    mean3, var3 = (f3 | (fdd3, ty))(txs).marginals()
+    assert fdd3.var.chol().rows_under == 0
+    assert _rel(mean.numpy(), mean3.numpy()) <= 1e-10 and _rel(var.numpy(), var3.numpy()) <= 1e-10
+
+
+def test_shapes_outside_the_rows_path_fall_back(oracle_backend):
+    rng = np.random.default_rng(2)
+    for n, ns, noise in ((200, 24, 0.1), (256, 4, 0.1), (256, 24, None)):       # not a multiple of 128; too few points; fine (no noise: jitter only)
+        x, xs = rng.standard_normal((n, 1)), rng.standard_normal((ns, 1))
+        y = rng.standard_normal((n, 1))
+        tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
+        f = st.GP(st.EQ())
+        eps0 = B.epsilon
+        try:
+            B.epsilon = 1e-8
+            fdd = f(tx) if noise is None else f(tx, noise)
+            mean, var = (f | (fdd, ty))(txs).marginals()
+            ref_mean, _, ref_var = O.gp_posterior([("eq", 1.0, 1.0)], x, 0.0 if noise is None else noise, y, xs, eps=1e-8, full_cov=False)
+        finally:
+            B.epsilon = eps0
+        assert (fdd.var.chol().rows_under == ns) == (n % 128 == 0 and ns >= 8)
+        assert _rel(mean.numpy(), ref_mean) <= 1e-6 and np.max(np.abs(var.numpy().reshape(-1) - ref_var.reshape(-1))) <= 1e-6
+
+
+def test_not_positive_definite_raises_from_the_rows_path(oracle_backend):
+    rng = np.random.default_rng(3)
+    x, xs, y = rng.standard_normal((128, 1)), rng.standard_normal((16, 1)), rng.standard_normal((128, 1))
+    f = st.GP(st.EQ())
+    with pytest.raises(torch.linalg.LinAlgError):
+        (f | (f(torch.as_tensor(x), -5.0), torch.as_tensor(y)))(torch.as_tensor(xs)).marginals()
