@@ -159,7 +159,9 @@ def pmc_traffic(name, w, kernel):
     path = os.path.join(ROOT, "profiles", "r05_pmc_%s.json" % name)
     if os.path.exists(path):
         with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel)
+            ks = json.load(f)["kernels"]
+        # (the profiler prints every template argument: the plain kernels carry their k-loop variant, `..., 2>`, behind what the hooks name)
+        k = ks.get(kernel) or ks.get(kernel[:-1] + ", 2>")
         if k is not None:
             return k["hbm_bytes_per_launch"], "profiles/r05_pmc_%s.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)" % name
     return None, None
