@@ -646,6 +646,13 @@ static void test_potrf_rows() {
     test_potrf_rows_case<T>(4096, 130, 256, 0, 512, 3);
     test_potrf_rows_case<T>(3840, 1000, 256, 0, 100, 2);   // tail shorter than a block: raised to one block
     test_potrf_rows_case<T>(2048, 77, 256, 0, 0);          // n <= the default tail: all plain
+    // orders that are whole 128-blocks but not whole panels: a last panel of one block, 17 / 33 blocks, the look-ahead's last outer
+    // block 128 wide with a plain tail whose last panel is one block
+    test_potrf_rows_case<T>(2176, 130, 0, 0, 0);
+    test_potrf_rows_case<T>(4224, 64, 0, 0, 0);
+    test_potrf_rows_case<T>(5248, 200, 0, 0, 0);
+    test_potrf_rows_case<T>(4224, 96, 1024, 0, 2048);
+    test_potrf_rows_case<T>(7296, 64, 1024, 512, 3072);
 }
 
 template <typename T>
