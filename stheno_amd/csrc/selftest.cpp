@@ -628,9 +628,9 @@ static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail,
     }
     char nm[200];
     snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d st%d/%d info%d: factor", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg, st, st2, info.down()[0]);
-    report(nm, (st || st2 || !finite || info.down()[0]) ? INFINITY : num / den, DT<T>::eps * 100);
+    report(nm, (st || st2 || !finite || info.down()[0]) ? INFINITY : num / den, DT<T>::eps);
     snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d: rows = E L^-T", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg);
-    report(nm, (st || !finite) ? INFINITY : znum / zden, DT<T>::eps * 2000);
+    report(nm, (st || !finite) ? INFINITY : znum / zden, DT<T>::eps * 2);
 }
 
 template <typename T>
