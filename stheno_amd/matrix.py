@@ -52,6 +52,9 @@ class _Config:
     #: and the separate many-column triangular solve disappears.  0 disables it.
     posterior_rows_from = 2048
     posterior_rows_min_points = 64
+    #: Pseudo-point bounds (VFE / DTC) with many more observations than inducing points: build the cross-covariance transposed and padded
+    #: to whole 128-tiles (``observations.py``), so that the M x N product runs in the GEMM kernel without bounds checks on two k-contiguous operands.
+    pseudo_padded_transposed = True
 
 
 config = _Config()

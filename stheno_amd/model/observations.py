@@ -65,12 +65,13 @@ def _syrk_splits(m, n):
 def _syrk_lower(be, v, out):
     """``out = v v^T`` (lower triangle) for ``v`` (..., M, N) on the MFMA GEMM."""
     m, n_obs = v.shape[-2], v.shape[-1]
-    splits = _syrk_splits(m, n_obs) if (v.dim() == 2 and v.is_contiguous()) else 1
+    splits = _syrk_splits(m, n_obs) if (v.dim() == 2 and v.stride(-1) == 1) else 1
     if splits > 1:
         # M x M output = few tiles, N huge: split the contraction over the observations into
         # `splits` batch entries (strided views of V, no copy) so the MFMA grid fills the GPU,
         # then add the partial products (deterministic, unlike atomics).
-        vs = v.view(m, splits, n_obs // splits).permute(1, 0, 2)          # (S, M, N/S), strides (N/S, N, 1)
+        # (S, M, N/S) with strides (N/S, ld, 1); ld > N when v is the leading columns of a padded buffer
+        vs = v.as_strided((splits, m, n_obs // splits), (n_obs // splits, v.stride(0), 1), v.storage_offset())
         parts = torch.zeros((splits, m, m), dtype=v.dtype, device=v.device)
         be.gemm(vs, vs, a_kmajor=True, b_kmajor=True, out=parts, lower_only=True)
         out.copy_(parts.sum(0))
@@ -316,9 +317,22 @@ class AbstractPseudoObservations(AbstractObservations):
         # VERDICT r4 #7 -- and measured it on cfg5: the V GEMM 0.771 of the fp32 peak against 0.80 this way round, the step 57.7 ms
         # against 55.4: N = 200000 is no multiple of the tile, and the bounds-checked kernel's k-contiguous B image pays for its clamped
         # rows.  Not kept; `Chol.solve_scaled(..., b_kmajor=True)` stays for callers that hold the transposed matrix anyway.)
-        K_zx = measure.kernels[p_z, p_x].pairwise(z, x)                       # :285
+        k_zx = measure.kernels[p_z, p_x]
         K_z = _kernel_matrix(measure.kernels[p_z], z, noise_z)                # :286
         self._K_z[measure] = K_z
+        # Round 5 (second attempt at VERDICT r4 #7): the cross-covariance TRANSPOSED and PADDED -- k(x_pad, z), N_pad = N rounded up to
+        # whole 128-tiles, the padding points' columns of V switched off by a zero column scale -- so that V = L_z^{-1} K_zx multiplies two
+        # k-contiguous operands in the kernel WITHOUT bounds checks (transposed alone lost: the bounds-checked kernel's clamped rows).
+        n_obs = x.shape[-2]
+        n_pad = (n_obs + 127) // 128 * 128
+        padded = (config.pseudo_padded_transposed and self.method != "fitc" and x.dim() == 2 and z.dim() == 2 and n_obs >= 8 * z.shape[-2]
+                  and z.shape[-2] % 128 == 0 and k_zx.terms() is not None and not x.requires_grad and not z.requires_grad
+                  and K_z.chol().solves_by_full_inverse(n_pad))
+        if padded:
+            x_pad = x if n_pad == n_obs else torch.cat([x, x[: n_pad - n_obs]], dim=0)       # (any finite points: their columns are scaled to zero)
+            K_zx = k_zx.pairwise(x_pad, z)                                    # :285, transposed: (N_pad, M)
+        else:
+            K_zx = k_zx.pairwise(z, x)                                        # :285
 
         if not isinstance(noise_x, Diagonal):                                 # :293-297
             raise RuntimeError(
@@ -332,7 +346,15 @@ class AbstractPseudoObservations(AbstractObservations):
         # forms V = L_z^{-1} K_zx (`Chol.solve_scaled`, gpk_gemm_colscale) -- no scaling pass, no reduction pass over the M x N matrix.
         # (FITC's K_n depends on Q_x_diag: the separate passes below.)
         fused = None
-        if self.method != "fitc" and K_zx.dim() == 2:
+        if padded:
+            s = torch.rsqrt(K_n)
+            s_pad = s if n_pad == n_obs else torch.cat([s, s.new_zeros(n_pad - n_obs)])
+            fused = K_z.chol().solve_scaled(K_zx, s_pad, want_colss=self.method == "vfe", b_kmajor=True)
+            if fused is None:           # (cannot happen: `padded` asked the factor first)
+                raise RuntimeError("the padded pseudo-point product was refused")
+            v, q_x_diag = fused[0][:, :n_obs], (fused[1][:n_obs] if fused[1] is not None else None)     # views: the padding columns are zero and stay behind
+            fused = (v, q_x_diag)
+        elif self.method != "fitc" and K_zx.dim() == 2:
             s = torch.rsqrt(K_n)
             fused = K_z.chol().solve_scaled(K_zx, s, want_colss=self.method == "vfe")
         if fused is not None:

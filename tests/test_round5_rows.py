@@ -138,3 +138,34 @@ def test_config2_full_size_golden_posterior_first():
         assert abs(got.sum() - ref["sum"]) <= 1e-6 * ref["sum_abs"]
         assert np.max(np.abs(got[::64] - np.array(ref["every_64th"]))) <= 1e-6 * ref["max_abs"]
         assert abs(np.abs(got).max() - ref["max_abs"]) <= 1e-6 * ref["max_abs"]
+
+
+@pytest.mark.parametrize("method", ["vfe", "dtc"])
+def test_pseudo_point_bound_with_the_padded_transposed_cross_covariance(method):
+    """cfg5's shape class (many more observations than inducing points, M a multiple of 128): ``k(x_pad, z)`` transposed and padded to
+    whole tiles, the padding columns switched off by a zero column scale (``observations.py:_compute``) -- the bound and ``mu`` against
+    the oracle, and against the same call with the ordinary cross-covariance."""
+    rng = np.random.default_rng(21)
+    n, m, d = 3000, 256, 3            # 3000 is not a multiple of 128: 72 padding columns
+    x, z = rng.standard_normal((n, d)), rng.standard_normal((m, d))
+    y = np.sin(x.sum(-1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
+    ref = O.pseudo_obs([("eq", 1.0, 1.0)], x, NOISE, y, z, method=method, eps=1e-10)
+    eps0 = B.epsilon
+    try:
+        B.epsilon = 1e-10
+        got = {}
+        for flag in (True, False):
+            matrix.config.pseudo_padded_transposed = flag
+            prior = st.Measure()
+            f = st.GP(st.EQ(), measure=prior)
+            tx, ty, tz = (torch.as_tensor(a, device=DEV) for a in (x, y, z))
+            obs = {"vfe": st.PseudoObs, "dtc": st.PseudoObsDTC}[method](f(tz), f(tx, NOISE), ty)
+            mu = obs.mu(prior)
+            got[flag] = (float(obs.elbo(prior)), (mu.mat if hasattr(mu, "mat") else mu).reshape(-1).cpu().numpy())
+    finally:
+        matrix.config.pseudo_padded_transposed = True
+        B.epsilon = eps0
+    for flag in (True, False):
+        assert abs(got[flag][0] - ref["elbo"]) <= 1e-6 * abs(ref["elbo"]), (flag, got[flag][0], ref["elbo"])
+        assert _rel(got[flag][1], ref["mu"]) <= 1e-6
+    assert abs(got[True][0] - got[False][0]) <= 1e-10 * abs(got[False][0])
