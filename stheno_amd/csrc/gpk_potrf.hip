@@ -1318,6 +1318,7 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     if (rows < n) rows = n;
     if (rows > INT32_MAX) return GPK_ERR_ARG(2);
     if (rows > n && n % GPK_DB != 0) return GPK_ERR_ARG(2);      // rows under the matrix: whole 128-blocks only
+    if (rows > n && gpk_cdiv(n, nb) > 64) return GPK_ERR_ARG(2);  // ... and at most 64 outer blocks (their column groups are a 64-bit mask)
     if (ld < n) return GPK_ERR_ARG(3);
     if (nb < 256 || nb > 4096 || (nb & (nb - 1))) return GPK_ERR_ARG(6);
     if (sb <= 0) sb = nb;
@@ -1388,12 +1389,16 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     struct ColGroup { int from; uint64_t mask; };          // column blocks (bit c - c_first) that are `from` panels deep
     auto group_cols = [&](int64_t c_first, int64_t j, bool all, std::vector<ColGroup>& out) {
         out.clear();
+        // more column blocks than a mask has bits (N / nb > 64): agg is 1 then, every block is updated in every step and they all
+        // have the same depth -- ONE group that means "every column" (all-ones; col_segment turns it into the plain triangle)
+        const bool wide = nblk - c_first > 64;
         for (int64_t c = c_first; c < nblk; ++c) {
             if (!all && (c - j) % agg != 0) continue;
             size_t g = 0;
             while (g < out.size() && out[g].from != applied[(size_t)c]) ++g;
             if (g == out.size()) out.push_back(ColGroup{applied[(size_t)c], 0});
-            out[g].mask |= (uint64_t)1 << (c - c_first);
+            if (wide) out[g].mask = ~(uint64_t)0;
+            else out[g].mask |= (uint64_t)1 << (c - c_first);
             applied[(size_t)c] = (int)(j + 1);
         }
     };

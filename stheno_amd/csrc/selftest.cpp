@@ -706,6 +706,7 @@ static void test_lookahead() {
         gpk_tune(40, 9216); gpk_tune(41, 512);
     }
     gpk_tune(47, 2);
+    test_potrf_la_case<T>(16896, 256, 1, 0, 1024);       // 66 outer blocks: more than a column-group mask has bits (every block, every step)
     // a non-positive-definite matrix is reported with the global pivot order
     {
         const int n = 1500, nb = 512, bad = 1111;

@@ -660,6 +660,8 @@ class KernelDense(Dense):
         n = self.kernel.num_outputs(self.x)
         if n != self.x.shape[-2] or n % 128 != 0 or n < config.posterior_rows_from or ns < config.posterior_rows_min_points or ns > 4 * n:
             return False
+        if n > 64 * 512:            # (the look-ahead's column groups are a 64-bit mask: at most 64 outer blocks of >= 512 columns)
+            return False
         return self._noise_parts()[2] is None
 
     def chol_with_rows(self, k_cross, xs):
