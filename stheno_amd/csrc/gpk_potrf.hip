@@ -1224,8 +1224,9 @@ GPK_KNOB(int, g_la_fuse_diag_nb, 512);          // tuning knob (gpk_tune(41, v))
 // Round 5: AGGREGATED trailing updates.  Column block c of the trailing matrix only has to be up to date when its own panel is
 // factorised, so outer step j updates -- besides the next panel's block j + 1, always -- only the column blocks c = j + 2, j + 2 + m,
 // j + 2 + 2m, ... (c == j mod m), each with ALL the panels it has not seen yet: m nb deep instead of nb.  Same flops, every C tile
-// of the trailing matrix visited N / (m nb) times instead of N / nb times -- a visit costs ~35 us outside its k loop whatever K is
-// (C tile arriving, stores draining: profiles/r04_experiments.md section 4).  m = 1: the classic right-looking update.
+// of the trailing matrix visited N / (m nb) times instead of N / nb times.  m = 1: the classic right-looking update.  Measured
+// (profiles/r05_experiments.md section 1): m = 2 -0.9 % fp64 N = 16384, -2.3 % fp32 N = 32768; m = 3, 4 slower than m = 1 -- most of
+// what a visit spends outside its k loop is covered by the CU's other workgroup already, and longer tiles cost at the end of a launch.
 GPK_KNOB(int, g_la_agg, 2);                     // tuning knob (gpk_tune(47, v)): m
 GPK_KNOB(int64_t, g_la_agg_min_rows, 0);        // tuning knob (gpk_tune(48, v)): aggregate only while the trailing matrix has >= this many rows (below: every column block, every step)
 
