@@ -27,6 +27,9 @@ class _Config:
     #: the scan is a device reduction plus ONE host read of its flag -- set False when `y` is known to be complete and the host should
     #: not wait for the device there
     check_nan = True
+    #: ``Normal.mean`` as the reference returns it (``README.md:58-68``: a ``Dense`` matrix that ``B.dense`` strips) instead of a plain
+    #: ``torch.Tensor``.  Off by default: every caller on this path wants the tensor, and ``B.dense`` accepts both.
+    mean_as_matrix = False
     #: outer block of the blocked Cholesky (0 = library default)
     potrf_nbo = 0
     #: single matrices of at least this order take the look-ahead factorisation (``gpk_potrf_la``); 0 disables it.  Below, the plain

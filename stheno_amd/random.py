@@ -137,11 +137,18 @@ class Normal(RandomVector):
     __str__ = __repr__
 
     @property
-    def mean(self):
-        """Column vector: mean."""
+    def _mean_t(self):
+        """The mean as a plain column-vector tensor (what every computation below uses)."""
         self._settle_mean(as_tensor=True)
         m = self._m.value
         return m.dense() if isinstance(m, AbstractMatrix) else m
+
+    @property
+    def mean(self):
+        """Column vector: mean.  A plain tensor -- or, with ``config.mean_as_matrix``, the reference's return type (``matrix.Dense``,
+        README.md:58-68; ``B.dense`` strips it)."""
+        m = self._mean_t
+        return Dense(m) if config.mean_as_matrix else m
 
     @property
     def mean_is_zero(self):
@@ -178,7 +185,7 @@ class Normal(RandomVector):
         """Marginal means and variances (the covariance is not formed when a
         ``mean_var_diag`` constructor is available)."""
         self._settle_jointly(self._d, self._joint_diag)
-        mean, var_diag = self.mean, self.var_diag
+        mean, var_diag = self._mean_t, self.var_diag
         if isinstance(var_diag, AbstractMatrix):
             var_diag = var_diag.dense()
         # Variances can come out slightly negative through round-off (random.py:221-227).
@@ -213,7 +220,7 @@ class Normal(RandomVector):
             if any_missing(x):
                 available = ~torch.isnan(x[:, 0])
                 idx = torch.nonzero(available)[:, 0]
-                mean = self.mean[idx]
+                mean = self._mean_t[idx]
                 var = self.var
                 if isinstance(var, KernelDense) and torch.is_tensor(var.x) and var.x.dim() == 2 and var._mat is None and not isinstance(var.noise, Dense) \
                         and var.kernel.num_outputs(var.x) == var.x.shape[0]:
@@ -231,7 +238,7 @@ class Normal(RandomVector):
 
         var = self.var
         n = self.dim
-        r = x - self.mean
+        r = x - self._mean_t
         # hyper-parameter learning: differentiable path for a kernel-matrix variance
         batched_ok = (r.dim() == 3 and r.shape[-1] == 1 and torch.is_tensor(getattr(var, "x", None)) and var.x.dim() == 3
                       and tuple(var.x.shape[:-2]) == tuple(r.shape[:-2]))
@@ -298,13 +305,13 @@ class Normal(RandomVector):
     @property
     def m2(self):
         """Second moment ``V + m m^T`` (``random.py:200-202``)."""
-        m = self.mean.contiguous()
+        m = self._mean_t.contiguous()
         be = ops.get_backend()
         return Dense(be.gemm(m, m, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=1.0, out=be.copy(self.var.dense())))
 
     def diagonalise(self):
         """The distribution with its correlations set to zero (``random.py:240-246``)."""
-        return Normal(self.mean, Diagonal(self.var_diag))
+        return Normal(self._mean_t, Diagonal(self.var_diag))
 
     def kl(self, other):
         """``KL(self || other)`` (``random.py:294-311``): ``tr(V_o^{-1} V_s) = |L_o^{-1} L_s|_F^2`` from the two
@@ -315,7 +322,7 @@ class Normal(RandomVector):
         w = vo.chol().solve(vs.chol().lower())
         _, ss = ops.get_backend().colreduce(w, want_ss=True)
         ratio = ss.sum(-1)
-        iqf = vo.iqf_diag(other.mean - self.mean)[..., 0]
+        iqf = vo.iqf_diag(other._mean_t - self._mean_t)[..., 0]
         return (iqf + ratio + vo.logdet() - vs.logdet() - self.dim) / 2
 
     # -- sampling (random.py:331-363; adjacent to the hot path) ----------------
@@ -346,28 +353,28 @@ class Normal(RandomVector):
                 xi = torch.randn(tuple(var.shape[:-1]) + (num,), dtype=var.dtype, device=var.device, generator=generator)
             out = ops.get_backend().gemm(l, xi.to(var.dtype), a_kmajor=True, b_kmajor=False)
         if not self.mean_is_zero:
-            out = out + self.mean
+            out = out + self._mean_t
         return out
 
     # -- arithmetic (random.py:365-393) ----------------------------------------
     def __add__(self, other):
         if isinstance(other, Normal):
-            return Normal(self.mean + other.mean, self.var + other.var)
+            return Normal(self._mean_t + other._mean_t, self.var + other.var)
         if isinstance(other, Random):
             raise TypeError(f"cannot add a {type(other).__name__} to a Normal")
-        return Normal(self.mean + other, self.var)
+        return Normal(self._mean_t + other, self.var)
 
     def __mul__(self, other):
         if isinstance(other, Random):
             raise TypeError(f"cannot multiply a Normal by a {type(other).__name__}")
-        return Normal(self.mean * other, Dense(self.var.dense() * (other * other)))
+        return Normal(self._mean_t * other, Dense(self.var.dense() * (other * other)))
 
     def lmatmul(self, a):
         """Distribution of ``a @ x`` (``random.py:365-371``): mean ``a m``, variance ``a V a^T`` (two GEMMs)."""
         a = a.dense() if isinstance(a, AbstractMatrix) else a
         be = ops.get_backend()
         av = be.gemm(a, self.var.dense(), a_kmajor=True, b_kmajor=False)          # a V
-        return Normal(be.gemm(a, self.mean, a_kmajor=True, b_kmajor=False), Dense(be.gemm(av, a, a_kmajor=True, b_kmajor=True)))
+        return Normal(be.gemm(a, self._mean_t, a_kmajor=True, b_kmajor=False), Dense(be.gemm(av, a, a_kmajor=True, b_kmajor=True)))
 
     def rmatmul(self, a):
         """Distribution of ``a^T @ x`` (``random.py:373-379``)."""

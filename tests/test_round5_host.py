@@ -10,7 +10,7 @@ import stheno_amd as st
 from oracle import gp_oracle as O
 from stheno_amd import B, matrix, ops
 
-from .conftest import OracleBackend
+from .conftest import DEVICE, OracleBackend
 
 
 @pytest.fixture()
@@ -90,3 +90,33 @@ def test_not_positive_definite_raises_from_the_rows_path(oracle_backend):
     f = st.GP(st.EQ())
     with pytest.raises(torch.linalg.LinAlgError):
         (f | (f(torch.as_tensor(x), -5.0), torch.as_tensor(y)))(torch.as_tensor(xs)).marginals()
+
+
+def test_mean_as_the_reference_returns_it(any_backend):
+    """``config.mean_as_matrix``: ``.mean`` is a ``Dense`` that ``B.dense`` strips (reference README.md:58-68); everything computed
+    FROM the mean (log-density, marginals, sampling, arithmetic) is unchanged."""
+    from stheno_amd import EQ, GP
+
+    dev = DEVICE[0]
+    x = torch.linspace(0, 2, 40, dtype=torch.float64, device=dev)
+    f = GP(lambda t: t ** 2, EQ())
+    y = torch.sin(x)
+    plain = f(x, 0.1)
+    want_mean, want_lp = plain.mean, plain.logpdf(y)
+    want_m, want_v = plain.marginals()
+    matrix.config.mean_as_matrix = True
+    try:
+        d = f(x, 0.1)
+        assert isinstance(d.mean, matrix.Dense)
+        assert torch.equal(B.dense(d.mean), want_mean)
+        assert torch.equal(d.logpdf(y), want_lp)
+        m, v = d.marginals()
+        assert torch.equal(m, want_m) and torch.equal(v, want_v)
+        mv_m, mv_v = d.mean_var
+        assert isinstance(mv_m, matrix.Dense) and isinstance(mv_v, matrix.AbstractMatrix)
+        assert torch.equal(B.dense((d + d).mean), 2 * want_mean)
+        post = f | (d, y)
+        assert isinstance(post(x).mean, matrix.Dense)
+    finally:
+        matrix.config.mean_as_matrix = False
+    assert torch.is_tensor(f(x, 0.1).mean)
