@@ -66,26 +66,31 @@ template <>
 __device__ __forceinline__ double gpk_exp<double>(double x) { return gpk_exp_neg(x); }   // every argument on this path is <= 0
 template <>
 __device__ __forceinline__ float gpk_exp<float>(float x) { return expf(x); }
+#ifndef GPK_KMAT_R4_MATH
+#define GPK_KMAT_R4_MATH 0       // 1: round 4's fp64 exp (degree-13 polynomial) and sqrt (two Goldschmidt steps), for `make ab`
+#endif
 template <typename T>
 __device__ __forceinline__ T gpk_sqrtk(T x);
-// sqrt of a squared distance times a positive constant (x >= 0, often exactly 0 on the diagonal): the hardware rsq estimate, two
-// coupled Goldschmidt steps and one residual correction (the scheme of sqrt_rsqrt in gpk_potrf.hip: ~1 ulp) -- 10 FMA-class
-// operations, no range scaling, no branch -- instead of the library sqrt.  Arguments below 1e-280 (0 included: rsq would overflow)
-// give 0: the kernel value moves by < 1e-140.  NaN stays NaN.
+// sqrt of a squared distance times a positive constant (x >= 0, often exactly 0 on the diagonal): the hardware rsq estimate
+// (~2^-23 relative), ONE coupled Goldschmidt step (-> ~2^-45 on both the root and the half reciprocal root) and one residual
+// correction, which is a Newton step of its own (-> rounding level; the second Goldschmidt step of sqrt_rsqrt in gpk_potrf.hip
+// bought nothing measurable here) -- 8 FMA-class operations, no range scaling, no branch, no select -- instead of the library
+// sqrt.  The argument is shifted by 1e-280 (rsq(0) would overflow): invisible from 1e-264 up, and sqrt(0) comes out as 1e-140,
+// which moves a kernel value by < 1e-140.  NaN stays NaN.
 template <>
 __device__ __forceinline__ double gpk_sqrtk<double>(double x) {
-    const bool tiny = x < 1e-280;
-    const double xc = tiny ? 1.0 : x;
+    const double xc = x + 1e-280;
     const double y = __builtin_amdgcn_rsq(xc);
     double g = xc * y, h = 0.5 * y;
     double e = fma(-h, g, 0.5);
     g = fma(g, e, g);
     h = fma(h, e, h);
+#if GPK_KMAT_R4_MATH
     e = fma(-h, g, 0.5);
     g = fma(g, e, g);
     h = fma(h, e, h);
-    g = fma(fma(-g, g, xc), h, g);
-    return tiny ? 0.0 : g;
+#endif
+    return fma(fma(-g, g, xc), h, g);
 }
 template <>
 __device__ __forceinline__ float gpk_sqrtk<float>(float x) { return sqrtf(x); }
@@ -241,6 +246,22 @@ __device__ __forceinline__ float gpk_exp_neg(float a) {
     const float f = (t - n) + e;
     return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
+// Two values at a time (round 5): the fp32 kernels are bound by the vector ALU (43 operations per element at D = 8, issued at the
+// chip's full rate), and gfx950 multiplies / adds / FMAs two fp32 values per lane and instruction (v_pk_*_f32).  Same arithmetic as
+// above -- the error term through explicit FMAs, never left to contraction -- with the product, both FMAs and the final sum packed;
+// clamp, rint, 2^x and ldexp have no packed form.
+typedef float gpk_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gpk_f2 gpk_exp_neg_pk(gpk_f2 a) {
+    a.x = (a.x < -104.f) ? -104.f : a.x;
+    a.y = (a.y < -104.f) ? -104.f : a.y;
+    const gpk_f2 L = {1.44269502162933349609375f, 1.44269502162933349609375f}, Ll = {1.925963033500011e-8f, 1.925963033500011e-8f};
+    const gpk_f2 t = a * L;
+    gpk_f2 e = __builtin_elementwise_fma(a, L, -t);
+    e = __builtin_elementwise_fma(a, Ll, e);
+    const gpk_f2 n = {rintf(t.x), rintf(t.y)};
+    const gpk_f2 f = (t - n) + e;
+    return gpk_f2{ldexpf(__builtin_amdgcn_exp2f(f.x), (int)n.x), ldexpf(__builtin_amdgcn_exp2f(f.y), (int)n.y)};
+}
 // fp64: Cody-Waite reduction a = n ln2 + r (|r| <= ln2 / 2, two-part ln2, one FMA each), the Taylor polynomial of degree 13 in
 // Horner form (truncation 4e-18 relative on that interval) and v_ldexp_f64: 13 + 4 FMA-class operations and no branch, against
 // ~3x that with branches for the library exp, which was what bounded the fp64 EQ build (2.3 of 8 TB/s).  Measured against
@@ -268,20 +289,75 @@ __device__ __forceinline__ double gpk_exp_neg(double a) {
     return ldexp(p, (int)n);
 }
 
+// The same with a table of 2^(j/128) (in LDS: `tab`): a = (128 m + j) ln2/128 + r, |r| <= ln2/256 = 0.0027, so the polynomial stops at
+// degree 5 (truncation r^6/720 < 6e-19) and exp(a) = 2^m (T_j + T_j (e^r - 1)): 12 FMA-class operations + 3 integer ones + one
+// 8-byte LDS read instead of 19.  Error: the table entry's rounding, one FMA rounding and ~0.003 ulp from the polynomial.
+__device__ const double gpk_exp2_128[128] = {
+    0x1.0000000000000p+0, 0x1.0163da9fb3335p+0, 0x1.02c9a3e778061p+0, 0x1.04315e86e7f85p+0,
+    0x1.059b0d3158574p+0, 0x1.0706b29ddf6dep+0, 0x1.0874518759bc8p+0, 0x1.09e3ecac6f383p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0cc922b7247f7p+0, 0x1.0e3ec32d3d1a2p+0, 0x1.0fb66affed31bp+0,
+    0x1.11301d0125b51p+0, 0x1.12abdc06c31ccp+0, 0x1.1429aaea92de0p+0, 0x1.15a98c8a58e51p+0,
+    0x1.172b83c7d517bp+0, 0x1.18af9388c8deap+0, 0x1.1a35beb6fcb75p+0, 0x1.1bbe084045cd4p+0,
+    0x1.1d4873168b9aap+0, 0x1.1ed5022fcd91dp+0, 0x1.2063b88628cd6p+0, 0x1.21f49917ddc96p+0,
+    0x1.2387a6e756238p+0, 0x1.251ce4fb2a63fp+0, 0x1.26b4565e27cddp+0, 0x1.284dfe1f56381p+0,
+    0x1.29e9df51fdee1p+0, 0x1.2b87fd0dad990p+0, 0x1.2d285a6e4030bp+0, 0x1.2ecafa93e2f56p+0,
+    0x1.306fe0a31b715p+0, 0x1.32170fc4cd831p+0, 0x1.33c08b26416ffp+0, 0x1.356c55f929ff1p+0,
+    0x1.371a7373aa9cbp+0, 0x1.38cae6d05d866p+0, 0x1.3a7db34e59ff7p+0, 0x1.3c32dc313a8e5p+0,
+    0x1.3dea64c123422p+0, 0x1.3fa4504ac801cp+0, 0x1.4160a21f72e2ap+0, 0x1.431f5d950a897p+0,
+    0x1.44e086061892dp+0, 0x1.46a41ed1d0057p+0, 0x1.486a2b5c13cd0p+0, 0x1.4a32af0d7d3dep+0,
+    0x1.4bfdad5362a27p+0, 0x1.4dcb299fddd0dp+0, 0x1.4f9b2769d2ca7p+0, 0x1.516daa2cf6642p+0,
+    0x1.5342b569d4f82p+0, 0x1.551a4ca5d920fp+0, 0x1.56f4736b527dap+0, 0x1.58d12d497c7fdp+0,
+    0x1.5ab07dd485429p+0, 0x1.5c9268a5946b7p+0, 0x1.5e76f15ad2148p+0, 0x1.605e1b976dc09p+0,
+    0x1.6247eb03a5585p+0, 0x1.6434634ccc320p+0, 0x1.6623882552225p+0, 0x1.68155d44ca973p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6c012750bdabfp+0, 0x1.6dfb23c651a2fp+0, 0x1.6ff7df9519484p+0,
+    0x1.71f75e8ec5f74p+0, 0x1.73f9a48a58174p+0, 0x1.75feb564267c9p+0, 0x1.780694fde5d3fp+0,
+    0x1.7a11473eb0187p+0, 0x1.7c1ed0130c132p+0, 0x1.7e2f336cf4e62p+0, 0x1.80427543e1a12p+0,
+    0x1.82589994cce13p+0, 0x1.8471a4623c7adp+0, 0x1.868d99b4492edp+0, 0x1.88ac7d98a6699p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8cf3216b5448cp+0, 0x1.8f1ae99157736p+0, 0x1.9145b0b91ffc6p+0,
+    0x1.93737b0cdc5e5p+0, 0x1.95a44cbc8520fp+0, 0x1.97d829fde4e50p+0, 0x1.9a0f170ca07bap+0,
+    0x1.9c49182a3f090p+0, 0x1.9e86319e32323p+0, 0x1.a0c667b5de565p+0, 0x1.a309bec4a2d33p+0,
+    0x1.a5503b23e255dp+0, 0x1.a799e1330b358p+0, 0x1.a9e6b5579fdbfp+0, 0x1.ac36bbfd3f37ap+0,
+    0x1.ae89f995ad3adp+0, 0x1.b0e07298db666p+0, 0x1.b33a2b84f15fbp+0, 0x1.b59728de5593ap+0,
+    0x1.b7f76f2fb5e47p+0, 0x1.ba5b030a1064ap+0, 0x1.bcc1e904bc1d2p+0, 0x1.bf2c25bd71e09p+0,
+    0x1.c199bdd85529cp+0, 0x1.c40ab5fffd07ap+0, 0x1.c67f12e57d14bp+0, 0x1.c8f6d9406e7b5p+0,
+    0x1.cb720dcef9069p+0, 0x1.cdf0b555dc3fap+0, 0x1.d072d4a07897cp+0, 0x1.d2f87080d89f2p+0,
+    0x1.d5818dcfba487p+0, 0x1.d80e316c98398p+0, 0x1.da9e603db3285p+0, 0x1.dd321f301b460p+0,
+    0x1.dfc97337b9b5fp+0, 0x1.e264614f5a129p+0, 0x1.e502ee78b3ff6p+0, 0x1.e7a51fbc74c83p+0,
+    0x1.ea4afa2a490dap+0, 0x1.ecf482d8e67f1p+0, 0x1.efa1bee615a27p+0, 0x1.f252b376bba97p+0,
+    0x1.f50765b6e4540p+0, 0x1.f7bfdad9cbe14p+0, 0x1.fa7c1819e90d8p+0, 0x1.fd3c22b8f71f1p+0,
+};
+__device__ __forceinline__ double gpk_exp_neg_tab(double a, const double* tab) {
+    a = (a < -750.0) ? -750.0 : a;
+    const double n = rint(a * 184.6649652337873);                  // 128 / ln 2
+    double r = fma(-n, 6.93147180369123816490e-01 / 128, a);      // ln2_hi / 128 (32 significant bits: exact times n < 2^17)
+    r = fma(-n, 1.90821492927058770002e-10 / 128, r);             // ln2_lo / 128
+    const int ni = (int)n;
+    const double t = tab[ni & 127];
+    double u = 8.333333333333333e-03;        // 1/5!
+    u = fma(u, r, 4.1666666666666664e-02);
+    u = fma(u, r, 1.6666666666666666e-01);
+    u = fma(u, r, 0.5);
+    u = fma(u, r, 1.0);
+    return ldexp(fma(t, u * r, t), ni >> 7);
+}
+__device__ __forceinline__ double gpk_exp_neg_t(double a, const double* tab) { return GPK_KMAT_R4_MATH ? gpk_exp_neg(a) : gpk_exp_neg_tab(a, tab); }
+__device__ __forceinline__ float gpk_exp_neg_t(float a, const float*) { return gpk_exp_neg(a); }
+
 template <typename T, int PROG>
-__device__ __forceinline__ T eval_prog(const KmatArgs<T>& p, T r2, T dot) {
+__device__ __forceinline__ T eval_prog(const KmatArgs<T>& p, T r2, T dot, const T* etab) {
     if (PROG == PROG_GENERIC) return eval_terms<T>(p, r2, dot);
     const T v0 = p.terms[0].variance, c0 = p.terms[0].ils2;
-    if (PROG == PROG_EQ) return v0 * gpk_exp_neg(T(-0.5) * c0 * r2);
-    if (PROG == PROG_EQ_LINEAR) return v0 * gpk_exp_neg(T(-0.5) * c0 * r2) + p.terms[1].variance * p.terms[1].ils2 * dot;
-    const T q = r2 * c0;
-    if (PROG == PROG_M12) return v0 * gpk_exp_neg(-gpk_sqrtk<T>(q));
+    if (PROG == PROG_EQ) return v0 * gpk_exp_neg_t(T(-0.5) * c0 * r2, etab);
+    if (PROG == PROG_EQ_LINEAR) return v0 * gpk_exp_neg_t(T(-0.5) * c0 * r2, etab) + p.terms[1].variance * p.terms[1].ils2 * dot;
+    // (the constants below are uniform: formed once per workgroup.  3 c0 r2 for (3 c0) r2 and v0 + v0 s + (v0 / 3) s^2 in Horner form
+    // move a value by an ulp or two against the literal formula -- the price of 1 + 2 operations less per element)
+    if (PROG == PROG_M12) return v0 * gpk_exp_neg_t(-gpk_sqrtk<T>(r2 * c0), etab);
     if (PROG == PROG_M32) {
-        const T sd = gpk_sqrtk<T>(T(3) * q);
-        return v0 * (T(1) + sd) * gpk_exp_neg(-sd);
+        const T sd = gpk_sqrtk<T>(r2 * (T(3) * c0));
+        return fma(v0, sd, v0) * gpk_exp_neg_t(-sd, etab);
     }
-    const T sd = gpk_sqrtk<T>(T(5) * q);
-    return v0 * (T(1) + sd + sd * sd * T(1.0 / 3.0)) * gpk_exp_neg(-sd);
+    const T sd = gpk_sqrtk<T>(r2 * (T(5) * c0));
+    return fma(fma(v0 * T(1.0 / 3.0), sd, v0), sd, v0) * gpk_exp_neg_t(-sd, etab);
 }
 
 constexpr int CT_MAX = 8;    // column tiles per workgroup (fewer when the grid would not fill the chip a few times over)
@@ -295,6 +371,9 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
     constexpr int YL = (TN * DC + 255) / 256;   // Y elements each thread stages per column tile
     __shared__ T xs[TM * DC];
     __shared__ __attribute__((aligned(16))) T ys[2][DC * TNP];   // Y tile, dimension-major: ys[j][c]
+    constexpr bool ETAB = sizeof(T) == 8 && PROG != PROG_GENERIC;  // fp64: exp through the 2^(j/128) table (gpk_exp_neg_tab)
+    constexpr bool PK32 = sizeof(T) == 4 && (PROG == PROG_EQ || PROG == PROG_EQ_LINEAR) && !GPK_KMAT_R4_MATH;   // fp32: two values per instruction
+    __shared__ T etab[ETAB ? 128 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,6 +431,7 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
     };
     fetch_y(ct0 * TN);
     commit_y(0);
+    if (ETAB && tid < 128) etab[tid] = (T)gpk_exp2_128[tid];
     __syncthreads();
 
     for (int c = 0; c < CT; ++c) {
@@ -375,21 +455,54 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
 #pragma unroll
             for (int j = 0; j < DC; ++j) xr[j] = xs[(wave * RW + r) * DC + j];
             T vals[VEC];
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                T r2 = T(0), dt = T(0);
+            if constexpr (PK32) {
+                // fp32 EQ / EQ + Linear: the row's four values as two pairs on the packed fp32 instructions (see gpk_exp_neg_pk)
+                gpk_f2 acc[2] = {gpk_f2{0.f, 0.f}, gpk_f2{0.f, 0.f}}, dot[2] = {gpk_f2{0.f, 0.f}, gpk_f2{0.f, 0.f}};
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
-                    const T df = xr[j] - ya[j][v];
-                    r2 += df * df;
-                    if (DOT) dt += xr[j] * ya[j][v];
+                    const gpk_f2 xx = {(float)xr[j], (float)xr[j]};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const gpk_f2 yy = {(float)ya[j][2 * h], (float)ya[j][2 * h + 1]};
+                        const gpk_f2 df = xx - yy;
+                        acc[h] = __builtin_elementwise_fma(df, df, acc[h]);
+                        if (DOT) dot[h] = __builtin_elementwise_fma(xx, yy, dot[h]);
+                    }
                 }
-                T val = eval_prog<T, PROG>(p, r2, dt);
-                if (has_diag && colb + v == row) {
-                    val += p.diag_add;
-                    if (p.diag_vec != nullptr) val += p.diag_vec[b * p.sDiag + row];
+                const float ca = -0.5f * (float)p.terms[0].ils2, v0 = (float)p.terms[0].variance;
+                const float vl = (PROG == PROG_EQ_LINEAR) ? (float)(p.terms[1].variance * p.terms[1].ils2) : 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    gpk_f2 k = gpk_exp_neg_pk(acc[h] * gpk_f2{ca, ca}) * gpk_f2{v0, v0};
+                    if (PROG == PROG_EQ_LINEAR) k = __builtin_elementwise_fma(dot[h], gpk_f2{vl, vl}, k);
+                    vals[2 * h] = (T)k.x;
+                    vals[2 * h + 1] = (T)k.y;
                 }
-                vals[v] = val;
+                if (has_diag) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        if (colb + v == row) {
+                            vals[v] += p.diag_add;
+                            if (p.diag_vec != nullptr) vals[v] += p.diag_vec[b * p.sDiag + row];
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    T r2 = T(0), dt = T(0);
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        const T df = xr[j] - ya[j][v];
+                        r2 += df * df;
+                        if (DOT) dt += xr[j] * ya[j][v];
+                    }
+                    T val = eval_prog<T, PROG>(p, r2, dt, etab);
+                    if (has_diag && colb + v == row) {
+                        val += p.diag_add;
+                        if (p.diag_vec != nullptr) val += p.diag_vec[b * p.sDiag + row];
+                    }
+                    vals[v] = val;
+                }
             }
             if (row >= p.n) continue;
             T* o = out + (int64_t)row * p.ld + colb;

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <limits>
 #include <vector>
 #include "../../include/gpk.h"
 
@@ -272,8 +273,49 @@ static void test_kmat_case(std::vector<int> kinds, int n, int m, int d, int batc
     snprintf(nm, sizeof nm, "kmat_%s k%d.. nt%d n%d m%d d%d b%d sym%d low%d acc%d dv%d st%d", DT<T>::name(), kinds[0], nt, n, m, d, batch, sym, lower, acc, dvec, st);
     report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * 50);
 }
+// kernel values ELEMENT by element against an 80-bit reference, in units of eps * (1 + |argument of the exponential|): that
+// factor is what the rounding of the squared distance (D terms, a few ulp) is amplified by; what is left measures the device's own
+// exp / sqrt (a table-based exp and a shortened rsqrt iteration since round 5).  Scales from near-duplicates to e^-600.
+template <typename T>
+static void test_kmat_ulp(int kind, double scale, double ilv) {
+    const int n = 192, m = 320, d = 8;
+    auto X = randv<T>((size_t)n * d, scale), Y = randv<T>((size_t)m * d, scale);
+    for (int k = 0; k < d; ++k) Y[k] = X[k] * (T)(1 + 64 * (double)std::numeric_limits<T>::epsilon());                 // one near-duplicate pair, one exact duplicate
+    for (int k = 0; k < d; ++k) Y[d + k] = X[d + k];
+    Dev<T> dX(X.size()), dY(Y.size()), dO((size_t)n * m);
+    dX.up(X); dY.up(Y);
+    double var = 1.3, il = ilv;
+    int st = gpk_kmat(DT<T>::v, &kind, &var, &il, 1, dX.p, n, d, 0, dY.p, m, d, 0, d, dO.p, m, 0, 1, 0, 0, 0.0, nullptr, 0, 0, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto got = dO.down();
+    double worst = 0, amin = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            long double r2 = 0;
+            for (int k = 0; k < d; ++k) { const long double df = (long double)X[(size_t)i * d + k] - (long double)Y[(size_t)j * d + k]; r2 += df * df; }
+            const long double q = r2 * (long double)il * (long double)il;
+            long double a, v;
+            if (kind == GPK_K_EQ) { a = -0.5L * q; v = expl(a); }
+            else if (kind == GPK_K_MATERN12) { a = -sqrtl(q); v = expl(a); }
+            else if (kind == GPK_K_MATERN32) { a = -sqrtl(3 * q); v = (1 - a) * expl(a); }
+            else { a = -sqrtl(5 * q); v = (1 - a + a * a / 3) * expl(a); }
+            v *= (long double)var;
+            if (a < (sizeof(T) == 8 ? -700 : -85)) continue;      // (denormal results: absolute, not relative, accuracy there)
+            const double e = (double)(fabsl((long double)got[(size_t)i * m + j] - v) / v) / ((double)std::numeric_limits<T>::epsilon() * (1.0 + (double)-a));
+            worst = std::max(worst, e);
+            amin = std::min(amin, (double)a);
+        }
+    char nm[160];
+    snprintf(nm, sizeof nm, "kmat_%s kind%d elementwise, exp arguments down to %.0f: worst error / (eps (1 + |arg|)) st%d", DT<T>::name(), kind, amin, st);
+    report(nm, st ? INFINITY : worst, 6.0);
+}
 template <typename T>
 static void test_kmat() {
+    for (int kind : {GPK_K_EQ, GPK_K_MATERN12, GPK_K_MATERN32, GPK_K_MATERN52}) {
+        test_kmat_ulp<T>(kind, 1.0, 0.9);
+        test_kmat_ulp<T>(kind, 1.0, (sizeof(T) == 8 ? 1.0 : 0.35) * (kind == GPK_K_EQ ? 6.0 : 60.0));
+        test_kmat_ulp<T>(kind, 1e-3, 1.0);
+    }
     for (int k = 0; k <= 5; ++k) test_kmat_case<T>({k}, 70, 45, 3, 1, false, false, false, false);
     test_kmat_case<T>({GPK_K_EQ}, 300, 300, 8, 2, true, false, false, true);
     test_kmat_case<T>({GPK_K_EQ}, 700, 700, 8, 1, true, true, false, false);
