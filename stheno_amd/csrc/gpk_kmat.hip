@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
     __shared__ T xs[TM * DC];
     __shared__ __attribute__((aligned(16))) T ys[2][DC * TNP];   // Y tile, dimension-major: ys[j][c]
     constexpr bool ETAB = sizeof(T) == 8 && PROG != PROG_GENERIC;  // fp64: exp through the 2^(j/128) table (gpk_exp_neg_tab)
-    constexpr bool PK32 = sizeof(T) == 4 && (PROG == PROG_EQ || PROG == PROG_EQ_LINEAR) && !GPK_KMAT_R4_MATH;   // fp32: two values per instruction
+    constexpr bool PK32 = sizeof(T) == 4 && PROG != PROG_GENERIC && !GPK_KMAT_R4_MATH;   // fp32: two values per instruction
     __shared__ T etab[ETAB ? 128 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
             for (int j = 0; j < DC; ++j) xr[j] = xs[(wave * RW + r) * DC + j];
             T vals[VEC];
             if constexpr (PK32) {
-                // fp32 EQ / EQ + Linear: the row's four values as two pairs on the packed fp32 instructions (see gpk_exp_neg_pk)
+                // fp32, every compile-time kernel program: the row's four values as two pairs on the packed fp32 instructions (see gpk_exp_neg_pk)
                 gpk_f2 acc[2] = {gpk_f2{0.f, 0.f}, gpk_f2{0.f, 0.f}}, dot[2] = {gpk_f2{0.f, 0.f}, gpk_f2{0.f, 0.f}};
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
@@ -469,12 +469,27 @@ __global__ __launch_bounds__(256) void kmat_band_kernel(KmatArgs<T> p) {
                         if (DOT) dot[h] = __builtin_elementwise_fma(xx, yy, dot[h]);
                     }
                 }
-                const float ca = -0.5f * (float)p.terms[0].ils2, v0 = (float)p.terms[0].variance;
+                const float c0 = (float)p.terms[0].ils2, v0 = (float)p.terms[0].variance;
                 const float vl = (PROG == PROG_EQ_LINEAR) ? (float)(p.terms[1].variance * p.terms[1].ils2) : 0.f;
+                const gpk_f2 vv = {v0, v0};
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    gpk_f2 k = gpk_exp_neg_pk(acc[h] * gpk_f2{ca, ca}) * gpk_f2{v0, v0};
-                    if (PROG == PROG_EQ_LINEAR) k = __builtin_elementwise_fma(dot[h], gpk_f2{vl, vl}, k);
+                    gpk_f2 k;
+                    if (PROG == PROG_EQ || PROG == PROG_EQ_LINEAR) {
+                        const float ca = -0.5f * c0;
+                        k = gpk_exp_neg_pk(acc[h] * gpk_f2{ca, ca}) * vv;
+                        if (PROG == PROG_EQ_LINEAR) k = __builtin_elementwise_fma(dot[h], gpk_f2{vl, vl}, k);
+                    } else {
+                        // Matern: sqrt straight from v_sqrt_f32 (1 ulp; the library sqrtf spends ~10 more instructions on rescaling
+                        // denormal arguments, i.e. distances below 1e-19, and on the last half ulp)
+                        const float cs = (PROG == PROG_M12 ? 1.f : PROG == PROG_M32 ? 3.f : 5.f) * c0;
+                        const gpk_f2 q = acc[h] * gpk_f2{cs, cs};
+                        const gpk_f2 sd = {__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y)};
+                        const gpk_f2 e = gpk_exp_neg_pk(-sd);
+                        if (PROG == PROG_M12) k = e * vv;
+                        else if (PROG == PROG_M32) k = __builtin_elementwise_fma(sd, vv, vv) * e;
+                        else k = __builtin_elementwise_fma(__builtin_elementwise_fma(sd, gpk_f2{v0 * (1.f / 3.f), v0 * (1.f / 3.f)}, vv), sd, vv) * e;
+                    }
                     vals[2 * h] = (T)k.x;
                     vals[2 * h + 1] = (T)k.y;
                 }
