@@ -278,10 +278,18 @@ class ZeroKernel(Kernel):
     def terms(self):
         return []
 
-    def pairwise(self, x, y=None, **kw):
+    def pairwise(self, x, y=None, *, out=None, diag_add=0.0, diag_vec=None, **kw):
         x = uprank(x)
-        y = x if y is None else uprank(y)
-        return torch.zeros(x.shape[:-1] + (y.shape[-2],), dtype=x.dtype, device=x.device)
+        sym = y is None
+        y = x if sym else uprank(y)
+        shape = tuple(x.shape[:-1]) + (y.shape[-2],)
+        if out is not None:               # a caller's (strided) view: the zeros go THERE (blocks of one buffer, rows under a matrix)
+            if tuple(out.shape) != shape:
+                raise ValueError(f"out has shape {tuple(out.shape)}, the kernel matrix {shape}")
+            out.zero_()
+        else:
+            out = torch.zeros(shape, dtype=x.dtype, device=x.device)
+        return _add_diag(out, diag_add, diag_vec) if sym else out      # (noise / jitter of `k(x) + noise`: the diagonal is all there is)
 
     def elwise(self, x, y=None, **kw):
         x = uprank(x)
@@ -782,10 +790,17 @@ def _whiten(cache, K_z, k, z, x, own_cross=False):
         return cache[key][0]
     # Nothing factorised yet (conditioning, then prediction, no log-density in between): the cross-covariance rides in the
     # factorisation as rows under the kernel matrix and comes out whitened, transposed -- no separate many-column solve.
-    if (own_cross and hasattr(K_z, "can_factor_with_rows") and k.terms() is not None and x.dim() == 2 and z.dim() == 2 and not x.requires_grad
+    # (a non-empty term list: the zero kernel -- the cross-kernel of a process independent of the observed one -- has `terms() == []`,
+    #  nothing to whiten and no business in the factorisation)
+    if (own_cross and hasattr(K_z, "can_factor_with_rows") and k.terms() and not isinstance(k, ZeroKernel) and x.dim() == 2 and z.dim() == 2 and not x.requires_grad
             and ("kzx", id(k), id(z), id(x)) not in (cache or {}) and z is getattr(K_z, "x", None) and K_z.can_factor_with_rows(x.shape[-2])):
         _, zt = K_z.chol_with_rows(k, x)
         v = WhitenedT(zt)
+        if cache is not None:
+            cache[key] = (v, K_z, k, z, x)
+        return v
+    if isinstance(k, ZeroKernel):         # an independent process: L^{-1} 0 = 0, nothing to solve
+        v = k.pairwise(z, x)
         if cache is not None:
             cache[key] = (v, K_z, k, z, x)
         return v

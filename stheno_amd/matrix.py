@@ -661,9 +661,13 @@ class KernelDense(Dense):
         if not hasattr(be, "potrf_rows_") or self.x.dim() != 2 or self.x.requires_grad:
             return False
         n = self.kernel.num_outputs(self.x)
-        if n != self.x.shape[-2] or n % 128 != 0 or n < config.posterior_rows_from or ns < config.posterior_rows_min_points or ns > 4 * n:
+        # ns <= n: the cached factor is a view of the (n + ns, n) buffer, so the whitened rows live as long as the factor does --
+        # at most twice the factor's memory (with ns up to 4 n it was five times)
+        if n != self.x.shape[-2] or n % 128 != 0 or n < config.posterior_rows_from or ns < config.posterior_rows_min_points or ns > n:
             return False
         if n > 64 * 512:            # (the look-ahead's column groups are a 64-bit mask: at most 64 outer blocks of >= 512 columns)
+            return False
+        if not rows_panels_fit(n, ns, self.x.element_size(), bool(config.potrf_lookahead_from) and n >= config.potrf_lookahead_from):
             return False
         return self._noise_parts()[2] is None
 
@@ -674,10 +678,28 @@ class KernelDense(Dense):
         n, ns = self.x.shape[-2], xs.shape[-2]
         buf = torch.empty((n + ns, n), dtype=self.x.dtype, device=self.x.device)
         _, dvec, _ = self._noise_parts()
-        self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n])
-        k_cross.pairwise(xs, self.x, out=buf[n:])
+        top = self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n])
+        low = k_cross.pairwise(xs, self.x, out=buf[n:])
+        # (a kernel that ignores `out=` would leave the buffer uninitialised and the factorisation would whiten garbage)
+        if top.data_ptr() != buf.data_ptr() or low.data_ptr() != buf[n:].data_ptr():
+            raise RuntimeError(f"{type(self.kernel).__name__} / {type(k_cross).__name__}.pairwise did not write into `out`")
         self._chol, zt = Chol.factor_rows_(buf, n)
         return self._chol, zt
+
+
+def rows_panels_fit(n, ns, itemsize, lookahead):
+    """Whether every pipelined panel ``gpk_potrf_rows`` would launch for an order ``n`` with ``ns`` rows under the matrix finds room
+    for its control words -- the native limit (``gpk_potrf.hip:potrf_panel_pipe``, ``gpk_potrf_pipe.hpp:pipe_ctrl_words``), mirrored
+    so that the host never picks a shape the library refuses (``GPK_ERR_ARG(2)`` where the separate solve would have worked): a panel
+    of ``npb`` 128-column blocks over ``m`` rows keeps ``96 + 2 ceil(m / 64) npb`` 4-byte words in ONE 128 x 128 slot of ``dinv``.
+    Orders up to 4096 are one panel over all ``n + ns`` rows; above, 1024-column panels, the tallest one over ``n + ns`` rows
+    (plain path) or over the look-ahead's plain tail of at most 6144 columns plus the ``ns`` rows."""
+    budget = 128 * 128 * itemsize // 4
+    if n <= 4096:
+        m, npb = n + ns, -(-n // 128)
+    else:
+        m, npb = (min(n, 6144) if lookahead else n) + ns, 8
+    return 96 + 2 * (-(-m // 64)) * npb <= budget
 
 
 class FactoredDense(Dense):

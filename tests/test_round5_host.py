@@ -120,3 +120,63 @@ def test_mean_as_the_reference_returns_it(any_backend):
     finally:
         matrix.config.mean_as_matrix = False
     assert torch.is_tensor(f(x, 0.1).mean)
+
+
+def test_an_independent_process_is_not_sent_through_the_rows_path(oracle_backend):
+    """the cross-kernel of a process independent of the observed one is the ZERO kernel, whose ``terms()``
+    is the empty list -- the rows-under-the-matrix path took it, ``ZeroKernel.pairwise`` ignored ``out=`` and the uninitialised
+    rows of the buffer came back as a whitened cross-covariance.  The posterior of an independent process is its prior
+    (``stheno/model/measure.py:172-173``: independent processes get ``ZeroKernel`` cross-kernels)."""
+    rng = np.random.default_rng(3)
+    n, ns, d = 256, 24, 2
+    x, xs = rng.standard_normal((n, d)), rng.standard_normal((ns, d))
+    y = rng.standard_normal((n, 1))
+    tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
+    m = st.Measure()
+    f = st.GP(st.EQ(), measure=m)
+    g = st.GP(2.0 * st.EQ(), measure=m)
+    fdd = f(tx, 0.1)
+    post = m | (fdd, ty)
+    mean, var = post(g)(txs).marginals()
+    assert np.allclose(mean.numpy(), 0.0, atol=1e-12) and np.allclose(var.numpy(), 2.0, rtol=1e-12)
+    # the observed process afterwards (the factor exists by now: the posterior mean of `g` asked for L^{-1} y) matches the oracle
+    mean_f, var_f = post(f)(txs).marginals()
+    ref_mean, _, ref_var = O.gp_posterior([("eq", 1.0, 1.0)], x, 0.1, y, xs, full_cov=False)
+    assert _rel(mean_f.numpy(), ref_mean) <= 1e-9 and _rel(var_f.numpy(), ref_var) <= 1e-9
+
+
+def test_zero_kernel_writes_into_the_view_it_is_given(oracle_backend):
+    from stheno_amd.kernels import ZeroKernel
+
+    buf = torch.full((6, 5), 7.0, dtype=torch.float64)
+    x, y = torch.zeros(3, 2, dtype=torch.float64), torch.zeros(5, 2, dtype=torch.float64)
+    out = ZeroKernel().pairwise(x, y, out=buf[2:5])
+    assert out.data_ptr() == buf[2:5].data_ptr() and float(buf[2:5].abs().max()) == 0.0 and float(buf[:2].min()) == 7.0
+    k = ZeroKernel().pairwise(x, None, diag_add=0.5, diag_vec=torch.ones(3, dtype=torch.float64))
+    assert torch.equal(k, 1.5 * torch.eye(3, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        ZeroKernel().pairwise(x, y, out=buf[:2])
+
+
+def test_rows_path_is_refused_where_the_native_panels_have_no_room():
+    """``can_factor_with_rows`` mirrors the native control-word budget (``gpk_potrf_pipe.hpp``:
+    96 + 2 ceil(m / 64) npb words in one 128 x 128 slot of ``dinv``) and caps the rows at the order of the matrix."""
+    fit = matrix.rows_panels_fit
+    assert fit(4096, 4096, 4, False) and fit(4096, 4096, 8, False)
+    assert not fit(4096, 16384, 4, False)           # the advisor's example: n = 4096 fp32, ns = 16384 -> 96 + 2 * 320 * 32 = 20576 > 16384
+    assert fit(4096, 16384, 8, False)
+    assert fit(32768, 32768, 4, True) and fit(11136, 11136, 4, False)
+    assert not fit(32768, 60000, 4, True) and fit(32768, 60000, 8, True)
+    k = matrix.KernelDense(st.EQ(), torch.zeros(4096, 2), None)
+
+    class _Be:
+        name = "hip"
+
+        def potrf_rows_(self, *a, **kw):
+            raise AssertionError
+
+    prev = ops.set_backend(_Be())
+    try:
+        assert k.can_factor_with_rows(4096) and not k.can_factor_with_rows(4097) and not k.can_factor_with_rows(16384)
+    finally:
+        ops.set_backend(prev)
