@@ -312,6 +312,15 @@ int gpk_kmat_vjp_dense(int dtype, const int* kinds, const double* variances, con
 int gpk_prof_start(void);
 int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops);
 
+/* The SUSTAINED rate of the matrix pipes, measured on the device the call runs on ("re-derive on the box from a measured
+ * MFMA micro-benchmark and print the value used"): one workgroup per CU, `waves_per_simd` (1 or 2) register-resident waves per SIMD
+ * streaming v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32 (the instructions every GEMM of this library issues) on pseudo-random
+ * operands into 8 independent accumulators, launches repeated until `min_ms` of device time have passed.  Out: *tflops = flops / HIP-event
+ * time; *ms = that time; *clock_mhz = the shader clock the stream ran at (s_memtime cycles over the 100 MHz wall clock, last launch,
+ * mean over CUs); *issue_eff = tflops / (CUs x clock x 128 (f64) / 256 (f32) flops per CU and cycle) -- the last three may be NULL.
+ * A measurement hook like gpk_prof_*: allocates its own 4 KiB of scratch, SYNCHRONISES the stream, not on the product path. */
+int gpk_mfma_peak(int dtype, double min_ms, int waves_per_simd, double* tflops, double* ms, double* clock_mhz, double* issue_eff, void* stream);
+
 /* Development aids.  The RELEASE library (stheno_amd/csrc/libgpk.so) has no tuning knobs: every one of them is a compile-time
  * constant at its measured optimum and gpk_tune() does nothing.  The dev build (stheno_amd/csrc/dev/libgpk.so, -DGPK_DEV_KNOBS;
  * what the native self-test links against and what GPK_DEV=1 makes the Python binding load) keeps them mutable for A/B runs

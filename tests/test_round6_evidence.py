@@ -1,0 +1,53 @@
+"""Round 6 evidence on the MI355X (all ``-m gpu``, through ``libgpk.so``)."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+from stheno_amd import _native, matrix
+
+from .conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+OUT = os.path.join(ROOT, "gpurun_out", "r06")
+
+
+def _note(name, rec):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "achieved.json")
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[name] = rec
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1)
+    print("ACHIEVED", name, json.dumps(rec))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_measured_mfma_peak_is_a_plausible_ceiling(hip_backend, dtype):
+    """``gpk_mfma_peak`` (the peak re-derived on the box): a register-resident MFMA stream on every SIMD cannot beat the
+    nominal peak, and on a healthy MI355X it reaches a good part of it; the clock it reports is a real shader clock."""
+    lib = _native.load()
+    nominal = {"f64": 78.6, "f32": 157.3}[dtype]
+    best = 0.0
+    for waves in (1, 2):
+        tf, ms, mhz, eff = (ctypes.c_double() for _ in range(4))
+        st_ = lib.gpk_mfma_peak(0 if dtype == "f32" else 1, 50.0, waves, ctypes.byref(tf), ctypes.byref(ms), ctypes.byref(mhz), ctypes.byref(eff),
+                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st_ == 0
+        assert ms.value >= 50.0
+        assert 0.3 * nominal < tf.value <= 1.02 * nominal, (dtype, waves, tf.value)
+        assert 500.0 < mhz.value <= 2500.0, mhz.value
+        assert 0.3 < eff.value <= 1.02, eff.value
+        best = max(best, tf.value)
+        _note(f"mfma_peak_{dtype}_{waves}w", {"tflops": tf.value, "ms": ms.value, "shader_clock_mhz": mhz.value, "issue_eff": eff.value})
+    assert lib.gpk_mfma_peak(1, 1.0, 3, ctypes.byref(tf), None, None, None, None) == -3
+    assert lib.gpk_mfma_peak(7, 1.0, 2, ctypes.byref(tf), None, None, None, None) == -1
