@@ -105,6 +105,12 @@ int64_t gpk_dinv_elems(int64_t n);
  * workgroups take the solves and updates of the panel as tasks and wait for each other through flag words in device memory
  * (gpk_potrf.hip, potrf_pipe_kernel; the task list is deadlock-free whatever part of the grid is resident).  A workgroup that
  * waited for seconds gives up and makes all others leave: `info` = -1 then (never observed; the factor is unusable).
+ * BATCHES of at least 64 fp32 matrices whose order is a multiple of 128 (from 512 on; 16-byte aligned, on a stream without a CU
+ * mask) take one launch for the diagonal blocks and ONE mixed-phase launch for everything below them per 128-column step
+ * (gpk_potrf.hip, batch_mix_kernel: panel solves and update tiles of different matrices share the CUs; per-matrix counters in the
+ * next `dinv` slot order them, without fences -- every task of a matrix runs on the XCD the matrix is pinned to).  That placement is
+ * checked on the device: a violation is reported as `info` = -2 for one of the batch's matrices (never observed; the factors are
+ * unusable).  Same arithmetic in the same order per entry as the lockstep launches other batches take: bit-identical factors.
  * Replaces `B.cholesky(B.reg(K))` (LAPACK potrf): implicit under B.logdet / B.iqf_diag at
  * stheno/random.py:274-276, explicit at stheno/model/observations.py:300. */
 int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv,
@@ -338,7 +344,10 @@ int gpk_mfma_peak(int dtype, double min_ms, int waves_per_simd, double* tflops, 
  * third of the CUs); 40 / 41: the look-ahead's update of the next diagonal block is the first segment of the trailing update while
  * that has at least (40) rows and the outer block is at most (41) wide; 42: small products with a lower-triangular A (the leaves of
  * the recursive solve) as pairs of 32-row tiles with equal K per workgroup; 45: batched 128-tile GEMM launches as a 1-D grid with all
- * tiles of a matrix on one XCD.  (Removed in round 4 with the code they selected: 2 / 4 /
+ * tiles of a matrix on one XCD; 53: batched factorisations take the mixed-phase steps (0 = lockstep launches, 1 = fp32, 2 = fp64 too);
+ * 54: ... from this many matrices on; 55: tasks between a matrix's solves and its update tiles in the queue order; 56: bit 0 = update
+ * tiles do not pull their C tile into the L2 before they wait, bit 2 = solve tiles publish behind an agent-scope release; 57: fp32
+ * batches of more matrices than CUs take the diagonal-block kernel compiled for two workgroups per CU.  (Removed in round 4 with the code they selected: 2 / 4 /
  * 13 -- XCD super-tile, row-pair and column-major tile orders -- and 30, the 256-thread diagonal-block kernel of rounds 1-2.)
  * gpk_tune_diag_prof: device buffer (32 int64 per diagonal block, or NULL) for cycle / wall-clock stamps of the diagonal-block
  * kernel and of the pipelined panel's chain and critical tasks (read by `gpk_selftest --diagprof`). */

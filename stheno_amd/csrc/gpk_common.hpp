@@ -76,6 +76,20 @@ struct Traits<float> {
 
 static inline int64_t gpk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// The workgroup barrier in front of a PUBLICATION (a flag / counter another workgroup waits for): every wave's global stores are
+// acknowledged by the L2 before any thread passes it.  __syncthreads() alone does not do that on gfx950 -- its workgroup-scope
+// release compiles to `s_waitcnt vmcnt(63) ... ; s_barrier`, the stores of the other waves may still be in flight when thread 0
+// goes on to its agent-scope release (which waits for thread 0's wave only) and sets the flag.  Round 6 found it with a batched fp64
+// factorisation whose update tiles read a panel row before the solve tile's last stores had landed; the publications of rounds 2-5
+// (pipelined panel, panel step, persistent update's signal, the resident sweep) had the same hole behind a write-back that happened
+// to cover it.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void gpk_barrier_stores_done() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#endif
+
 #define GPK_CHECK_LAUNCH()                                   \
     do {                                                     \
         hipError_t e__ = hipGetLastError();                  \

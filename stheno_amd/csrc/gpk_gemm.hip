@@ -297,7 +297,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
                 gemm_tile<T, TS, true, true, EDGE, 1, NW, false, 1>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr,
                                                                     (r == k.reps - 1) ? pf_c : nullptr, pf_ld, (r == k.reps - 1) ? &p.ctrl[0] : nullptr, &nxt);
             if (p.sig[k.sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
-                __syncthreads();               // every wave's stores of the tile are out (vmcnt drained before the barrier)
+                gpk_barrier_stores_done();     // every wave's stores of the tile are out
                 if (tid == 0) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(PanelStepArgs<T> p) 
     }
     if (cb == 0) {
         gemm_tile<T, TS, true, true, EDGE, NCT, 4, true>(p.trsm, strip, 0, 0, 0, smem);      // (TRIB: inv(L_cc) is lower triangular)
-        __syncthreads();                        // every wave's stores of the strip are out (vmcnt drained before the barrier)
+        gpk_barrier_stores_done();              // every wave's stores of the strip are out
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

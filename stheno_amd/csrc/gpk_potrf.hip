@@ -614,8 +614,12 @@ __device__ __forceinline__ void diag3_block(T* __restrict__ S, T* __restrict__ r
 }
 
 
-template <typename T>
-__global__ __launch_bounds__(D3_THREADS, 2) void potrf_diag3_kernel(DiagArgs<T> p) {
+// WPE: waves per SIMD the kernel is compiled for.  2: one 512-thread workgroup per CU, 189 registers (fp32) -- the latency of ONE block
+// counts (single matrices).  4 (fp32 only: the fp64 block fills the LDS): two workgroups per CU at 128 registers and two dozen spills --
+// batches of more matrices than CUs, where a launch is rounds of blocks (512 matrices: 15.15 -> 15.06 ms per factorisation in lockstep,
+// 14.98 -> 14.65 with the mixed-phase steps; profiles/r06_experiments.md).
+template <typename T, int WPE = 2>
+__global__ __launch_bounds__(D3_THREADS, WPE) void potrf_diag3_kernel(DiagArgs<T> p) {
     __shared__ __attribute__((aligned(16))) T S[D3_LDS_ELEMS];
     const int64_t b = blockIdx.x;
     T* A = p.A + b * p.bstride + p.off * p.ld + p.off;
@@ -710,7 +714,7 @@ __device__ __forceinline__ bool pipe_wait(unsigned* w0, unsigned* w1, unsigned* 
 // all threads: this workgroup's global stores are visible agent-wide before the word changes.  counter == nullptr: *word = v.
 // Otherwise *counter += 1 and, if that made it `full`, *word = v (word may be nullptr: the counter is what consumers poll).
 __device__ __forceinline__ void pipe_publish(unsigned* word, unsigned v, unsigned* counter = nullptr, unsigned full = 0u) {
-    __syncthreads();
+    gpk_barrier_stores_done();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -889,11 +893,179 @@ __global__ __launch_bounds__(D3_THREADS, 2) void potrf_pipe_kernel(PipeArgs<T> p
     if (threadIdx.x == 0 && __hip_atomic_load(p.ctrl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(p.info, -1);
 }
 
-long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
+// ---------------------------------------------------------------------------
+// batch_mix_kernel (round 6) -- the panel solves AND the update of one 128-column step of the batched factorisation in ONE launch in
+// which the two phases MIX.
+//
+// The batched path of rounds 1-5 is batch-wide launches in lockstep: diagonal blocks (latency-bound, one workgroup per matrix), panel
+// solves (half memory-bound: a 128 x 128 tile read, multiplied by the inverted block, written back), update GEMMs (MFMA-bound) -- 47
+// launches per 2048-matrix, and while the chip is in a solve launch its matrix pipes idle (cfg4: the solves are 2.3 of 15.2 ms).  Here
+// everything step `jn` does below its diagonal blocks is one launch of the 128-tile's own workgroups (256 threads, two per CU), ONE
+// TASK EACH, in per-XCD queues: block L is task L / 8 of queue L % 8 -- the dispatcher places block L on XCD L % 8 and starts blocks in
+// index order, so the queue order is the start order and matrix m = queue m % 8 keeps its panels in one L2:
+//
+//   T(m, r)        the panel solve of row tile r below block jn (TRIB tile, in place, against the inverse the diagonal-block launch in
+//                  front of this one left in `dinv`); then cnt[m] += 1 behind a barrier that waits for the tile's stores;
+//   U(m, ti, tj)   one 128 x 128 tile of the update that block column jn now owes the matrix (depth K = 128, 256, ... as the recursive
+//                  halving of potrf_panel has it, or the outer panel's rank-nbo trailing update); pulls its C tile into the L2, waits for
+//                  cnt[m] == all solves of m, multiplies.
+//
+// Queue order: slot s = [the solves of matrix s] [the update tiles of matrix s - lag]: memory-bound solves and MFMA-bound updates of
+// DIFFERENT matrices share every CU at every moment.  Every dependency of a task is a block with a LOWER index, which has started
+// whenever this one has and never waits for a later one: no deadlock whatever part of the grid is resident.
+//
+// NO FENCES between the solves and the updates of a matrix: all of them run on ITS XCD, whose L2 is the point of coherence of its
+// CUs -- a solve tile's stores are in that L2 when the counter moves (write-through L1, counted after the stores were acknowledged),
+// the counter is read past the L1 (agent-scope atomic load), and no CU can hold a stale L1 line of a solved row (it would have had to
+// read the row earlier in this launch: only the workgroup that solves a row reads it unsolved).  Agent-scope release / acquire
+// fences write back / invalidate the XCD's WHOLE L2: one release per solve tile costs 2.4 ms per 512 x 2048^2 factorisation, a
+// release / acquire pair per task 3 ms (profiles/r06_experiments.md).  What this rests on -- every block of a queue on one XCD -- is
+// CHECKED: the first block of a queue records its XCC_ID, every other one compares, a mismatch is reported as info = -2 (never seen;
+// the host keeps streams with a CU mask on the lockstep path).
+//
+// Also built and measured: the same queues served by a RESIDENT grid (one workgroup per slot, tasks from atomic counters, the next
+// tile's input prefetched, claims inside the tile body as in gemm_persist_kernel) -- 14.9-15.0 ms against 14.5 for this kernel and
+// 15.1 for the lockstep launches: a workgroup that goes from one tile to the next must have its own stores acknowledged before it can
+// consume the next tile's loads (one in-order counter per wave), a FRESH workgroup's loads return as they arrive
+// (profiles/r06_batched_resident_task_loop.patch).  The diagonal blocks stay a launch of their own between two of these (512 threads
+// and 189 registers: they do not fit beside the tiles; inlined into a 512-thread task loop they and the 8-wave tile spill) -- which
+// also clears the control words: the first 4 KiB of the dinv slot jn + 1 of every matrix (word 0 = cnt[m]; of matrix 0's: word 16 =
+// abort, words 24..31 = XCC_ID + 1 of the queues).
+// ---------------------------------------------------------------------------
+template <typename T>
+struct BatchStepArgs {
+    T* A;
+    int64_t ld, bstride;
+    int n, batch;
+    T* dinv;
+    int64_t dstride;
+    int* info;
+    int jn;          // the diagonal block whose rows are solved (c = 128 jn); the update starts at row / column c + 128
+    int K;           // depth of the update: panel columns [c + 128 - K, c + 128)
+    int tn, tm;      // 128-column tiles of the updated region; 128-row tiles below block jn (= solves per matrix)
+    int nU;          // update tiles per matrix
+    int lag;
+    int opts;        // development (knob 56): 1 = an update tile does not pull its C tile into the L2 before it waits, 4 = solve tiles publish behind an agent-scope release
+};
 
 template <typename T>
+__device__ __forceinline__ unsigned* batch_ctrl(const BatchStepArgs<T>& p, int m) {
+    return reinterpret_cast<unsigned*>(p.dinv + (int64_t)m * p.dstride + (int64_t)(p.jn + 1) * (GPK_DB * GPK_DB));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void batch_mix_kernel(BatchStepArgs<T> p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * op_bytes(128)];
+    __shared__ int s_ctl[4];
+    const int tid = threadIdx.x;
+    const int L = (int)blockIdx.x, qx = L & 7, q = L >> 3;
+    const int nmx = (p.batch - qx + 7) >> 3;
+    const int P = p.tm + p.nU;
+    if (nmx <= 0 || q >= (nmx + p.lag) * P) return;
+    const int c1 = (p.jn + 1) * GPK_DB;
+    const int slot = q / P, r = q - slot * P;
+    if (tid == 0) {                           // every block of a queue on ONE XCD: what the fence-free protocol rests on
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned* home = batch_ctrl(p, 0) + 24 + qx;
+        const unsigned mine = (xcc & 7u) + 1u;
+        const unsigned seen = atomicCAS(home, 0u, mine);
+        if (seen != 0u && seen != mine) atomicExch(p.info + qx, -2);
+    }
+    GemmArgs<T> g;
+    g.lda = g.ldb = g.ldc = g.ldcin = p.ld;
+    g.sA = g.sB = g.sC = p.bstride;
+    g.sA2 = g.sB2 = g.sC2 = 0;
+    g.lower_only = 0; g.vec_ok = 1; g.tri_k = g.tri_k_lo = g.tri_k_lo_b = g.pair_cols = 0;
+    g.colscale = nullptr; g.colss = nullptr; g.ldss = 0; g.xcd_batch = g.xcd_tiles = 0; g.colmask = 0; g.grp_tiles = 0;
+    g.split_from = INT32_MAX;
+    if (r < p.tm) {
+        if (slot >= nmx) return;
+        const int m = qx + 8 * slot;
+        g.A = p.A + (int64_t)c1 * p.ld + (c1 - GPK_DB); g.C = const_cast<T*>(g.A); g.Cin = g.A;
+        g.B = p.dinv + (int64_t)p.jn * (GPK_DB * GPK_DB); g.ldb = GPK_DB; g.sB = p.dstride;
+        g.M = p.n - c1; g.N = GPK_DB; g.K = GPK_DB;
+        g.alpha = T(1); g.beta_over_alpha = T(0); g.has_beta = 0;
+        g.tiles_m = p.tm; g.tiles_n = 1;
+        gemm_tile<T, 128, true, true, false, 1, 4, true>(g, r, 0, m, 0, smem);
+        gpk_barrier_stores_done();            // every wave's stores of the tile are acknowledged
+        if (tid == 0) {
+            if (p.opts & 4) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __hip_atomic_fetch_add(batch_ctrl(p, m), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const int i = slot - p.lag;
+    if (i < 0 || i >= nmx) return;
+    const int m = qx + 8 * i;
+    const int u = r - p.tm;
+    int ti = u, tj = 0;
+    if (u >= p.tm) {                          // column 0 from the top, then the other columns row by row
+        int rem = u - p.tm;
+        ti = 1;
+        for (;;) {
+            const int cnt = (ti < p.tn - 1) ? ti : p.tn - 1;
+            if (rem < cnt) break;
+            rem -= cnt;
+            ++ti;
+        }
+        tj = 1 + rem;
+    }
+    g.A = p.A + (int64_t)c1 * p.ld + (c1 - p.K); g.B = g.A;
+    g.C = p.A + (int64_t)c1 * p.ld + c1; g.Cin = g.C;
+    g.M = p.n - c1; g.N = p.tn * GPK_DB; g.K = p.K;
+    g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
+    g.tiles_m = p.tm; g.tiles_n = p.tn;
+    if (!(p.opts & 1)) {
+        // the C tile does not depend on the solves: pull it into the L2 while thread 0 looks at the counter (one dword of every 128-byte line)
+        constexpr int LPR = 128 * (int)sizeof(T) / 128;
+        const T* ct = g.Cin + (int64_t)m * p.bstride + (int64_t)ti * GPK_DB * p.ld + (int64_t)tj * GPK_DB;
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 128 * LPR / 256; ++j) {
+            const int id = tid + 256 * j;
+            acc ^= *reinterpret_cast<const int*>(reinterpret_cast<const char*>(ct + (int64_t)(id / LPR) * p.ld) + (id % LPR) * 128);
+        }
+        asm volatile("" ::"v"(acc));
+    }
+    if (tid == 0) {
+        unsigned* cw = batch_ctrl(p, m);
+        unsigned* abort_word = batch_ctrl(p, 0) + 16;
+        unsigned it = 0;
+        int ok = 1;
+        while (__hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.tm) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++it & 255u) == 0 && (it > PIPE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        s_ctl[1] = ok;
+    }
+    __syncthreads();
+    if (s_ctl[1] == 0) {
+        if (tid == 0) atomicExch(p.info + m, -1);
+        return;
+    }
+    gemm_tile<T, 128, true, true, false, 1, 4, false, 1>(g, ti, tj, m, 0, smem);
+}
+
+long long* g_diag_prof = nullptr;   // development aid, set through gpk_tune_diag_prof
+
+GPK_KNOB(int, g_diag_two_per_cu, 1);         // tuning knob (gpk_tune(57, v)): fp32 batches of more matrices than CUs take the 128-register diagonal-block kernel
+template <typename T>
 void launch_diag(const DiagArgs<T>& d, unsigned batch, hipStream_t stream) {
-    hipLaunchKernelGGL((potrf_diag3_kernel<T>), dim3(batch), dim3(D3_THREADS), 0, stream, d);
+    if constexpr (sizeof(T) == 4) {
+        if (g_diag_two_per_cu && batch > 256u) {
+            hipLaunchKernelGGL((potrf_diag3_kernel<T, 4>), dim3(batch), dim3(D3_THREADS), 0, stream, d);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((potrf_diag3_kernel<T, 2>), dim3(batch), dim3(D3_THREADS), 0, stream, d);
 }
 
 template <typename T>
@@ -1116,6 +1288,72 @@ int potrf_panel_any(const PanelCtx<T>& x, int64_t c0, int64_t w) {
 // block that receives cycle-counter stamps of the diag kernel's phases.
 void gpk_set_diag_prof(long long* dev_buf) { g_diag_prof = dev_buf; }
 
+GPK_KNOB(int, g_batch_mixed, 1);             // tuning knob (gpk_tune(53, v)): batches of aligned matrices take the mixed-phase steps (1: fp32 only -- the fp64 kernel, two tile bodies at 256 registers, spills; 2: fp64 too)
+GPK_KNOB(int64_t, g_batch_mixed_min, 64);    // tuning knob (gpk_tune(54, v)): ... from this many matrices on
+GPK_KNOB(int, g_batch_opts, 0);              // tuning knob (gpk_tune(56, v)): development switches of batch_mix_kernel (BatchStepArgs::opts)
+GPK_KNOB(int, g_batch_lag, 96);              // tuning knob (gpk_tune(55, v)): tasks between a matrix's solves and its update tiles, at least (32 / 96 / 256 / 512: 14.70 / 14.51 / 14.60 / 14.69 ms)
+
+// A stream created with a CU mask (hipExtStreamCreateWithCUMask) may not see every XCD, and the mixed-phase steps rest on block L
+// running on XCD L % 8: such streams keep the lockstep launches.  (No mask set / the query fails: every CU.)
+static bool stream_has_all_cus(hipStream_t stream) {
+    uint32_t mask[16];
+    for (int i = 0; i < 16; ++i) mask[i] = 0xffffffffu;
+    if (stream == nullptr || hipExtStreamGetCUMask(stream, 16, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    int set = 0;
+    for (int i = 0; i < 16; ++i) set += __builtin_popcount(mask[i]);
+    return set == 0 || set >= cus;
+}
+
+// The batched factorisation with the solves and the update of every 128-column step in one mixed-phase launch (batch_mix_kernel),
+// the diagonal blocks in a launch of their own in front of it.  Same arithmetic, same order per entry as the lockstep path below:
+// recursive halving inside outer panels of `nbo` columns, rank-nbo trailing updates.
+template <typename T>
+static int potrf_batched_mixed(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv, int64_t dstride, int* info, int nbo,
+                               int info_base, hipStream_t stream) {
+    const int nblk = (int)(n / GPK_DB), npb = nbo / GPK_DB;
+    for (int jn = 0; jn < nblk; ++jn) {
+        const bool below = jn + 1 < nblk;
+        DiagArgs<T> d;
+        d.A = A; d.ld = ld; d.bstride = bstride; d.off = (int64_t)jn * GPK_DB; d.n = (int)n;
+        d.dinv = dinv; d.dinv_bstride = dstride; d.info = info; d.info_base = info_base;
+        d.prof = g_diag_prof;
+        d.zero_next = below ? 1 : 0;          // the control words of the step kernel behind it
+        launch_diag<T>(d, (unsigned)batch, stream);
+        GPK_CHECK_LAUNCH();
+        if (!below) break;
+        BatchStepArgs<T> p;
+        p.A = A; p.ld = ld; p.bstride = bstride; p.n = (int)n; p.batch = (int)batch;
+        p.dinv = dinv; p.dstride = dstride; p.info = info;
+        p.jn = jn;
+        p.tm = nblk - jn - 1;
+        const int jl = jn % npb;                          // block jn inside its outer panel
+        if (jl == npb - 1) {                              // the panel is complete: its rank-nbo update of everything behind it
+            p.K = nbo; p.tn = p.tm;
+        } else {
+            int z = 0;
+            while ((jl >> z) & 1) ++z;                    // trailing ones: the halving level that block closes
+            p.K = GPK_DB << z;
+            p.tn = (p.K / GPK_DB < p.tm) ? p.K / GPK_DB : p.tm;
+        }
+        p.nU = p.tm;
+        for (int ti = 1; ti < p.tm; ++ti) p.nU += (ti < p.tn - 1) ? ti : p.tn - 1;
+        p.opts = g_batch_opts;
+        p.lag = (g_batch_lag + p.tm + p.nU - 1) / (p.tm + p.nU);
+        const int per_xcd = (int)((batch + 7) / 8);
+        if (p.lag > per_xcd) p.lag = per_xcd;
+        if (p.lag < 1) p.lag = 1;
+        const int64_t qlen = (int64_t)(per_xcd + p.lag) * (p.tm + p.nU);
+        hipLaunchKernelGGL((batch_mix_kernel<T>), dim3((unsigned)(8 * qlen)), dim3(256), 0, stream, p);
+        GPK_CHECK_LAUNCH();
+    }
+    return GPK_OK;
+}
+
 template <typename T>
 static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
                        int* info, int nbo, int info_base, hipStream_t stream, int64_t rows = 0) {
@@ -1132,6 +1370,12 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     if (dinv == nullptr && n > GPK_DB) return GPK_ERR_ARG(6);
     const int64_t nblk = gpk_cdiv(n, GPK_DB);
     const int64_t dstride = nblk * GPK_DB * GPK_DB;
+
+    // batches of aligned matrices: one mixed-phase launch per 128-column step instead of lockstep launches per phase
+    if (g_batch_mixed && batch >= g_batch_mixed_min && rows == n && dinv != nullptr && n % GPK_DB == 0 && n >= 4 * GPK_DB && nbo <= n &&
+        (sizeof(T) == 4 || g_batch_mixed >= 2) && n <= 64 * 1024 && stream_has_all_cus(stream) && ld % Traits<T>::VEC == 0 && bstride % Traits<T>::VEC == 0 && (uintptr_t)A % 16 == 0 &&
+        (uintptr_t)dinv % 16 == 0 && ld < GPK_PIPE_LD_MAX && batch <= INT32_MAX / 8)
+        return potrf_batched_mixed<T>(A, n, ld, batch, bstride, dinv, dstride, info, nbo, info_base, stream);
 
     PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream, info_base};
     ctx.rows = rows;
@@ -1299,6 +1543,11 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 47) GPK_KNOB_SET(g_la_agg = (int)value;);
     if (key == 48) GPK_KNOB_SET(g_la_agg_min_rows = value;);
     if (key == 52) GPK_KNOB_SET(g_plain_nbo = value;);
+    if (key == 53) GPK_KNOB_SET(g_batch_mixed = (int)value;);
+    if (key == 54) GPK_KNOB_SET(g_batch_mixed_min = value;);
+    if (key == 55) GPK_KNOB_SET(g_batch_lag = (int)value;);
+    if (key == 56) GPK_KNOB_SET(g_batch_opts = (int)value;);
+    if (key == 57) GPK_KNOB_SET(g_diag_two_per_cu = (int)value;);
     if (key == 38) GPK_KNOB_SET(g_pipe_fill = (int)value;);
     if (key == 39) GPK_KNOB_SET(g_pipe_panel_wgs = (int)value;);
 }

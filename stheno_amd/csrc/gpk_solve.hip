@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void trsv_sweep_kernel(const T* __restrict__ L
     unsigned epoch = 0;
     auto grid_barrier = [&]() -> bool {          // false: give up (abort raised)
         ++epoch;
-        __syncthreads();
+        gpk_barrier_stores_done();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __hip_atomic_fetch_add(&ctrl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

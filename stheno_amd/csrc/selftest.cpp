@@ -515,6 +515,15 @@ static void test_potrf() {
     test_potrf_case<T>(1664, 1, 256, 1, 300, 256);
     test_potrf_case<T>(700, 70, 256, 1, 0, 128);     // larger batch, ragged
     test_potrf_case<T>(512, 64, 128, 2, 0, 128);
+    // the mixed-phase batched steps (batch >= 64, orders that are multiples of 128 from 512 on; fp32 by default, knob 53 = 2: fp64 too):
+    // every halving level, a partial last outer panel, batches that do not divide by the 8 queues
+    gpk_tune(53, 2);
+    test_potrf_case<T>(1024, 64, 256, 1, 0, 128);
+    test_potrf_case<T>(640, 67, 256, 1, 0, 128);
+    test_potrf_case<T>(1536, 65, 512, 1, 0, 128);
+    test_potrf_case<T>(2048, 72, 0, 1, 0, 128);
+    test_potrf_case<T>(1152, 64, 1024, 1, 0, 128);
+    gpk_tune(53, 1);
 }
 
 
@@ -1930,6 +1939,29 @@ int main(int argc, char** argv) {
                 gpk_potrf(GPK_F32, K.p, n, n, (int64_t)n * n, batch, dinv.p, info.p, nbo, nullptr);
                 const float ms = tm.stop();
                 if (rep) printf("BATCHED potrf_f32 512x2048 nbo=%d  %.3f ms  %.2f TFLOP/s\n", nbo, ms, batch * (double)n * n * n / 3.0 / ms * 1e-9);
+            }
+            {   // the mixed-phase steps against the lockstep launches (dev build: knob 53): the same arithmetic in the same order per entry --
+                // the factors of the first and the last 4 matrices, lower triangles, bit by bit
+                std::vector<float> ref[2];
+                for (int mode = 0; mode < 2; ++mode) {
+                    gpk_tune(53, mode);
+                    info.zero();
+                    gpk_kmat(GPK_F32, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, X.p, n, d, (int64_t)n * d, d, K.p, n, (int64_t)n * n, batch, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+                    gpk_potrf(GPK_F32, K.p, n, n, (int64_t)n * n, batch, dinv.p, info.p, nbo, nullptr);
+                    hipDeviceSynchronize();
+                    ref[mode].resize((size_t)8 * n * n);
+                    hipMemcpy(ref[mode].data(), K.p, (size_t)4 * n * n * sizeof(float), hipMemcpyDeviceToHost);
+                    hipMemcpy(ref[mode].data() + (size_t)4 * n * n, K.p + (size_t)(batch - 4) * n * n, (size_t)4 * n * n * sizeof(float), hipMemcpyDeviceToHost);
+                }
+                size_t diff = 0;
+                for (int b = 0; b < 8; ++b)
+                    for (int i = 0; i < n; ++i)
+                        for (int j = 0; j <= i; ++j) {
+                            const size_t at = (size_t)b * n * n + (size_t)i * n + j;
+                            if (memcmp(&ref[0][at], &ref[1][at], sizeof(float)) != 0) ++diff;
+                        }
+                printf("BATCHED mixed-phase steps vs lockstep launches: %zu differing entries in 8 factors (release library: both runs are the default path)\n", diff);
+                gpk_tune(53, 1);
             }
             // the forward solve of one right-hand side per matrix (the quadratic form of the log-density)
             auto hy = randv<float>((size_t)batch * n);

@@ -241,8 +241,9 @@ class Chol:
                 bad = lo if lo < 0 else hi
             self._checked = True
             if bad < 0:
-                self._error = RuntimeError("cholesky: the workgroups of the pipelined panel kernel stopped waiting for each other (gpk.h: "
-                                           "info = -1); the factor is unusable -- please report this")
+                self._error = RuntimeError("cholesky: the workgroups of a multi-workgroup factorisation kernel stopped waiting for each other "
+                                           "(gpk.h: info = -1) or ran on another XCD than their matrix is pinned to (info = -2); info = %d, the "
+                                           "factor is unusable -- please report this" % bad)
             elif bad != 0:
                 self._error = torch.linalg.LinAlgError(
                     f"cholesky: the leading minor of order {bad} is not positive-definite "
