@@ -58,6 +58,9 @@ class _Config:
     #: Pseudo-point bounds (VFE / DTC) with many more observations than inducing points: build the cross-covariance transposed and padded
     #: to whole 128-tiles (``observations.py``), so that the M x N product runs in the GEMM kernel without bounds checks on two k-contiguous operands.
     pseudo_padded_transposed = True
+    #: fp32 kernel matrices that are regularised by the jitter alone (the pseudo-points' ``K_z``) are evaluated in fp64 and rounded
+    #: once up to this order (``observations._kernel_matrix``); 0 disables it
+    fp64_build_max_order = 4096
 
 
 config = _Config()
@@ -207,10 +210,13 @@ class Chol:
         return c
 
     @classmethod
-    def factor_rows_(cls, buf, n):
+    def factor_rows_(cls, buf, n, n_true=None):
         """Factorise the leading ``n x n`` of ``buf`` (rows, n) IN PLACE, the rows under it riding along (``gpk_potrf_rows``): returns
-        ``(chol, zt)`` with ``zt = buf[n:]`` holding ``buf[n:] L^{-T}`` afterwards.  The factor is a view of ``buf``."""
+        ``(chol, zt)`` with ``zt = buf[n:]`` holding ``buf[n:] L^{-T}`` afterwards.  The factor is a view of ``buf``.
+        ``n_true < n``: the matrix is ``diag(A, I)`` with ``A`` of order ``n_true`` (``KernelDense.chol_with_rows`` pads to whole
+        128-blocks): the factor and the rows handed back are the leading-``n_true`` views."""
         be = ops.get_backend()
+        n_true = n if n_true is None else n_true
         nb = sb = 0
         if config.potrf_lookahead_from and n >= config.potrf_lookahead_from:
             nb = config.potrf_lookahead_nb.get(buf.dtype, 0)
@@ -218,10 +224,11 @@ class Chol:
                 nb = 512
             sb = min(nb, config.potrf_lookahead_inv.get(buf.dtype, nb)) if nb else 0
         dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb)
-        c = cls(buf[:n], dinv, info)
+        c = cls(buf[:n_true, :n_true], dinv, info)
         if nb:
             c.lookahead_nb, c.lookahead_sb = nb, sb
-            if sb == _solve_block(n, 1, buf.dtype == torch.float64):
+            # (a padded order: the solves merge their own inverses -- the blocks the look-ahead leaves are those of the padded matrix)
+            if n_true == n and sb == _solve_block(n, 1, buf.dtype == torch.float64):
                 c._dinv_sb[sb] = dnb
         c.rows_under = buf.shape[0] - n        # (which path ran; the tests ask)
         if config.check_info:
@@ -229,7 +236,7 @@ class Chol:
                 _deferred_state.pending.append(c)
             else:
                 c.check()
-        return c, buf[n:]
+        return c, buf[n:, :n_true]
 
     def check(self):
         if self._error is not None:
@@ -664,27 +671,37 @@ class KernelDense(Dense):
         n = self.kernel.num_outputs(self.x)
         # ns <= n: the cached factor is a view of the (n + ns, n) buffer, so the whitened rows live as long as the factor does --
         # at most twice the factor's memory (with ns up to 4 n it was five times)
-        if n != self.x.shape[-2] or n % 128 != 0 or n < config.posterior_rows_from or ns < config.posterior_rows_min_points or ns > n:
+        if n != self.x.shape[-2] or n < config.posterior_rows_from or ns < config.posterior_rows_min_points or ns > n:
             return False
-        if n > 64 * 512:            # (the look-ahead's column groups are a 64-bit mask: at most 64 outer blocks of >= 512 columns)
+        npad = -(-n // 128) * 128      # (round 6: any order -- the native path wants whole 128-blocks, `chol_with_rows` pads with the identity)
+        if npad > 64 * 512:         # (the look-ahead's column groups are a 64-bit mask: at most 64 outer blocks of >= 512 columns)
             return False
-        if not rows_panels_fit(n, ns, self.x.element_size(), bool(config.potrf_lookahead_from) and n >= config.potrf_lookahead_from):
+        if not rows_panels_fit(npad, ns, self.x.element_size(), bool(config.potrf_lookahead_from) and npad >= config.potrf_lookahead_from):
             return False
         return self._noise_parts()[2] is None
 
     def chol_with_rows(self, k_cross, xs):
         """The factor AND ``k_cross(xs, x) L^{-T}`` (ns, n) from one factorisation: the kernel matrix is built in the first ``n`` rows
         of an (n + ns, n) buffer, the cross-covariance under it, and ``gpk_potrf_rows`` carries those rows through its panel solves
-        and trailing updates.  Replaces ``cholesky`` + ``solve(L, K_zx)`` of mlkernels' PosteriorKernel (observations.py:148-168)."""
+        and trailing updates.  Replaces ``cholesky`` + ``solve(L, K_zx)`` of mlkernels' PosteriorKernel (observations.py:148-168).
+
+        An order that is no multiple of 128 (round 6) is PADDED to one: ``diag(K, I)`` in an (npad + ns, npad) buffer, zero columns
+        under the identity -- its factor is ``diag(L, I)``, the rows come out as ``[K* L^{-T}, 0]``; the factor and the whitened rows
+        handed on are the leading-``n`` views of that buffer (every consumer takes a leading dimension)."""
         n, ns = self.x.shape[-2], xs.shape[-2]
-        buf = torch.empty((n + ns, n), dtype=self.x.dtype, device=self.x.device)
+        npad = -(-n // 128) * 128
+        buf = torch.empty((npad + ns, npad), dtype=self.x.dtype, device=self.x.device)
         _, dvec, _ = self._noise_parts()
-        top = self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n])
-        low = k_cross.pairwise(xs, self.x, out=buf[n:])
+        top = self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n, :n])
+        low = k_cross.pairwise(xs, self.x, out=buf[npad:, :n])
         # (a kernel that ignores `out=` would leave the buffer uninitialised and the factorisation would whiten garbage)
-        if top.data_ptr() != buf.data_ptr() or low.data_ptr() != buf[n:].data_ptr():
+        if top.data_ptr() != buf.data_ptr() or low.data_ptr() != buf[npad:].data_ptr():
             raise RuntimeError(f"{type(self.kernel).__name__} / {type(k_cross).__name__}.pairwise did not write into `out`")
-        self._chol, zt = Chol.factor_rows_(buf, n)
+        if npad > n:
+            buf[n:npad].zero_()
+            buf[n:npad, n:npad].fill_diagonal_(1.0)
+            buf[npad:, n:].zero_()
+        self._chol, zt = Chol.factor_rows_(buf, npad, n)
         return self._chol, zt
 
 

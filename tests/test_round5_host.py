@@ -67,7 +67,7 @@ def test_posterior_first_takes_the_rows_path_and_matches_the_oracle(oracle_backe
 
 def test_shapes_outside_the_rows_path_fall_back(oracle_backend):
     rng = np.random.default_rng(2)
-    for n, ns, noise in ((200, 24, 0.1), (256, 4, 0.1), (256, 24, None)):       # not a multiple of 128; too few points; fine (no noise: jitter only)
+    for n, ns, noise in ((200, 24, 0.1), (256, 4, 0.1), (256, 24, None)):       # not a multiple of 128 (round 6: padded, taken); too few points; fine (no noise: jitter only)
         x, xs = rng.standard_normal((n, 1)), rng.standard_normal((ns, 1))
         y = rng.standard_normal((n, 1))
         tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
@@ -80,7 +80,7 @@ def test_shapes_outside_the_rows_path_fall_back(oracle_backend):
             ref_mean, _, ref_var = O.gp_posterior([("eq", 1.0, 1.0)], x, 0.0 if noise is None else noise, y, xs, eps=1e-8, full_cov=False)
         finally:
             B.epsilon = eps0
-        assert (fdd.var.chol().rows_under == ns) == (n % 128 == 0 and ns >= 8)
+        assert (fdd.var.chol().rows_under == ns) == (ns >= 8)
         assert _rel(mean.numpy(), ref_mean) <= 1e-6 and np.max(np.abs(var.numpy().reshape(-1) - ref_var.reshape(-1))) <= 1e-6
 
 
@@ -180,3 +180,25 @@ def test_rows_path_is_refused_where_the_native_panels_have_no_room():
         assert k.can_factor_with_rows(4096) and not k.can_factor_with_rows(4097) and not k.can_factor_with_rows(16384)
     finally:
         ops.set_backend(prev)
+
+
+def test_a_ragged_order_is_padded_into_the_rows_path(oracle_backend):
+    """Round 6: orders that are no multiple of 128 take the factorisation with rows under the matrix too -- ``chol_with_rows`` pads
+    with the identity and hands on views (``tests/test_round5_rows.py`` has the MI355X version)."""
+    rng = np.random.default_rng(5)
+    n, ns, d = 300, 40, 2
+    x, xs = rng.standard_normal((n, d)), rng.standard_normal((ns, d))
+    y = np.cos(x.sum(-1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
+    tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
+    f = st.GP(st.EQ() + st.Linear())
+    fdd = f(tx, 0.1)
+    post = f | (fdd, ty)
+    mean, var = post(txs).marginals()
+    chol = fdd.var.chol()
+    assert chol.rows_under == ns and chol.n == n and chol.l.stride(0) == 384
+    terms = [("eq", 1.0, 1.0), ("linear", 1.0, 1.0)]
+    ref_mean, ref_cov, ref_var = O.gp_posterior(terms, x, 0.1, y, xs, full_cov=True)
+    assert _rel(mean.numpy(), ref_mean) <= 1e-9 and _rel(var.numpy(), ref_var) <= 1e-9
+    assert abs(float(fdd.logpdf(ty)) - O.gp_logpdf(terms, x, 0.1, y)) <= 1e-9 * abs(O.gp_logpdf(terms, x, 0.1, y))
+    f2 = st.GP(st.EQ() + st.Linear())
+    assert _rel(B.dense((f2 | (f2(tx, 0.1), ty))(txs).var).numpy(), ref_cov) <= 1e-9

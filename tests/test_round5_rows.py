@@ -97,8 +97,8 @@ def test_posterior_first_fp32_against_the_oracle():
 
 
 def test_shapes_the_native_path_does_not_take_fall_back():
-    # an order that is no multiple of 128, too few test points, a factor that exists already: the separate solve as before
-    for n, ns in ((2100, 200), (2048, 8)):
+    # too few test points, more test points than observations: the separate solve as before
+    for n, ns in ((2048, 8), (2048, 2304)):
         x, y, xs = _data(n, 2, ns, np.float64, seed=5)
         tx, ty, txs = (torch.as_tensor(a, device=DEV) for a in (x, y, xs))
         f = st.GP(st.EQ())
@@ -107,6 +107,40 @@ def test_shapes_the_native_path_does_not_take_fall_back():
         assert fdd.var.chol().rows_under == 0
         ref_mean, _, ref_var = O.gp_posterior([("eq", 1.0, 1.0)], x, NOISE, y, xs, full_cov=False)
         assert _rel(mean.cpu().numpy(), ref_mean) <= 1e-6 and _rel(var.cpu().numpy(), ref_var) <= 1e-6
+
+
+@pytest.mark.parametrize("n,ns,dtype", [(2100, 200, np.float64), (4001, 77, np.float64), (2177, 2177, np.float32), (11300, 333, np.float64)])
+def test_orders_that_are_no_multiple_of_128_are_padded_into_the_rows_path(n, ns, dtype):
+    """Round 6: ``KernelDense.chol_with_rows`` pads the order to whole 128-blocks with the identity (zero columns
+    under it), the factor and the whitened rows handed on are views of the padded buffer.  Plain panels and the look-ahead; the
+    posterior, the full covariance (the k-contiguous product on strided views) and the log-density that shares the padded factor."""
+    fp64 = dtype == np.float64
+    x, y, xs = _data(n, 3, ns, dtype, seed=11)
+    tx, ty, txs = (torch.as_tensor(a, device=DEV) for a in (x, y, xs))
+    eps0 = B.epsilon
+    try:
+        B.epsilon = 1e-12 if fp64 else 1e-6
+        f = st.GP(st.EQ())
+        fdd = f(tx, NOISE)
+        post = f | (fdd, ty)
+        mean, var = post(txs).marginals()
+        chol = fdd.var.chol()
+        assert chol.rows_under == ns and chol.n == n
+        if n >= 11264:
+            assert chol.lookahead_nb == 1024
+        lp = float(fdd.logpdf(ty))
+        x64, y64, xs64 = (a.astype(np.float64) for a in (x, y, xs))
+        ref_lp = O.gp_logpdf([("eq", 1.0, 1.0)], x64, NOISE, y64, eps=B.epsilon)
+        ref_mean, ref_cov, ref_var = O.gp_posterior([("eq", 1.0, 1.0)], x64, NOISE, y64, xs64, eps=B.epsilon, full_cov=ns <= 400)
+        tol = 1e-6 if fp64 else 1e-3
+        assert abs(lp - ref_lp) <= tol * abs(ref_lp)
+        assert _rel(mean.cpu().numpy(), ref_mean) <= tol and _rel(var.cpu().numpy(), ref_var) <= tol
+        if ns <= 400:
+            f2 = st.GP(st.EQ())
+            cov = B.dense((f2 | (f2(tx, NOISE), ty))(txs).var)
+            assert _rel(cov.cpu().numpy(), ref_cov) <= tol
+    finally:
+        B.epsilon = eps0
 
 
 def test_not_positive_definite_is_reported_through_the_rows_path():
