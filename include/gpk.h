@@ -212,7 +212,7 @@ int gpk_gemm_colscale(int dtype, int a_kmajor, int b_kmajor, int64_t m, int64_t 
  * both problems from a device-side counter: one ramp, one tail):
  *   c[m][n] = cin[m][n] + alpha * sum_k a[m][k] b[n][k]        a: m x k, b: n x k, both row-major
  * `cin` may differ from `c` (out-of-place update).  lower_only: tiles on/below the diagonal only.
- * ctrl: 128 bytes of device scratch (zeroed by the call).  reserve_cus != 0: the kernel leaves one CU per XCD
+ * ctrl: 256 bytes of device scratch (zeroed by the call).  reserve_cus != 0: the kernel leaves one CU per XCD
  * empty while it runs, for work enqueued on another stream (what gpk_potrf_la does for its panel chain).
  * This is the trailing update of gpk_potrf_la, exposed for measurement and reuse. */
 typedef struct {

@@ -132,7 +132,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
 //   C[m][n] = Cin[m][n] + alpha * sum_k A[m][k] B[n][k]     (A: M x K, B: N x K, both k contiguous)
 // lower_only: tiles on/below the diagonal only.  ctrl: GPK_PERSIST_CTRL_WORDS unsigned words of device
 // scratch (zeroed by the launch).  reserve: keep one CU per XCD free of this kernel's workgroups.
-#define GPK_PERSIST_CTRL_WORDS 32
+#define GPK_PERSIST_CTRL_WORDS 64
 // The library's helper stream (one per device, created on first use): masked to one CU per XCD; keys[x] = the
 // HW_ID key (+1) of that CU on XCD x, 0 if nothing is reserved.
 int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]);

@@ -184,6 +184,7 @@ struct PersistArgs {
     unsigned* ctrl;
     int reserve;
     int max_leave;
+    int chunks;               // tasks are claimed in chunks of 64 per XCD (gpk_claim_task): ctrl[8 + x] = XCD x's counter, ctrl[16 + 4 x ..] its slots
     unsigned rkeys[8];
     long long* prof;          // development aid: 8 slots (6 stamps) for each of the first 8 tiles of every workgroup (nullable)
 };
@@ -198,6 +199,12 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
     typedef __attribute__((address_space(3))) volatile int lds_word_t;
     lds_word_t& s_tile = *(lds_word_t*)(uint32_t)(uintptr_t)(smem + TS * 128);
     const int tid = threadIdx.x;
+    unsigned xcc0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc0));
+    xcc0 &= 7u;
+    unsigned* const cl_ctr = p.chunks ? &p.ctrl[8 + xcc0] : &p.ctrl[0];         // what a claim increments (gpk_claim_task)
+    unsigned* const ch_ctr = p.chunks ? &p.ctrl[0] : nullptr;
+    unsigned* const ch_slots = p.chunks ? &p.ctrl[16 + 4 * xcc0] : nullptr;
     if (p.reserve) {
         if (tid == 0) {
             unsigned xcc, hw;
@@ -221,7 +228,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
     // tile drain while the next one starts (a __syncthreads() here waited 20-35 us for them, profiles/r04_gemm_checks_tileprof_1.log).
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto claim_now = [&]() -> int {
-        if (tid == 0) s_tile = (int)atomicAdd(&p.ctrl[0], 1u);
+        if (tid == 0) s_tile = gpk_claim_task(cl_ctr, ch_ctr, ch_slots);
         lds_barrier();
         const int v = __builtin_amdgcn_readfirstlane(s_tile);     // uniform by construction; tell the compiler (scalar loads of the segment)
         lds_barrier();
@@ -295,7 +302,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
 #pragma unroll 1
             for (int r = 0; r < k.reps; ++r)     // ONE call site: a second inlined copy of the tile body costs registers
                 gemm_tile<T, TS, true, true, EDGE, 1, NW, false, 1>(g, k.ti, (k.reps == 2 && r == 0) ? g.tiles_n - 1 - k.tj : k.tj, 0, 0, smem, pr,
-                                                                    (r == k.reps - 1) ? pf_c : nullptr, pf_ld, (r == k.reps - 1) ? &p.ctrl[0] : nullptr, &nxt);
+                                                                    (r == k.reps - 1) ? pf_c : nullptr, pf_ld, (r == k.reps - 1) ? cl_ctr : nullptr, &nxt, ch_ctr, ch_slots);
             if (p.sig[k.sgi]) {                  // somebody outside this launch waits for the tiles of this segment (the look-ahead's next chain)
                 gpk_barrier_stores_done();     // every wave's stores of the tile are out
                 if (tid == 0) {
@@ -305,7 +312,7 @@ __device__ __forceinline__ void persist_body(const PersistArgs<T>& p, char* smem
                 }
             }
         }
-        if (!ok && tid == 0) nxt = (int)atomicAdd(&p.ctrl[0], 1u);      // (no full tile body ran: a quarter tile of the last round, an empty task)
+        if (!ok && tid == 0) nxt = gpk_claim_task(cl_ctr, ch_ctr, ch_slots);      // (no full tile body ran: a quarter tile of the last round, an empty task)
         if (tid == 0) s_tile = nxt;
         lds_barrier();
         t = tn;
@@ -384,6 +391,8 @@ namespace {
 long long* g_tile_prof = nullptr;       // development aid (gpk_tune_tile_prof)
 int64_t g_tile_prof_only = -1;          // tuning knob (gpk_tune(20, v)): stamp only the v-th persistent launch since the knob was set (-1: every one)
 int64_t g_tile_prof_count = 0;
+GPK_KNOB(int, g_persist_chunks, 0);              // tuning knob (gpk_tune(58, v)): the persistent update hands its tiles out in chunks of 64 per XCD (gpk_claim_task)
+GPK_KNOB(int64_t, g_persist_chunks_min, 2048);   // tuning knob (gpk_tune(59, v)): ... from this many tiles on
 GPK_KNOB(int64_t, g_persist_small_below, 512);   // tuning knob (gpk_tune(8, v)): the persistent update takes 64x64 tiles below this many 128-tiles
 int g_cu_count[64] = {0};
 int device_cus() {
@@ -404,6 +413,8 @@ void gpk_set_tile_prof(long long* dev_buf) { g_tile_prof = dev_buf; }
 void gpk_tune_gemm(int key, int64_t value) {
     if (key == 1) GPK_KNOB_SET(g_small_tile_below = value;);
     if (key == 8) GPK_KNOB_SET(g_persist_small_below = value;);
+    if (key == 58) GPK_KNOB_SET(g_persist_chunks = (int)value;);
+    if (key == 59) GPK_KNOB_SET(g_persist_chunks_min = value;);
     if (key == 31) GPK_KNOB_SET(g_split_tail = (int)value;);
     if (key == 36) GPK_KNOB_SET(g_trib = (int)value;);
     if (key == 42) GPK_KNOB_SET(g_trilo_pairs = (int)value;);
@@ -784,6 +795,7 @@ int gpk_gemm_persist_launch(const GpkSeg<T>* segs, int nseg, T alpha, unsigned* 
     pa.ntasks = (int)total;
     pa.split_from = INT32_MAX;
     pa.ctrl = ctrl;
+    pa.chunks = (g_persist_chunks && total >= g_persist_chunks_min) ? 1 : 0;
     pa.prof = nullptr;
     if (g_tile_prof != nullptr) {
         if (g_tile_prof_only < 0 || g_tile_prof_count == g_tile_prof_only) pa.prof = g_tile_prof;

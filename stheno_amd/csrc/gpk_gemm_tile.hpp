@@ -56,6 +56,31 @@ struct GemmArgs {
                       // split_from + 1, ... -- the last, partial round of a launch cut four times finer (see gpk_gemm_launch2)
 };
 
+// ---- task claims of the persistent kernels ------------------------------------
+// Plain: the next index of ONE device-wide counter.  Chained (chain_ctr != nullptr; round 6): `ctr` is the counter of the calling
+// workgroup's XCD, and tasks are handed out in CHUNKS of 64 consecutive indices per XCD -- the workgroup whose claim opens a chunk
+// (local index a multiple of 64) takes the next chunk number from the device-wide counter `chain_ctr` and publishes it in one of four
+// tagged slots of its XCD, the 63 others read it there.  64 consecutive tiles of a trailing update are 8 tile rows x the 8 tile columns
+// of a column group: the 64 workgroups of an XCD then share 16 operand panels instead of holding up to 128 different ones, start
+// together and walk k together, so a k-slice of a panel is fetched into the XCD's L2 once instead of once per tile.
+__device__ __forceinline__ int gpk_claim_task(unsigned* ctr, unsigned* chain_ctr, unsigned* chain_slots) {
+    const unsigned i = atomicAdd(ctr, 1u);
+    if (chain_ctr == nullptr) return (int)i;
+    const unsigned k = i >> 6, want = (k + 1u) & 0xfffu;
+    unsigned* slot = chain_slots + (k & 3u);
+    unsigned v;
+    if ((i & 63u) == 0u) {
+        v = (want << 20) | (atomicAdd(chain_ctr, 1u) & 0xfffffu);
+        __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        do {
+            v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((v >> 20) != want);        // (published right behind the opening claim, which precedes this one)
+    }
+    const unsigned c = v & 0xfffffu;
+    return c >= 0x7ffffu ? 0x7fffffff : (int)(c * 64u + (i & 63u));
+}
+
 // ---- global -> registers ---------------------------------------------------
 // `fast`: (EDGE kernels only) this tile's rows and this k-chunk lie fully inside the operand and
 // 16-byte loads are legal -- interior tiles of a ragged problem take the vector path too.
@@ -155,7 +180,7 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
     return *reinterpret_cast<const T*>(lds + off);
 }
 
-// claim_ctr / claimed (persistent kernel): see the claim below the k loop.
+// claim_ctr / claimed (/ chain_ctr / chain_slots) (persistent kernel): see the claim below the k loop and gpk_claim_task.
 // pf_c / pf_ld (pipelined 128-tile only): first element and leading dimension of the C tile this workgroup will READ NEXT (the
 // persistent kernel knows its next task).  Round 4, from the per-tile time stamps (profiles/r04_gemm_checks_tileprof_1.log): a
 // workgroup waits 20-45 us for the 1024 cache lines of its C tile (HBM misses, a few dozen in flight per CU) before its first
@@ -179,7 +204,8 @@ __device__ __forceinline__ T fragread(const char* lds, int rowbase, int lr, int 
 template <typename T, int TS, bool A_KMAJ, bool B_KMAJ, bool EDGE, int NCT, int NW = 4, bool TRIB = false, int PIPE = GPK_GEMM_PIPE>
 __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, int64_t b, int64_t b2, char* smem,
                                           long long* prof = nullptr, const T* pf_c = nullptr, int64_t pf_ld = 0,
-                                          unsigned* claim_ctr = nullptr, int* claimed = nullptr) {
+                                          unsigned* claim_ctr = nullptr, int* claimed = nullptr,
+                                          unsigned* chain_ctr = nullptr, unsigned* chain_slots = nullptr) {
     if (prof != nullptr && threadIdx.x == 0) prof[0] = wall_clock64();
     typedef typename Traits<T>::acc_t acc_t;
     typedef typename Traits<T>::vec_t vec_t;
@@ -667,7 +693,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs<T>& p, int ti, int tj, 
     }
     // (persistent kernel) thread 0 claims the workgroup's next-but-one task HERE: no load and no store of this wave is outstanding, so
     // waiting for the atomic's result costs one round trip of wave 0 and nothing else
-    if (claim_ctr != nullptr && threadIdx.x == 0) *claimed = (int)atomicAdd(claim_ctr, 1u);
+    if (claim_ctr != nullptr && threadIdx.x == 0) *claimed = gpk_claim_task(claim_ctr, chain_ctr, chain_slots);
     // (in-place use: every global read of this workgroup's rows of A happened above)
     // Fused column statistics / scaling (round 4; `gpk_gemm_colscale`, what SURVEY 8(b) called gpk_syrk_scaled, split where the path
     // needs it): V = L_z^{-1} K_zx leaves this kernel already multiplied by K_n^{-1/2} per column, and the column sums of squares of the

@@ -1290,6 +1290,7 @@ void gpk_set_diag_prof(long long* dev_buf) { g_diag_prof = dev_buf; }
 
 GPK_KNOB(int, g_batch_mixed, 1);             // tuning knob (gpk_tune(53, v)): batches of aligned matrices take the mixed-phase steps (1: fp32 only -- the fp64 kernel, two tile bodies at 256 registers, spills; 2: fp64 too)
 GPK_KNOB(int64_t, g_batch_mixed_min, 64);    // tuning knob (gpk_tune(54, v)): ... from this many matrices on
+GPK_KNOB(int, g_batch_left, 0);              // tuning knob (gpk_tune(60, v)): the mixed-phase steps update left-looking inside an outer panel (see potrf_batched_mixed)
 GPK_KNOB(int, g_batch_opts, 0);              // tuning knob (gpk_tune(56, v)): development switches of batch_mix_kernel (BatchStepArgs::opts)
 GPK_KNOB(int, g_batch_lag, 96);              // tuning knob (gpk_tune(55, v)): tasks between a matrix's solves and its update tiles, at least (32 / 96 / 256 / 512: 14.70 / 14.51 / 14.60 / 14.69 ms)
 
@@ -1334,6 +1335,11 @@ static int potrf_batched_mixed(T* A, int64_t n, int64_t ld, int64_t batch, int64
         const int jl = jn % npb;                          // block jn inside its outer panel
         if (jl == npb - 1) {                              // the panel is complete: its rank-nbo update of everything behind it
             p.K = nbo; p.tn = p.tm;
+        } else if (g_batch_left) {
+            // LEFT-LOOKING inside the outer panel: only the NEXT block column, with every column of the panel solved so far (128 (jl + 1)
+            // deep) -- tm tiles per step instead of the halving's tm / 2 tm - 1 / tm tiles at depths 128 / 256 / 128: the same flops in
+            // fewer, deeper visits of the panel's C tiles (a visit costs ~16 us whatever its depth)
+            p.K = GPK_DB * (jl + 1); p.tn = 1;
         } else {
             int z = 0;
             while ((jl >> z) & 1) ++z;                    // trailing ones: the halving level that block closes
@@ -1547,6 +1553,7 @@ void gpk_tune_potrf(int key, int64_t value) {
     if (key == 54) GPK_KNOB_SET(g_batch_mixed_min = value;);
     if (key == 55) GPK_KNOB_SET(g_batch_lag = (int)value;);
     if (key == 56) GPK_KNOB_SET(g_batch_opts = (int)value;);
+    if (key == 60) GPK_KNOB_SET(g_batch_left = (int)value;);
     if (key == 57) GPK_KNOB_SET(g_diag_two_per_cu = (int)value;);
     if (key == 38) GPK_KNOB_SET(g_pipe_fill = (int)value;);
     if (key == 39) GPK_KNOB_SET(g_pipe_panel_wgs = (int)value;);

@@ -538,7 +538,7 @@ static void test_update2_case(int M0, int N0, int M1, int K, int reserve, int pa
     auto A1 = randv<T>((size_t)M1 * lda1), C1 = randv<T>((size_t)M1 * ldc1);
     std::vector<T> C0((size_t)M0 * ldc0, (T)7);
     Dev<T> dA0(A0.size()), dB0(B0.size()), dCin(Cin.size()), dC0(C0.size()), dA1(A1.size()), dC1(C1.size());
-    Dev<unsigned> ctrl(32);
+    Dev<unsigned> ctrl(64);
     dA0.up(A0); dB0.up(B0); dCin.up(Cin); dC0.up(C0); dA1.up(A1); dC1.up(C1);
     gpk_update_t u[2];
     u[0] = gpk_update_t{M0, N0, K, dA0.p, lda0, dB0.p, ldb0, dCin.p, ldcin, dC0.p, ldc0, 0};
@@ -1053,7 +1053,7 @@ static void perf_la(int nmax) {
     {
         const int n = std::min(15360, nmax - 1024), k = 1024;
         Dev<T> P((size_t)(n + 1024) * k), C((size_t)n * n), Tn((size_t)n * 1024), Cs((size_t)n * 1024);
-        Dev<unsigned> ctrl(32);
+        Dev<unsigned> ctrl(64);
         P.up(randv<T>((size_t)(n + 1024) * k, 0.01)); C.zero(); Cs.zero();
         for (int rep = 0; rep < 2; ++rep) {
             tm.start();
@@ -1273,7 +1273,7 @@ static void la_clock(int n, int nb, int warm = 0) {
     const int d = 8, grid = 512;
     // `warm` big updates enqueued right before every factorisation (no idle in between): what does the load history do to the clock?
     Dev<T> WP(warm ? (size_t)15360 * 1024 : 1), WC(warm ? (size_t)15360 * 15360 : 1);
-    Dev<unsigned> wctrl(32);
+    Dev<unsigned> wctrl(64);
     if (warm) { WP.up(randv<T>((size_t)15360 * 1024, 0.01)); WC.zero(); }
     hipEvent_t ea, eb;
     hipEventCreate(&ea); hipEventCreate(&eb);
@@ -1586,7 +1586,7 @@ static void dispatch_experiment() {
         for (int x = 0; x < 8; ++x) printf(" x%d:%d.%d", x, ((keys[x] - 1) >> 5) & 7, (keys[x] - 1) & 15);
         printf("\n");
     }
-    Dev<unsigned> ctrl(32);
+    Dev<unsigned> ctrl(64);
     Dev<long long> tstart(1);
     const int nprobe = 12;
     for (int cfg = 0; cfg < 6; ++cfg) {
@@ -1626,7 +1626,7 @@ static void dispatch_experiment() {
 static void tile_profile(int k = 1024, int lower = 1, int warm = 0) {
     const int n = 15360, grid = 512;
     Dev<double> P((size_t)n * k), C((size_t)n * n);
-    Dev<unsigned> ctrl(32);
+    Dev<unsigned> ctrl(64);
     Dev<long long> prof((size_t)grid * 8 * 8);
     P.up(randv<double>((size_t)n * k, 0.01)); C.zero();
     Timer tm;
