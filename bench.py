@@ -70,6 +70,7 @@ WORKLOADS = {
 TORCH_DTYPE = {"f64": torch.float64, "f32": torch.float32}
 DEFER_CHECKS = False         # (--deferred-checks: the whole step inside st.deferred_checks(); measured 0.4 ms SLOWER per cfg2 step -- the one host
                              # read moves to the end of the step, where nothing of the next step is queued yet: profiles/r05_experiments.md section 7)
+DRY_RUN_GPS = 16             # (--dry-run-gps: stand-in GPs of the dry run; any number, also one the ranks do not divide)
 ORDER = "posterior-first"    # (--order: which of the step's two API calls comes first -- the same work either way)
 
 
@@ -198,6 +199,8 @@ def _variant_name(code, dtype):
     t = "double" if dtype == "f64" else "float"
     ts = 64 if code & 16 else 128
     edge = "true" if code & 1 else "false"
+    if code >= 160:                  # one mixed-phase step of a batched factorisation (panel solves + update tiles in one launch)
+        return f"batch_mix_kernel<{t}>"
     if code >= 128:                  # the panel solve against a triangular inverse: its own kernel (and its own code since round 4)
         return f"gemm_trib_kernel<{t}, {ts}, {edge}, {2 if ts == 64 else 1}>"
     if code >= 96:
@@ -427,7 +430,7 @@ def _batched_record(device, rank, world, steps, warmup, barrier, use_dist, dry_r
     if dry_run:
         from stheno_amd.dist import shard_bounds, sharded_logpdf
 
-        w = dict(WORKLOADS[name], n=8, b=16)
+        w = dict(WORKLOADS[name], n=8, b=DRY_RUN_GPS)
         lo, hi = shard_bounds(w["b"], world, rank)
         g = torch.Generator(device="cpu").manual_seed(0)
         x = torch.randn(w["b"], w["n"], w["d"], generator=g)[lo:hi].to(device)
@@ -448,7 +451,7 @@ def _batched_record(device, rank, world, steps, warmup, barrier, use_dist, dry_r
         if not dry_run:
             st.B.epsilon = eps0
     assert full.shape == (w["b"],) and bool(torch.isfinite(full).all())
-    rec = {"metric": "batched GP logpdfs/sec (512 x N=2048 D=3 fp32)" if not dry_run else "dry run of the batched path (16 stand-in GPs)",
+    rec = {"metric": "batched GP logpdfs/sec (512 x N=2048 D=3 fp32)" if not dry_run else "dry run of the batched path (%d stand-in GPs)" % w["b"],
            "value": w["b"] * steps / elapsed, "unit": "GPs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong", "dtype": "f32",
            "parallelism": "GPs sharded over %d ranks (contiguous blocks), all-gather of the log-densities" % world,
@@ -479,9 +482,11 @@ def main():
     ap.add_argument("--no-batched-record", action="store_true", help="skip the `batched` sub-record (configs[3] sharded over the ranks)")
     ap.add_argument("--dry-run-dist", action="store_true",
                     help="GPU-less proof of the N-rank path: gloo, a stand-in step, the same launch / barrier / all-gather / JSON code")
+    ap.add_argument("--dry-run-gps", type=int, default=16, help="--dry-run-dist: how many stand-in GPs are sharded over the ranks")
     args = ap.parse_args()
 
-    global DEFER_CHECKS, ORDER
+    global DEFER_CHECKS, ORDER, DRY_RUN_GPS
+    DRY_RUN_GPS = max(1, args.dry_run_gps)
     DEFER_CHECKS = bool(args.deferred_checks)
     ORDER = args.order
     if args.cpu_baseline_full:

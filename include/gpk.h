@@ -313,7 +313,8 @@ int gpk_kmat_vjp_dense(int dtype, const int* kinds, const double* variances, con
  * launch count and ALGORITHMIC flops (2mnk; mnk for a lower-only symmetric update) of the
  * launches of one kernel variant: 16*(64x64-tile kernel) + 8*(f64) + 4*(a_kmajor) + 2*(b_kmajor)
  * + 1*(bounds-checked kernel); + 32 = the persistent update (gemm_persist_kernel), 64 + ... = panel_step_kernel,
- * 96 + ... = gemm_trilo_pair_kernel, 128 + ... = gemm_trib_kernel; or -1 for all.  Not thread-safe; off by default; not used
+ * 96 + ... = gemm_trilo_pair_kernel, 128 + ... = gemm_trib_kernel, 160 (+ 8: f64) = batch_mix_kernel (one mixed-phase step of a batched
+ * factorisation: its panel solves at the TRSM count + its update tiles at the symmetric count); or -1 for all.  Not thread-safe; off by default; not used
  * by the product path. */
 int gpk_prof_start(void);
 int gpk_prof_stop(int variant, double* total_ms, int64_t* launches, double* useful_flops);

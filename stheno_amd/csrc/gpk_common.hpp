@@ -188,6 +188,10 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
 template <typename T>
 int gpk_potrf_rows_launch(T* A, int64_t n, int64_t rows, int64_t ld, T* dinv, int* info, hipStream_t stream);
 
+// measurement hooks (gpk_prof_* in gpk.h) for launches outside gpk_gemm.hip: HIP events around a launch, filed under `variant`
+void* gpk_prof_begin(int variant, double flops, hipStream_t stream);
+void gpk_prof_end(void* slot, hipStream_t stream);
+
 void gpk_tune_gemm(int key, int64_t value);
 void gpk_tune_potrf(int key, int64_t value);
 void gpk_tune_kmat(int key, int64_t value);

@@ -422,6 +422,12 @@ void gpk_tune_gemm(int key, int64_t value) {
     if (key == 20) { g_tile_prof_only = value; g_tile_prof_count = 0; }
 }
 
+// the hooks for launches made outside this file (the mixed-phase batched steps of gpk_potrf.hip); nullptr when the hooks are off
+void* gpk_prof_begin(int variant, double flops, hipStream_t stream) { return g_prof.on ? (void*)g_prof.begin(variant, flops, stream) : nullptr; }
+void gpk_prof_end(void* slot, hipStream_t stream) {
+    if (slot != nullptr) g_prof.end(static_cast<ProfSlot*>(slot), stream);
+}
+
 extern "C" int gpk_prof_start(void) {
     for (auto& s : g_prof.used) g_prof.pool.push_back(s);
     g_prof.used.clear();

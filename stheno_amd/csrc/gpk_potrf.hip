@@ -1354,7 +1354,12 @@ static int potrf_batched_mixed(T* A, int64_t n, int64_t ld, int64_t batch, int64
         if (p.lag > per_xcd) p.lag = per_xcd;
         if (p.lag < 1) p.lag = 1;
         const int64_t qlen = (int64_t)(per_xcd + p.lag) * (p.tm + p.nU);
+        // algorithmic flops of the step: the solves at the TRSM count (128^3 per tile), the update at the symmetric count (a diagonal tile half)
+        const int ndiag = p.tn < p.tm ? p.tn : p.tm;
+        const double fl = (double)batch * ((double)p.tm * GPK_DB * GPK_DB * GPK_DB + (2.0 * (p.nU - ndiag) + ndiag) * GPK_DB * GPK_DB * (double)p.K);
+        void* slot = gpk_prof_begin(160 + (sizeof(T) == 8 ? 8 : 0), fl, stream);
         hipLaunchKernelGGL((batch_mix_kernel<T>), dim3((unsigned)(8 * qlen)), dim3(256), 0, stream, p);
+        gpk_prof_end(slot, stream);
         GPK_CHECK_LAUNCH();
     }
     return GPK_OK;

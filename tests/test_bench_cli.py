@@ -33,6 +33,16 @@ def test_gpus_flag_spawns_that_many_ranks(n):
     assert (b["allgather_us"] is not None) == (16 % n == 0)      # (the stand-in batch of 16 splits evenly over 2 ranks, raggedly over 3)
 
 
+def test_eight_ranks_with_a_batch_they_do_not_divide():
+    """The shape of the first real 8-GPU run: eight ranks, a batch that is no multiple of eight -- shards of 3 and 2
+    GPs, the padded all-gather of ``dist.sharded_logpdf``, one JSON line."""
+    out = _run("--gpus", "8", "--dry-run-dist", "--dry-run-gps", "20", "--steps", "2", "--warmup", "1")
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and out["world_size"] == 8 and out["backend"] == "gloo"
+    b = out["batched"]
+    assert b["n_gpus"] == 8 and b["value"] > 0 and b["allgather_us"] is None      # (the timed all-gather is the even-split one)
+    assert "20 stand-in GPs" in b["metric"]
+
+
 def test_one_rank_dry_run_needs_no_process_group():
     out = _run("--dry-run-dist", "--steps", "2", "--warmup", "0")
     assert out["n_gpus"] == 1 and out["world_size"] == 0 and out["batched"]["allgather_us"] is None
