@@ -549,6 +549,20 @@ def main():
     step = make_step(name, w, tensors)
     elapsed = _timed(step, args.steps, args.warmup, barrier, use_dist, device)
 
+    # -- the OTHER call order of the same step, a few steps (the default order is the one the rows-under-the-matrix path
+    #    accelerates; the record carries both so that rounds stay comparable) --
+    other_order = None
+    if name in ("dense_f64", "sum_f32"):
+        first = ORDER
+        ORDER = "logpdf-first" if first == "posterior-first" else "posterior-first"
+        try:
+            k_other = max(2, min(args.steps, 5))
+            el = _timed(step, k_other, 1, barrier, use_dist, device)
+            other_order = {"call_order": ORDER, "steps": k_other, "ms_per_step": 1e3 * el / k_other,
+                           "value": k_other * (world if name != "batched_f32" else 1) / el}
+        finally:
+            ORDER = first
+
     # -- live roofline of the dominant kernel: extra untimed steps under HIP-event hooks --
     roofline = None
     lib = _native.load()
@@ -631,6 +645,8 @@ def main():
             "rccl_world_size": (dist.get_world_size() if use_dist else 0),
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.n) else cpu_baseline(name),
         }
+        if other_order is not None:
+            out["other_call_order"] = other_order
         if allgather is not None:
             out["allgather_us"] = allgather
         if batched is not None:

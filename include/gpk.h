@@ -250,6 +250,13 @@ int gpk_colreduce(int dtype, const void* v, int64_t rows, int64_t cols, int64_t 
                   const void* w, int64_t sw, void* out_dot, void* out_ss, void* ws, int64_t batch,
                   void* stream);
 
+/* out[i][j] = sum_s parts[s][i][j] for j <= i: the partial products of a SPLIT-K symmetric update (`nparts` n x n matrices, `sp`
+ * elements apart, of which only the lower tiles were written -- gpk_gemm with GPK_GEMM_LOWER over a batch of k-slices) added up in a
+ * fixed order, lower triangle only (entries above the diagonal of `out` are unspecified).  The pseudo-point path's
+ * `V K_n^{-1} V^T` (observations.py:322) with its 200 000-long contraction cut into 25 slices: replaces a zero fill of the 25 partial
+ * matrices and a torch reduction over all of them. */
+int gpk_sum_lower(int dtype, const void* parts, int64_t nparts, int64_t n, int64_t ldp, int64_t sp, void* out, int64_t ldo, void* stream);
+
 /* Zero the strict upper triangle (clean Cholesky factor for `B.cholesky` consumers). */
 int gpk_tril(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* stream);
 

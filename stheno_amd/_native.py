@@ -106,6 +106,7 @@ SIGNATURES = {
          _c_ptr, _c_ptr, _c_i64, _c_ptr],
     ),
     "gpk_mfma_peak": (_c_int, [_c_int, _c_dbl, _c_int, _p_dbl, _p_dbl, _p_dbl, _p_dbl, _c_ptr]),
+    "gpk_sum_lower": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_ptr]),
     "gpk_prof_start": (_c_int, []),
     "gpk_prof_stop": (_c_int, [_c_int, _p_dbl, ctypes.POINTER(ctypes.c_int64), _p_dbl]),
     "gpk_copy2d": (

@@ -177,6 +177,10 @@ int gpk_tril(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batc
     D1(dtype, gpk_tril_launch<T>((T*)a, n, ld, sa, batch, (hipStream_t)stream));
 }
 
+int gpk_sum_lower(int dtype, const void* parts, int64_t nparts, int64_t n, int64_t ldp, int64_t sp, void* out, int64_t ldo, void* stream) {
+    D1(dtype, gpk_sum_lower_launch<T>((const T*)parts, nparts, n, ldp, sp, (T*)out, ldo, (hipStream_t)stream));
+}
+
 int gpk_add_diag(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, double s, const void* v,
                  int64_t sv, int64_t batch, void* stream) {
     D1(dtype, gpk_add_diag_launch<T>((T*)a, n, ld, sa, (T)s, (const T*)v, sv, batch, (hipStream_t)stream));

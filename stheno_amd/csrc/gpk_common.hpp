@@ -229,6 +229,8 @@ int gpk_rowreduce_launch(const T* Z, int64_t rows, int64_t n, int64_t ld, const 
 template <typename T>
 int gpk_tril_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipStream_t stream);
 template <typename T>
+int gpk_sum_lower_launch(const T* parts, int64_t nparts, int64_t n, int64_t ldp, int64_t sP, T* out, int64_t ldo, hipStream_t stream);
+template <typename T>
 int gpk_add_diag_launch(T* A, int64_t n, int64_t ld, int64_t sA, T s, const T* v, int64_t sv,
                         int64_t batch, hipStream_t stream);
 template <typename T>

@@ -112,6 +112,45 @@ __global__ __launch_bounds__(256) void tril_kernel(T* __restrict__ A, int64_t n,
     }
 }
 
+// out[i][j] = sum_s parts[s][i][j] over the tiles on / below the diagonal (the partial products of a split-K symmetric update:
+// only their lower tiles were ever written); fixed summation order s = 0, 1, ...; 16-byte loads when everything is aligned.
+template <typename T>
+__global__ __launch_bounds__(256) void sum_lower_kernel(const T* __restrict__ parts, int S, int64_t n, int64_t ldp, int64_t sP,
+                                                        T* __restrict__ out, int64_t ldo, int vec_ok) {
+    typedef typename Traits<T>::vec_t vec_t;
+    constexpr int VEC = Traits<T>::VEC;
+    const int64_t r0 = (int64_t)blockIdx.y * 16, c0 = (int64_t)blockIdx.x * (256 * VEC);
+    if (c0 > r0 + 15) return;                 // the block of 16 rows x 256 VEC columns lies above the diagonal
+    const int64_t c = c0 + (int64_t)threadIdx.x * VEC;
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = r0 + i;
+        if (r >= n || c > r) continue;        // (whole vectors up to the one holding the diagonal: a few entries above it are written too -- with the sums of what the products wrote there or left there, never read as part of a lower triangle)
+        if ((vec_ok & 1) && c + VEC <= n) {
+            vec_t acc = *reinterpret_cast<const vec_t*>(parts + r * ldp + c);
+            for (int s = 1; s < S; ++s) {
+                const vec_t v = *reinterpret_cast<const vec_t*>(parts + (int64_t)s * sP + r * ldp + c);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+            }
+            // only the entries on / below the diagonal (vec_ok bit 1: `out` takes 16-byte stores)
+            if ((vec_ok & 2) && c + VEC - 1 <= r) {
+                *reinterpret_cast<vec_t*>(out + r * ldo + c) = acc;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (c + e <= r) out[r * ldo + c + e] = acc[e];
+            }
+        } else {
+            for (int e = 0; e < VEC; ++e) {
+                if (c + e >= n || c + e > r) continue;
+                T acc = parts[r * ldp + c + e];
+                for (int s = 1; s < S; ++s) acc += parts[(int64_t)s * sP + r * ldp + c + e];
+                out[r * ldo + c + e] = acc;
+            }
+        }
+    }
+}
+
 // A[i][i] += s + (v ? v[i] : 0)
 template <typename T>
 __global__ void add_diag_kernel(T* __restrict__ A, int64_t n, int64_t ld, int64_t sA, T s,
@@ -330,6 +369,18 @@ int gpk_tril_launch(T* A, int64_t n, int64_t ld, int64_t sA, int64_t batch, hipS
 }
 
 template <typename T>
+int gpk_sum_lower_launch(const T* parts, int64_t nparts, int64_t n, int64_t ldp, int64_t sP, T* out, int64_t ldo, hipStream_t stream) {
+    if (n <= 0 || nparts <= 0) return GPK_OK;
+    if (nparts > INT32_MAX) return GPK_ERR_ARG(3);
+    constexpr int VEC = Traits<T>::VEC;
+    const int vec_ok = ((((uintptr_t)parts % 16 == 0) && (ldp % VEC == 0) && (sP % VEC == 0)) ? 1 : 0) | ((((uintptr_t)out % 16 == 0) && (ldo % VEC == 0)) ? 2 : 0);
+    dim3 g((unsigned)gpk_cdiv(n, 256 * VEC), (unsigned)gpk_cdiv(n, 16));
+    hipLaunchKernelGGL((sum_lower_kernel<T>), g, dim3(256), 0, stream, parts, (int)nparts, n, ldp, sP, out, ldo, vec_ok);
+    GPK_CHECK_LAUNCH();
+    return GPK_OK;
+}
+
+template <typename T>
 int gpk_add_diag_launch(T* A, int64_t n, int64_t ld, int64_t sA, T s, const T* v, int64_t sv,
                         int64_t batch, hipStream_t stream) {
     if (n <= 0 || batch <= 0) return GPK_OK;
@@ -367,6 +418,7 @@ int gpk_set_identity_launch(T* dst, int64_t n, int64_t ld, int64_t sd, int64_t b
     template int gpk_colreduce_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,     \
                                          int64_t, T*, T*, T*, int64_t, hipStream_t);                 \
     template int gpk_tril_launch<T>(T*, int64_t, int64_t, int64_t, int64_t, hipStream_t);            \
+    template int gpk_sum_lower_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, T*, int64_t, hipStream_t); \
     template int gpk_add_diag_launch<T>(T*, int64_t, int64_t, int64_t, T, const T*, int64_t, int64_t, \
                                         hipStream_t);                                                \
     template int gpk_copy2d_launch<T>(const T*, int64_t, int64_t, T*, int64_t, int64_t, int64_t,     \

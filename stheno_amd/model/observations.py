@@ -72,9 +72,11 @@ def _syrk_lower(be, v, out):
         # then add the partial products (deterministic, unlike atomics).
         # (S, M, N/S) with strides (N/S, ld, 1); ld > N when v is the leading columns of a padded buffer
         vs = v.as_strided((splits, m, n_obs // splits), (n_obs // splits, v.stride(0), 1), v.storage_offset())
-        parts = torch.zeros((splits, m, m), dtype=v.dtype, device=v.device)
+        # (round 6: `parts` is NOT zero-filled -- 1.7 GB of stores at cfg5 -- and the partial products are added up over their lower
+        # triangles only, natively (`gpk_sum_lower`); rounds 1-5 zero-filled it and summed all of it with a torch reduction)
+        parts = torch.empty((splits, m, m), dtype=v.dtype, device=v.device)
         be.gemm(vs, vs, a_kmajor=True, b_kmajor=True, out=parts, lower_only=True)
-        out.copy_(parts.sum(0))
+        be.sum_lower(parts, out)
     else:
         be.gemm(v, v, a_kmajor=True, b_kmajor=True, alpha=1.0, beta=0.0, out=out, lower_only=True)
     return out

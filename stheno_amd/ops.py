@@ -518,6 +518,19 @@ class HipBackend:
         return a
 
     @_on_operand_device
+    def sum_lower(self, parts, out):
+        """``out[i, j] = sum_s parts[s, i, j]`` for ``j <= i`` (``gpk_sum_lower``): the partial products of a split-K symmetric update,
+        of which only the lower tiles were written, added up in a fixed order.  Entries above the diagonal of ``out`` are unspecified."""
+        if parts.dim() != 3 or out.dim() != 2 or parts.shape[1] != parts.shape[2] or tuple(out.shape) != tuple(parts.shape[1:]):
+            raise ValueError("sum_lower takes (S, n, n) partial products and an (n, n) output")
+        if parts.stride(-1) != 1 or out.stride(-1) != 1:
+            raise ValueError("sum_lower: unit inner strides")
+        self._check(parts, out)
+        self._st(self.lib.gpk_sum_lower(_dtype_id(out), self._ptr(parts), parts.shape[0], out.shape[0], parts.stride(1), parts.stride(0),
+                                        self._ptr(out), out.stride(0), self._stream()), "gpk_sum_lower")
+        return out
+
+    @_on_operand_device
     def symmetrize_(self, a):
         a3, _ = _as3_out(a)
         self._check(a3)

@@ -225,6 +225,10 @@ class OracleBackend:
         a.copy_(torch.tril(a))
         return a
 
+    def sum_lower(self, parts, out):
+        out.copy_(torch.tril(parts.sum(0)))
+        return out
+
     def symmetrize_(self, a):
         a.copy_(torch.tril(a) + torch.tril(a, -1).transpose(-1, -2))
         return a

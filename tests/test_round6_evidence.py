@@ -51,3 +51,30 @@ def test_measured_mfma_peak_is_a_plausible_ceiling(hip_backend, dtype):
         _note(f"mfma_peak_{dtype}_{waves}w", {"tflops": tf.value, "ms": ms.value, "shader_clock_mhz": mhz.value, "issue_eff": eff.value})
     assert lib.gpk_mfma_peak(1, 1.0, 3, ctypes.byref(tf), None, None, None, None) == -3
     assert lib.gpk_mfma_peak(7, 1.0, 2, ctypes.byref(tf), None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,S,pad", [(300, 5, 0), (512, 25, 1), (1000, 3, 4), (64, 1, 0)])
+def test_sum_of_split_k_parts_over_the_lower_triangle(hip_backend, dtype, n, S, pad):
+    """``gpk_sum_lower``: the partial products of the pseudo-point path's split-K SYRK (observations.py:322) added up natively, lower
+    triangle only, into a strided view (the statistics buffer has one column more than the matrix); nothing above the diagonal of a
+    row's last vector is written, what lies above the diagonal in the parts is never read as part of the result."""
+    g = torch.Generator(device="cpu").manual_seed(n + S)
+    parts = torch.randn(S, n, n, generator=g, dtype=torch.float64).to(dtype).cuda()
+    ref = torch.tril(parts.to(torch.float64).sum(0))
+    parts_nan = parts.clone()
+    iu = torch.triu_indices(n, n, 128 * ((0 + 127) // 128) + 128)      # strictly above the diagonal TILES: never read
+    if iu.numel():
+        parts_nan[:, iu[0], iu[1]] = float("nan")
+    buf = torch.full((n, n + pad), 7.0, dtype=dtype, device="cuda")
+    out = buf[:, :n]
+    hip_backend.sum_lower(parts_nan, out)
+    got = torch.tril(out).to(torch.float64)
+    tol = 1e-13 if dtype == torch.float64 else 1e-5
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= tol * float(ref.abs().max())
+    if pad:
+        assert float(buf[:, n:].min()) == 7.0 and float(buf[:, n:].max()) == 7.0
+    # far above the diagonal nothing was touched
+    if n > 300:
+        assert float(out[0, 300:].min()) == 7.0
