@@ -1297,17 +1297,23 @@ GPK_KNOB(int, g_batch_lag, 96);              // tuning knob (gpk_tune(55, v)): t
 // A stream created with a CU mask (hipExtStreamCreateWithCUMask) may not see every XCD, and the mixed-phase steps rest on block L
 // running on XCD L % 8: such streams keep the lockstep launches.  (No mask set / the query fails: every CU.)
 static bool stream_has_all_cus(hipStream_t stream) {
-    uint32_t mask[16];
-    for (int i = 0; i < 16; ++i) mask[i] = 0xffffffffu;
-    if (stream == nullptr || hipExtStreamGetCUMask(stream, 16, mask) != hipSuccess) {
-        (void)hipGetLastError();
-        return true;
-    }
+    if (stream == nullptr) return true;                 // (the legacy default stream carries no mask)
     int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1 ||
+        cus > 32 * 32)
+        return false;
+    // (the runtime fills ceil(CUs / 32) words and refuses a shorter array; an unmasked stream reports all ones: measured on MI355X,
+    // scripts/dev_probe_cu_mask.py)
+    const uint32_t words = (uint32_t)((cus + 31) / 32);
+    uint32_t mask[32];
+    for (uint32_t i = 0; i < 32; ++i) mask[i] = 0u;
+    if (hipExtStreamGetCUMask(stream, words, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;                                    // nothing vouches for the placement: the lockstep launches
+    }
     int set = 0;
-    for (int i = 0; i < 16; ++i) set += __builtin_popcount(mask[i]);
-    return set == 0 || set >= cus;
+    for (uint32_t i = 0; i < words; ++i) set += __builtin_popcount(mask[i]);
+    return set >= cus;
 }
 
 // The batched factorisation with the solves and the update of every 128-column step in one mixed-phase launch (batch_mix_kernel),

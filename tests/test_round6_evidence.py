@@ -78,3 +78,43 @@ def test_sum_of_split_k_parts_over_the_lower_triangle(hip_backend, dtype, n, S, 
     # far above the diagonal nothing was touched
     if n > 300:
         assert float(out[0, 300:].min()) == 7.0
+
+
+def test_batched_factorisation_on_a_cu_masked_stream_keeps_to_the_lockstep_launches(hip_backend):
+    """The mixed-phase batched steps rest on block L of a launch running on XCD L % 8 (all tasks of a matrix on one XCD: no fences).  A
+    stream with a CU mask may not see every XCD: ``potrf_plain`` asks the runtime for the stream's mask and keeps such streams on the
+    lockstep launches.  Here: 72 fp32 matrices of order 1024 on a stream confined to the first 32 CU-mask bits, against the default
+    stream -- the same factors bit for bit (both paths run the same arithmetic in the same order), ``info`` clean."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = ctypes.c_void_p()
+    mask = (ctypes.c_uint32 * 8)(0xffffffff, 0, 0, 0, 0, 0, 0, 0)
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), 8, mask)
+    if rc != 0:
+        pytest.skip("the runtime refuses CU-masked streams here")
+    try:
+        g = torch.Generator(device="cpu").manual_seed(3)
+        x = torch.randn(72, 1024, 3, generator=g, dtype=torch.float32).cuda()
+        k = hip_backend.kmat(st.ops.KTerms([("eq", 1.0, 1.0)]), x, None, lower=True, diag_add=0.1)
+        a0, a1 = k.clone(), k.clone()
+        lib = _native.load()
+
+        def mixed_launches():
+            ms, nl, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            lib.gpk_prof_stop(160, ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(fl))
+            return nl.value
+
+        lib.gpk_prof_start()
+        dinv0, info0 = hip_backend.potrf_(a0)
+        torch.cuda.synchronize()
+        assert mixed_launches() == 1024 // 128 - 1          # the default stream: one mixed-phase launch per step below the last block
+        ext = torch.cuda.ExternalStream(stream.value)
+        lib.gpk_prof_start()
+        with torch.cuda.stream(ext):
+            dinv1, info1 = hip_backend.potrf_(a1)
+        ext.synchronize()
+        assert mixed_launches() == 0                         # the masked stream: none
+        assert int(info0.abs().max()) == 0 and int(info1.abs().max()) == 0
+        assert torch.equal(torch.tril(a0), torch.tril(a1)) and torch.equal(dinv0, dinv1)
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(stream)
