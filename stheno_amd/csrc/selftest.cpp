@@ -1918,11 +1918,51 @@ static void perf_trsv(int n, std::vector<int> sbs) {
     }
 }
 
+// XOR of every 32-bit word of the lower triangles of `batch` n x n fp32 matrices: an order-independent fingerprint of ALL factors of a
+// batched factorisation (--batched-stress)
+__global__ void xor_lower_kernel(const unsigned* a, int n, long long per, unsigned* out) {
+    const long long b = blockIdx.y;
+    const int row = blockIdx.x;
+    unsigned v = 0;
+    for (int c = threadIdx.x; c <= row; c += blockDim.x) v ^= a[b * per + (long long)row * n + c] * (unsigned)(2654435761u + row + 7 * c);
+    for (int off = 32; off > 0; off >>= 1) v ^= __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) atomicXor(out, v);
+}
+
 int main(int argc, char** argv) {
     bool do_perf = false, only_perf = false;
     for (int i = 1; i + 2 < argc; ++i)     // --set KEY VALUE: tuning knobs (gpk_debug_set)
         if (!strcmp(argv[i], "--set")) gpk_tune(atoi(argv[i + 1]), atoll(argv[i + 2]));
     for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--batched-stress") && i + 1 < argc) {   // REPS runs of the mixed-phase batched factorisation against ONE lockstep run: every factor, bit for bit
+            const int reps = atoi(argv[i + 1]);
+            const int n = 2048, d = 3, batch = 512;
+            auto hx = randv<float>((size_t)batch * n * d);
+            Dev<float> X(hx.size()), K((size_t)batch * n * n), dinv((size_t)batch * gpk_dinv_elems(n));
+            Dev<int> info(batch);
+            Dev<unsigned> fp(1);
+            X.up(hx);
+            int kind = GPK_K_EQ; double var = 1.0, il = 1.0;
+            auto run = [&](int mode) -> unsigned {
+                gpk_tune(53, mode);
+                info.zero();
+                fp.zero();
+                gpk_kmat(GPK_F32, &kind, &var, &il, 1, X.p, n, d, (int64_t)n * d, X.p, n, d, (int64_t)n * d, d, K.p, n, (int64_t)n * n, batch, 1, 1, 0.1, nullptr, 0, 0, nullptr);
+                gpk_potrf(GPK_F32, K.p, n, n, (int64_t)n * n, batch, dinv.p, info.p, 0, nullptr);
+                hipLaunchKernelGGL(xor_lower_kernel, dim3(n, batch), dim3(256), 0, nullptr, reinterpret_cast<const unsigned*>(K.p), n, (long long)n * n, fp.p);
+                unsigned h = 0;
+                hipMemcpy(&h, fp.p, sizeof(h), hipMemcpyDeviceToHost);
+                std::vector<int> inf(batch);
+                hipMemcpy(inf.data(), info.p, sizeof(int) * batch, hipMemcpyDeviceToHost);
+                for (int b = 0; b < batch; ++b) if (inf[b] != 0) { printf("info[%d] = %d\n", b, inf[b]); h ^= 0xdeadu; }
+                return h;
+            };
+            const unsigned ref = run(0);
+            int bad = 0;
+            for (int r = 0; r < reps; ++r) bad += run(1) != ref;
+            printf("BATCHED-STRESS %d mixed-phase factorisations of 512 x 2048^2 against the lockstep one (fingerprint %08x of every lower triangle): %d differ\n", reps, ref, bad);
+            return bad ? 1 : 0;
+        }
         if (!strcmp(argv[i], "--batched") && i + 1 < argc) {   // 512 x 2048 f32 potrf with outer block NBO
             const int nbo = atoi(argv[i + 1]);
             const int n = 2048, d = 3, batch = 512;
