@@ -964,14 +964,14 @@ __global__ __launch_bounds__(256, 2) void batch_mix_kernel(BatchStepArgs<T> p) {
     if (nmx <= 0 || q >= (nmx + p.lag) * P) return;
     const int c1 = (p.jn + 1) * GPK_DB;
     const int slot = q / P, r = q - slot * P;
-    if (tid == 0) {                           // every block of a queue on ONE XCD: what the fence-free protocol rests on
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned* home = batch_ctrl(p, 0) + 24 + qx;
-        const unsigned mine = (xcc & 7u) + 1u;
-        const unsigned seen = atomicCAS(home, 0u, mine);
-        if (seen != 0u && seen != mine) atomicExch(p.info + qx, -2);
-    }
+    // Every block of a queue on ONE XCD is what the fence-free protocol rests on: each block ORs the bit of the XCD it runs on into the
+    // queue's word (fire and forget: no block waits for it at its start), the solve tiles look at the word when they publish -- more than
+    // one bit = info -2.  (A first version did a compare-and-swap with a returned value at the top of every block: ~2 us of exposed
+    // latency per tile.)
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned* const home = batch_ctrl(p, 0) + 24 + qx;
+    const unsigned mybit = 1u << (xcc & 7u);
     GemmArgs<T> g;
     g.lda = g.ldb = g.ldc = g.ldcin = p.ld;
     g.sA = g.sB = g.sC = p.bstride;
@@ -995,6 +995,8 @@ __global__ __launch_bounds__(256, 2) void batch_mix_kernel(BatchStepArgs<T> p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __hip_atomic_fetch_add(batch_ctrl(p, m), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned seen = __hip_atomic_fetch_or(home, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | mybit;
+            if (seen & (seen - 1u)) atomicExch(p.info + qx, -2);
         }
         return;
     }
@@ -1019,6 +1021,12 @@ __global__ __launch_bounds__(256, 2) void batch_mix_kernel(BatchStepArgs<T> p) {
     g.M = p.n - c1; g.N = p.tn * GPK_DB; g.K = p.K;
     g.alpha = T(-1); g.beta_over_alpha = T(-1); g.has_beta = 1;
     g.tiles_m = p.tm; g.tiles_n = p.tn;
+    unsigned first_look = 0u;
+    if (tid == 0) {
+        // (the counter is asked for FIRST: loads return in order, behind the C lines it would wait for them too)
+        first_look = __hip_atomic_load(batch_ctrl(p, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(home, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (result unused: no wait)
+    }
     if (!(p.opts & 1)) {
         // the C tile does not depend on the solves: pull it into the L2 while thread 0 looks at the counter (one dword of every 128-byte line)
         constexpr int LPR = 128 * (int)sizeof(T) / 128;
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void batch_mix_kernel(BatchStepArgs<T> p) {
         unsigned* abort_word = batch_ctrl(p, 0) + 16;
         unsigned it = 0;
         int ok = 1;
-        while (__hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.tm) {
+        while (first_look != (unsigned)p.tm && __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)p.tm) {
             __builtin_amdgcn_s_sleep(2);
             if ((++it & 255u) == 0 && (it > PIPE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                 __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
