@@ -131,3 +131,35 @@ def test_mixed_phase_batched_factorisation_reproduces_the_lockstep_factors_every
         pytest.skip("native self-test not built")
     r = subprocess.run([exe, "--batched-stress", "40"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and ": 0 differ" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+
+
+@pytest.mark.parametrize("b,n", [(64, 512), (70, 640), (96, 1024)])
+def test_mixed_phase_batches_give_the_lockstep_factors_bit_for_bit(hip_backend, b, n):
+    """The public path: a batch of at least 64 fp32 GPs of an order that is a multiple of 128 is factorised by the mixed-phase steps,
+    the same GPs in two batches of fewer than 64 by the lockstep launches -- the same arithmetic in the same order per entry, so the
+    FACTORS agree bit for bit; three log-densities against the oracle at 1e-3 (batched semantics: ``stheno/random.py:261,274``,
+    ``tests/model/test_cases.py:134-155``)."""
+    rng = np.random.default_rng(b + n)
+    x = rng.standard_normal((b, n, 3)).astype(np.float32)
+    y = rng.standard_normal((b, n, 1)).astype(np.float32)
+    tx, ty = torch.as_tensor(x, device="cuda"), torch.as_tensor(y, device="cuda")
+    eps0 = st.B.epsilon
+    try:
+        st.B.epsilon = 1e-6
+        f = st.GP(st.EQ())
+        fdd = f(tx, 0.1)
+        whole = fdd.logpdf(ty)
+        h = b // 2
+        parts = [f(tx[:h].contiguous(), 0.1), f(tx[h:].contiguous(), 0.1)]
+        halves = torch.cat([parts[0].logpdf(ty[:h].contiguous()), parts[1].logpdf(ty[h:].contiguous())])
+        # the FACTORS bit for bit (the single-column solves behind the log-density are different kernels for >= 64 and < 64 matrices:
+        # their sums run in another order, the log-densities agree to rounding)
+        l_whole = fdd.var.chol().lower()
+        l_halves = torch.cat([parts[0].var.chol().lower(), parts[1].var.chol().lower()])
+        assert torch.equal(l_whole, l_halves)
+        assert whole.shape == (b,) and float(((whole - halves).abs() / whole.abs()).max()) <= 2e-6
+        for i in (0, b // 3, b - 1):
+            ref = O.gp_logpdf([("eq", 1.0, 1.0)], x[i].astype(np.float64), 0.1, y[i].astype(np.float64), eps=1e-6)
+            assert abs(float(whole[i]) - ref) <= 1e-3 * abs(ref)
+    finally:
+        st.B.epsilon = eps0
