@@ -1963,9 +1963,9 @@ int main(int argc, char** argv) {
             printf("BATCHED-STRESS %d mixed-phase factorisations of 512 x 2048^2 against the lockstep one (fingerprint %08x of every lower triangle): %d differ\n", reps, ref, bad);
             return bad ? 1 : 0;
         }
-        if (!strcmp(argv[i], "--batched") && i + 1 < argc) {   // 512 x 2048 f32 potrf with outer block NBO
+        if (!strcmp(argv[i], "--batched") && i + 1 < argc) {   // --batched NBO [BATCH]: BATCH (512) x 2048 f32 potrf with outer block NBO
             const int nbo = atoi(argv[i + 1]);
-            const int n = 2048, d = 3, batch = 512;
+            const int n = 2048, d = 3, batch = (i + 2 < argc && atoi(argv[i + 2]) >= 8) ? atoi(argv[i + 2]) : 512;
             auto hx = randv<float>((size_t)batch * n * d);
             Dev<float> X(hx.size()), K((size_t)batch * n * n), dinv((size_t)batch * gpk_dinv_elems(n));
             Dev<int> info(batch);
@@ -1978,7 +1978,7 @@ int main(int argc, char** argv) {
                 tm.start();
                 gpk_potrf(GPK_F32, K.p, n, n, (int64_t)n * n, batch, dinv.p, info.p, nbo, nullptr);
                 const float ms = tm.stop();
-                if (rep) printf("BATCHED potrf_f32 512x2048 nbo=%d  %.3f ms  %.2f TFLOP/s\n", nbo, ms, batch * (double)n * n * n / 3.0 / ms * 1e-9);
+                if (rep) printf("BATCHED potrf_f32 %dx2048 nbo=%d  %.3f ms  %.2f TFLOP/s\n", batch, nbo, ms, batch * (double)n * n * n / 3.0 / ms * 1e-9);
             }
             {   // the mixed-phase steps against the lockstep launches (dev build: knob 53): the same arithmetic in the same order per entry --
                 // the factors of the first and the last 4 matrices, lower triangles, bit by bit
