@@ -61,6 +61,17 @@ class _Config:
     #: fp32 kernel matrices that are regularised by the jitter alone (the pseudo-points' ``K_z``) are evaluated in fp64 and rounded
     #: once up to this order (``observations._kernel_matrix``); 0 disables it
     fp64_build_max_order = 4096
+    #: Solves against an ILL-CONDITIONED factor get one step of iterative refinement against the factor
+    #: (``x += L^{-1} (b - L x)``, :meth:`Chol._refined`): the blocked solves multiply by EXPLICIT inverses of 512- ... 2048-wide diagonal
+    #: blocks, which is as accurate as substitution while those blocks are well conditioned and loses with their condition number
+    #: beyond that -- measured against an 80-bit reference (``tests/golden/illcond_n1536.json``): posterior variance 500x, mean 20x
+    #: the error of LAPACK's substitution at kappa ~ 5e8; one refinement step brings both back to what 128-wide blocks give.
+    #: "auto": when the a-priori bound ``n * sum(variances) / (noise + epsilon)`` on the condition number
+    #: (:meth:`KernelDense.cond_bound`; host-side, no device read) reaches ``refine_kappa`` of the dtype -- i.e. noise-free or
+    #: nearly noise-free fp64 models (the README's regime, ``README.md:43-86``); never for the noisy benchmark configs.
+    #: True / False: always / never (factors of kernel matrices; a ``Dense`` handed in by the user is never refined).
+    refine_solves = "auto"
+    refine_kappa = {torch.float64: 1e9}
 
 
 config = _Config()
@@ -178,6 +189,8 @@ class Chol:
         self.lookahead_nb = 0
         self.lookahead_sb = 0
         self.rows_under = 0
+        self.refine = False           # one refinement step behind every solve (config.refine_solves; set by the matrix that owns the factor)
+        self.refined = 0              # (how many solves took it; the tests ask)
         self._residuals = {}
 
     @classmethod
@@ -320,14 +333,45 @@ class Chol:
         return ops.get_backend().gemm_colscale(dsb[0, 0][: self.n, : self.n], b, colscale, want_colss=want_colss, a_kmajor=True,
                                                b_kmajor=b_kmajor, tri_k_lower=True)
 
-    def solve_(self, b):
-        """``L^{-1} b``, overwriting ``b`` where possible (``b``: (..., n, nrhs), unit inner stride).
-        Use the RETURN value: the single-GEMM case writes a fresh buffer and leaves ``b`` as it was."""
+    def _solve_once_(self, b):
         out = self._apply_full_inverse(b)
         if out is not None:
             return out
         sb, dsb = self._blocks(b.shape[-1])
         return ops.get_backend().tri_solve_(self.l, dsb, sb, b)
+
+    def _refines(self, b):
+        return self.refine and self.l.dim() == 2 and b.dim() == 2 and b.shape[-1] > 0
+
+    def _refined(self, b0, x):
+        """``x + L^{-1} (b0 - L x)``: one step of iterative refinement of ``x ~ L^{-1} b0`` against the factor (``config.refine_solves``).
+        ``b0`` (a private copy of the right-hand side) is used up, ``x`` is updated in place."""
+        be = ops.get_backend()
+        l = self.lower()                  # (the residual product reads whole tiles / rows of L: zeros above the diagonal)
+        if x.shape[-1] <= 8:
+            r = be.gemv(l, x, alpha=-1.0, beta=1.0, out=b0)
+        else:
+            r = be.gemm(l, x, a_kmajor=True, b_kmajor=False, alpha=-1.0, beta=1.0, out=b0, tri_k_lower=True)
+        self.refined += 1
+        return x.add_(self._solve_once_(r))
+
+    def refine_rows_(self, zt, kxs):
+        """The rows that rode through the factorisation, ``zt ~ kxs L^{-T}`` (ns, n), refined in place by one step against the factor:
+        ``zt += ((kxs - zt L^T) L^{-T})``; ``kxs`` (a fresh evaluation of the cross-covariance, (ns, n)) is used up."""
+        be = ops.get_backend()
+        r = be.gemm(zt, self.lower(), a_kmajor=True, b_kmajor=True, alpha=-1.0, beta=1.0, out=kxs)
+        dz = self._solve_once_(r.transpose(-1, -2).contiguous())
+        self.refined += 1
+        zt.add_(dz.transpose(-1, -2))
+        return zt
+
+    def solve_(self, b):
+        """``L^{-1} b``, overwriting ``b`` where possible (``b``: (..., n, nrhs), unit inner stride).
+        Use the RETURN value: the single-GEMM case writes a fresh buffer and leaves ``b`` as it was."""
+        if self._refines(b):
+            b0 = b.clone()
+            return self._refined(b0, self._solve_once_(b))
+        return self._solve_once_(b)
 
     def solve(self, b):
         """``L^{-1} b`` as a new tensor."""
@@ -337,10 +381,12 @@ class Chol:
         if lb and bb and lb != bb:
             raise ValueError(f"batch shapes {lb} and {bb} do not match")
         out = self._apply_full_inverse(b)
-        if out is not None:
-            return out
-        out = b.expand((lb or bb) + tuple(b.shape[-2:])).clone(memory_format=torch.contiguous_format)
-        return self.solve_(out)
+        if out is None:
+            out = b.expand((lb or bb) + tuple(b.shape[-2:])).clone(memory_format=torch.contiguous_format)
+            out = self._solve_once_(out)
+        if self._refines(b):
+            out = self._refined(b.clone(memory_format=torch.contiguous_format), out)
+        return out
 
     def iqf_diag(self, b, source=None):
         """Column-wise ``|L^{-1} b|^2``: (..., nrhs).  ``source``: see :meth:`solve_residual`."""
@@ -657,8 +703,41 @@ class KernelDense(Dense):
                 return super().chol()
             a = self._build(lower=True, jitter=config.epsilon)
             self._chol = Chol.factor_(a)
+            self._chol.refine = self.wants_refinement()
             return self._chol
         return self._chol.vetted()
+
+    def cond_bound(self):
+        """An a-priori upper bound on the condition number of ``k(x) + noise + epsilon I`` from what the HOST knows (no device read):
+        ``n * sum of the stationary terms' variances / (noise + epsilon)`` -- ``lambda_max <= trace``, ``lambda_min >=`` the smallest
+        diagonal addition.  ``None`` when the host does not know the pieces: a kernel that is no sum of primitives, noise given as a
+        tensor (its smallest entry lives on the device), dense noise.  Non-stationary terms (``Linear``) are left out of the trace:
+        they add at most ``D`` large eigenvalues, the bound is a trigger for `config.refine_solves`, not a guarantee."""
+        terms = self.kernel.terms() if hasattr(self.kernel, "terms") else None
+        if not terms or self.x.dim() != 2:
+            return None
+        noise = self.noise
+        if noise is None or isinstance(noise, Zero):
+            floor = 0.0
+        elif isinstance(noise, Diagonal) and getattr(noise, "host_min", None) is not None:
+            floor = float(noise.host_min)
+        else:
+            return None
+        floor += float(config.epsilon)
+        if not floor > 0.0:
+            return math.inf
+        trace = sum(float(var) for kind, var, _ in terms if kind != "linear")
+        return self.x.shape[-2] * max(trace, 0.0) / floor
+
+    def wants_refinement(self):
+        mode = config.refine_solves
+        if mode is True or mode is False:
+            return mode
+        limit = config.refine_kappa.get(self.dtype)
+        if limit is None or self.x.dim() != 2:
+            return False
+        bound = self.cond_bound()
+        return bound is not None and bound >= limit
 
     def can_factor_with_rows(self, ns):
         """Whether :meth:`chol_with_rows` applies: nothing factorised or materialised yet, ONE matrix of an order the native path
@@ -702,6 +781,9 @@ class KernelDense(Dense):
             buf[n:npad, n:npad].fill_diagonal_(1.0)
             buf[npad:, n:].zero_()
         self._chol, zt = Chol.factor_rows_(buf, npad, n)
+        self._chol.refine = self.wants_refinement()
+        if self._chol.refine:
+            self._chol.refine_rows_(zt, k_cross.pairwise(xs, self.x))
         return self._chol, zt
 
 

@@ -15,13 +15,17 @@ def _noise_as_matrix(noise, x, n):
         return Zero(x.dtype, n, n, device=x.device, batch=tuple(x.shape[:-2]))
     if isinstance(noise, AbstractMatrix):
         return noise
+    host_min = None
     if isinstance(noise, (int, float)) and not isinstance(noise, bool):
+        host_min = float(noise)       # (what the host knows about the diagonal without reading the device: KernelDense.cond_bound)
         noise = torch.full((), float(noise), dtype=x.dtype, device=x.device)      # (a fill on the device: no host-to-device copy to wait for)
     if not torch.is_tensor(noise):
         noise = torch.as_tensor(noise, dtype=x.dtype, device=x.device)
     noise = noise.to(dtype=x.dtype, device=x.device)
     if noise.dim() == 0:
-        return Diagonal(noise.expand(tuple(x.shape[:-2]) + (n,)).contiguous())
+        d = Diagonal(noise.expand(tuple(x.shape[:-2]) + (n,)).contiguous())
+        d.host_min = host_min
+        return d
     if noise.dim() == 1 or (x.dim() > 2 and noise.dim() == x.dim() - 1):
         return Diagonal(noise)
     return Dense(noise)
