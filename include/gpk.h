@@ -148,6 +148,26 @@ int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, vo
 int gpk_potrf_rows(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
                    void* stream);
 
+/* The same with flags (round 6):
+ *   GPK_ROWS_RHS               the last GPK_ROWS_RHS_STRIP (64) rows are a strip whose FIRST row, a[rows - 64][0 .. n), is one right-hand
+ *                              side b (contiguous); the other 63 are padding (initialise them -- zeros; unspecified on return): whole
+ *                              64-row strips keep the plain tail on its fast kernels.  b comes out as L^{-1} b like every
+ *                              other row does, but through the look-ahead steps it is treated as the vector it is -- the two matrix-vector
+ *                              products per diagonal block of gpk_trsv_lower, enqueued as soon as a panel is final on a third stream (CU mask of the helper stream), so
+ *                              that they run beside the trailing updates instead of as ~30 dependent launches behind the factorisation;
+ *                              the plain tail (and the pipelined panels, nb = 0) carry it as a row.  The observations y - m(x) of the
+ *                              posterior mean / log-density: the single-column solve disappears from the step.
+ *   GPK_ROWS_NO_TAIL_INVERSES  the sb-wide explicit inverses of the plain tail's diagonal blocks (the last <= 6144 columns) are NOT
+ *                              written to dinv_sb (nobody is going to solve against this factor with them; gpk_trtri_merge computes
+ *                              them from `dinv` on demand).  The look-ahead panels' own inverses are always there.
+ * Replaces `B.cholesky` + `B.solve(L, K_zx)` + the solve inside `B.iqf_diag(K, y - m)`: stheno/model/observations.py:148-168,
+ * stheno/random.py:272-279. */
+#define GPK_ROWS_RHS 1
+#define GPK_ROWS_NO_TAIL_INVERSES 2
+#define GPK_ROWS_RHS_STRIP 64
+int gpk_potrf_rows_rhs(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
+                       int flags, void* stream);
+
 /* Merge the 128-block inverses into inverses of sb x sb diagonal blocks
  * (sb = 128 * 2^k <= 4096); dinv_sb: [batch][ceil(n/sb)][sb][sb];
  * tmp: >= ceil(n/sb) * sb * sb / 4 elements.  Part of the blocked TRSM below. */

@@ -28,11 +28,13 @@ static int update2(const gpk_update_t* upd, int nupd, double alpha, void* ctrl, 
 }
 
 template <typename T>
-static int potrf_rows_any(T* a, int64_t n, int64_t rows, int64_t ld, T* dinv, T* dinv_sb, int nb, int sb, T* ws, int* info, hipStream_t stream) {
+static int potrf_rows_any(T* a, int64_t n, int64_t rows, int64_t ld, T* dinv, T* dinv_sb, int nb, int sb, T* ws, int* info, int flags, hipStream_t stream) {
     if (rows < n) return GPK_ERR_ARG(4);
     if (n % GPK_DB != 0 && rows > n) return GPK_ERR_ARG(3);
-    if (nb > 0) return gpk_potrf_la_launch<T>(a, n, ld, dinv, dinv_sb, nb, ws, info, stream, sb, rows);
-    return gpk_potrf_rows_launch<T>(a, n, rows, ld, dinv, info, stream);
+    if (flags & ~(GPK_ROWS_RHS | GPK_ROWS_NO_TAIL_INVERSES)) return GPK_ERR_ARG(12);
+    if ((flags & GPK_ROWS_RHS) && rows < n + GPK_ROWS_RHS_STRIP) return GPK_ERR_ARG(4);
+    if (nb > 0) return gpk_potrf_la_launch<T>(a, n, ld, dinv, dinv_sb, nb, ws, info, stream, sb, rows, flags);
+    return gpk_potrf_rows_launch<T>(a, n, rows, ld, dinv, info, stream);       // (pipelined panels: the right-hand side is a row like the others)
 }
 
 extern "C" {
@@ -74,7 +76,12 @@ int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* di
 
 int gpk_potrf_rows(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
                    void* stream) {
-    D1(dtype, potrf_rows_any<T>((T*)a, n, rows, ld, (T*)dinv, (T*)dinv_sb, nb, sb, (T*)ws, info, (hipStream_t)stream));
+    D1(dtype, potrf_rows_any<T>((T*)a, n, rows, ld, (T*)dinv, (T*)dinv_sb, nb, sb, (T*)ws, info, 0, (hipStream_t)stream));
+}
+
+int gpk_potrf_rows_rhs(int dtype, void* a, int64_t n, int64_t rows, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,
+                       int flags, void* stream) {
+    D1(dtype, potrf_rows_any<T>((T*)a, n, rows, ld, (T*)dinv, (T*)dinv_sb, nb, sb, (T*)ws, info, flags, (hipStream_t)stream));
 }
 
 int gpk_potrf_la_split(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_sb, int nb, int sb, void* ws, int* info,

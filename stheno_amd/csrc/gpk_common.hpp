@@ -136,6 +136,7 @@ int gpk_gemm_launch2(bool a_kmaj, bool b_kmaj, int64_t M, int64_t N, int64_t K, 
 // The library's helper stream (one per device, created on first use): masked to one CU per XCD; keys[x] = the
 // HW_ID key (+1) of that CU on XCD x, 0 if nothing is reserved.
 int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]);
+int gpk_helper_side_stream(hipStream_t* side);      // a second stream on the helper stream's CUs; nullptr where there is no CU mask
 void gpk_helper_shutdown();
 void gpk_potrf_shutdown();
 template <typename T>
@@ -181,7 +182,7 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
 int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb);
 template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
-                        hipStream_t stream, int sb = 0, int64_t rows = 0);     // sb: width of the explicit inverses (0 = nb); dinv_big: [ceil(n/sb)][sb][sb]
+                        hipStream_t stream, int sb = 0, int64_t rows = 0, int flags = 0);     // sb: width of the explicit inverses (0 = nb); dinv_big: [ceil(n/sb)][sb][sb]
                                                                                  // rows > n: rows under the matrix (gpk_potrf_la_rows in gpk.h)
 
 // One matrix with `rows - n` more rows under it (gpk_potrf_rows in gpk.h), the plain path: pipelined panels.
@@ -252,6 +253,17 @@ template <typename T>
 int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t lda, int64_t sA,
                     const T* x, int64_t ldx, int64_t sx, T beta, T* y, int64_t ldy, int64_t sy,
                     int64_t batch, hipStream_t stream);
+// one diagonal block of the single-column sweep (gpk_trsv_lower's inner step) on a contiguous vector:
+//   bq (rq entries) <- W bq,   bbelow (nbelow entries) -= Lbelow (nbelow x rq, ld) bq;   tmp: rq elements
+template <typename T>
+int gpk_trsv_step_launch(const T* W, int64_t ldw, int64_t rq, const T* Lbelow, int64_t ld, int64_t nbelow, T* bq, T* bbelow, T* tmp,
+                         hipStream_t stream);
+// (flags of gpk_potrf_rows_rhs, as gpk.h defines them)
+#ifndef GPK_ROWS_RHS
+#define GPK_ROWS_RHS 1
+#define GPK_ROWS_NO_TAIL_INVERSES 2
+#define GPK_ROWS_RHS_STRIP 64
+#endif
 int64_t gpk_kmat_vjp_blocks_impl(int64_t n);
 template <typename T>
 int gpk_kmat_vjp_launch(const int* kinds, const double* inv_ls, int nterms, const T* X, int64_t n, int64_t ldx,

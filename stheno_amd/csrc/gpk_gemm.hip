@@ -626,6 +626,8 @@ namespace {
 struct HelperDev {
     int state = 0;              // 0 = not tried, 1 = ready, -1 = unavailable
     hipStream_t aux = nullptr;
+    hipStream_t side = nullptr;  // a second stream on the same CUs (gpk_helper_side_stream)
+    int side_state = 0;
     unsigned keys[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 HelperDev g_helper[64];
@@ -688,6 +690,33 @@ int gpk_helper_stream(hipStream_t* aux, unsigned keys[8]) {
     return GPK_OK;
 }
 
+// A SECOND stream with the helper stream's CU mask (round 6): memory-bound side work -- the matrix-vector products of a right-hand
+// side that rides through the look-ahead factorisation -- runs there BESIDE the serial panel chain, on the CUs the trailing update
+// keeps empty.  (An unmasked stream would take residency slots the persistent update counts on: measured, +1.7 ms per cfg2 eval.)
+// *side = nullptr when the device has no masked helper stream: the caller runs that work in line.
+int gpk_helper_side_stream(hipStream_t* side) {
+    hipStream_t aux;
+    unsigned keys[8];
+    *side = nullptr;
+    const int st = gpk_helper_stream(&aux, keys);
+    if (st != GPK_OK) return st;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GPK_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_helper_mutex);
+    HelperDev& h = g_helper[dev];
+    if (h.state == 1 && h.side_state == 0) {
+        h.side_state = -1;
+        uint32_t mask[8] = {0xffu, 0, 0, 0, 0, 0, 0, 0};
+        hipStream_t s2 = nullptr;
+        if (hipExtStreamCreateWithCUMask(&s2, 8, mask) == hipSuccess) {
+            h.side = s2;
+            h.side_state = 1;
+        }
+    }
+    if (h.side_state == 1) *side = h.side;
+    return GPK_OK;
+}
+
 // Destroy the helper streams (gpk_shutdown): a process that exits with a CU-masked stream still alive can crash in
 // the runtime's / a profiler's own teardown (seen with rocprofv3 around a torch process).
 void gpk_helper_shutdown() {
@@ -696,8 +725,12 @@ void gpk_helper_shutdown() {
     (void)hipGetDevice(&cur);
     for (int dev = 0; dev < 64; ++dev) {
         HelperDev& h = g_helper[dev];
+        if (h.aux != nullptr || h.side != nullptr) (void)hipSetDevice(dev);
+        if (h.side != nullptr) {
+            (void)hipStreamSynchronize(h.side);
+            (void)hipStreamDestroy(h.side);
+        }
         if (h.aux != nullptr) {
-            (void)hipSetDevice(dev);
             (void)hipStreamSynchronize(h.aux);
             (void)hipStreamDestroy(h.aux);
         }

@@ -1580,18 +1580,19 @@ void gpk_tune_potrf(int key, int64_t value) {
 
 #define GPK_LA_PAD 16
 int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb) {
-    return (n > nb ? n : nb) * (int64_t)(nb + GPK_LA_PAD) + (int64_t)nb * nb / 4 + 16 + 64;   // panel, merge scratch, 64 elements >= the control words
+    return (n > nb ? n : nb) * (int64_t)(nb + GPK_LA_PAD) + (int64_t)nb * nb / 4 + 16 + 64 + nb;   // panel, merge scratch, 64 elements >= the control words, one block of the right-hand side
 }
 
 template <typename T>
 static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* ws, int* info,
-                         hipStream_t stream, int64_t rows);
+                         hipStream_t stream, int64_t rows, int flags);
 
 template <typename T>
 int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, T* ws, int* info,
-                        hipStream_t stream, int sb, int64_t rows) {
+                        hipStream_t stream, int sb, int64_t rows, int flags) {
     if (n <= 0) return GPK_OK;
     if (rows < n) rows = n;
+    if ((flags & GPK_ROWS_RHS) && rows < n + GPK_ROWS_RHS_STRIP) return GPK_ERR_ARG(2);
     if (rows > INT32_MAX) return GPK_ERR_ARG(2);
     if (rows > n && n % GPK_DB != 0) return GPK_ERR_ARG(2);      // rows under the matrix: whole 128-blocks only
     if (rows > n && gpk_cdiv(n, nb) > 64) return GPK_ERR_ARG(2);  // ... and at most 64 outer blocks (their column groups are a 64-bit mask)
@@ -1604,7 +1605,7 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     std::lock_guard<std::mutex> lock(g_la_mutex);
     LaDevice* dev = la_device();
     if (dev == nullptr) return GPK_ERR_LAUNCH;
-    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, stream, rows);
+    if (stream != nullptr) return potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, stream, rows, flags);
 
     // The legacy default stream (what torch's default stream is) synchronises implicitly with every BLOCKING
     // stream -- and the CU-masked helper stream is one (hipExtStreamCreateWithCUMask takes no flags): each
@@ -1618,23 +1619,34 @@ int gpk_potrf_la_launch(T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, in
     hipEvent_t e_in = la_event(*dev, 0), e_out = la_event(*dev, 1);
     if (e_in == nullptr || e_out == nullptr) return GPK_ERR_LAUNCH;
     if (hipEventRecord(e_in, nullptr) != hipSuccess || hipStreamWaitEvent(dev->priv, e_in, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, dev->priv, rows);
+    const int st = potrf_la_body<T>(dev, A, n, ld, dinv128, dinv_big, nb, sb, ws, info, dev->priv, rows, flags);
     // joined whatever `st` is: what was enqueued on the private stream before a failure still uses the caller's buffers
     if (hipEventRecord(e_out, dev->priv) != hipSuccess || hipStreamWaitEvent(nullptr, e_out, 0) != hipSuccess) return st ? st : GPK_ERR_LAUNCH;
     return st;
 }
 
 // rows > n: `rows - n` more rows under the square matrix (PanelCtx::rows): every panel solve and trailing update carries them.
+// flags & GPK_ROWS_RHS (round 6): the last GPK_ROWS_RHS_STRIP (64) of those rows are a strip whose FIRST row is one right-hand side b
+// (n entries, contiguous; the other 63 are padding, so that the plain tail keeps whole 64-row strips -- one ragged row put its six
+// panels and five updates on the bounds-checked kernels: +160 us at N = 16384): b comes out as L^{-1} b like
+// every other row -- but through the look-ahead steps it is not a row of the GEMMs (a 129th tile row for one vector) but a vector of
+// the single-column sweep (gpk_trsv_lower's two matrix-vector products per diagonal block), enqueued as soon as a panel is final on a THIRD stream with the
+// helper stream's CU mask: memory-bound work beside the serial chain on the CUs the trailing update keeps empty, ordered by nothing but its own panels.
+// The plain tail then carries it as the row it is.
 template <typename T>
 static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128, T* dinv_big, int nb, int sb, T* ws, int* info,
-                         hipStream_t stream, int64_t rows) {
-    const int64_t R = rows;              // rows of the buffer (>= n)
+                         hipStream_t stream, int64_t rows, int flags) {
+    const bool rhs = (flags & GPK_ROWS_RHS) != 0;
+    const int64_t Rall = rows;           // rows of the buffer (>= n), the right-hand side among them
+    const int64_t R = rhs ? rows - GPK_ROWS_RHS_STRIP : rows;     // ... the rows the look-ahead's GEMMs carry
+    T* bvec = rhs ? A + R * ld : nullptr;
     unsigned* ctrl = reinterpret_cast<unsigned*>(ws);                   // 64 elements reserved
     // n x nb, leading dimension nb + 16: with a power-of-two pitch the rows of a tile sit on a few memory channels and
     // the panel GEMM, which streams this buffer once, crawls (measured 2x)
     const int64_t ldt = nb + GPK_LA_PAD;
     T* Tp = ws + 64;
-    T* tmp = Tp + (R > nb ? R : nb) * ldt;
+    T* tmp = Tp + (Rall > nb ? Rall : nb) * ldt;
+    T* vtmp = tmp + (int64_t)nb * nb / 4 + 16;       // one block of the right-hand side (side stream only)
     const int64_t nblk = gpk_cdiv(n, nb);
     const int64_t per = (int64_t)sb * sb;      // one explicit inverse
     size_t ev = 2;                       // (events 0 and 1 belong to the default-stream stand-in)
@@ -1643,15 +1655,49 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     // (no explicit block inverse, no separate panel GEMM) is faster -- measured crossover ~5000 rows.
     auto finish_plain = [&](int64_t k) -> int {       // factor A[k:, k:] (all earlier panels applied) the plain way
         int s = potrf_plain<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB), info,
-                               0, (int)k, stream, R - k);
+                               0, (int)k, stream, Rall - k);
         if (s) return s;
+        if (flags & GPK_ROWS_NO_TAIL_INVERSES) return GPK_OK;       // (nobody is going to solve with the sb-wide inverses of the tail)
         return gpk_trtri_merge_launch<T>(A + k * ld + k, n - k, ld, 1, 0, dinv128 + (k / GPK_DB) * (int64_t)(GPK_DB * GPK_DB),
                                          sb, dinv_big + (k / sb) * per, Tp, stream);   // the panel workspace is free by now
     };
     int64_t tail_rows = g_la_tail_rows > 0 ? g_la_tail_rows : 6144;
-    if (R > n && tail_rows < nb) tail_rows = nb;      // (rows under the matrix: the last column block's rows are solved by the plain tail)
+    if (Rall > n && tail_rows < nb) tail_rows = nb;      // (rows under the matrix: the last column block's rows are solved by the plain tail)
     if (n <= tail_rows) return finish_plain(0);
 
+    // the right-hand side's share of panel j (final on `stream` at the point of the call): for every sb-wide diagonal block of the
+    // panel  b_q <- W_q b_q,  b[below, within n] -= L[below, q] b_q  -- on the side stream, behind an event of `stream`
+    hipEvent_t e_side = nullptr;
+    bool side_used = false;
+    hipStream_t side = nullptr;          // the helper stream's sibling (same CU mask); none: the products run in line on `stream`
+    if (rhs && g_la_mode == 1 && dev->aux != nullptr && gpk_helper_side_stream(&side) != GPK_OK) side = nullptr;
+    auto rhs_panel = [&](int64_t j) -> int {
+        if (!rhs) return GPK_OK;
+        hipStream_t s = stream;
+        if (side != nullptr) {
+            hipEvent_t e = la_event(*dev, ev++);
+            if (e == nullptr || hipEventRecord(e, stream) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+            side_used = true;
+            s = side;
+        }
+        const int64_t k0 = j * nb;
+        for (int64_t c = 0; c < nb; c += sb) {
+            const int64_t r0 = k0 + c, r1 = r0 + sb;
+            const int st1 = gpk_trsv_step_launch<T>(dinv_big + (r0 / sb) * per, sb, sb, A + r1 * ld + r0, ld, n - r1, bvec + r0, bvec + r1, vtmp, s);
+            if (st1) return st1;
+        }
+        return GPK_OK;
+    };
+    // ... and `stream` behind everything the side stream has been given (before the plain tail reads the vector as a row, and on
+    // every way out: the side stream's work references the caller's buffers)
+    auto rhs_join = [&]() -> int {
+        if (!side_used) return GPK_OK;
+        if (e_side == nullptr) e_side = la_event(*dev, ev++);
+        if (e_side == nullptr || hipEventRecord(e_side, side) != hipSuccess || hipStreamWaitEvent(stream, e_side, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+        return GPK_OK;
+    };
+    // (a lambda, so that the side stream is joined on every way out)
+    auto steps = [&]() -> int {
     int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, 0, stream);
     if (st) return st;
     if (nblk > 1) {   // the first panel enters the workspace as it is
@@ -1712,6 +1758,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
             st = gpk_gemm_persist_launch<T>(&ps, 1, T(1), ctrl, 0, stream);
         }
         if (st) return st;
+        st = rhs_panel(j);
+        if (st) return st;
         if (n - k1 <= tail_rows) {
             // last look-ahead step: the whole trailing matrix is brought up to date in place (every column block with the panels it
             // has not seen: one segment per depth), the rest is factorised the plain way
@@ -1723,6 +1771,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
                 st = gpk_gemm_persist_launch<T>(sg, ns, T(-1), ctrl, 0, stream);
                 if (st) return st;
             }
+            st = rhs_join();          // (the tail carries the right-hand side as a row: all look-ahead panels applied to it first)
+            if (st) return st;
             return finish_plain(k1);
         }
         // the next panel's column block (diagonal block + strip): the panels it has not seen yet (one with m <= 2, m - 1 in general)
@@ -1806,10 +1856,14 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         if (st) return st;
     }
     return GPK_OK;
+    };
+    const int st_all = steps();
+    const int st_join = rhs_join();
+    return st_all ? st_all : st_join;
 }
 
-template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t, int, int64_t);
-template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t, int, int64_t);
+template int gpk_potrf_la_launch<double>(double*, int64_t, int64_t, double*, double*, int, double*, int*, hipStream_t, int, int64_t, int);
+template int gpk_potrf_la_launch<float>(float*, int64_t, int64_t, float*, float*, int, float*, int*, hipStream_t, int, int64_t, int);
 
 template <typename T>
 int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,

@@ -517,6 +517,17 @@ int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t
                           stream);
 }
 
+template <typename T>
+int gpk_trsv_step_launch(const T* W, int64_t ldw, int64_t rq, const T* Lbelow, int64_t ld, int64_t nbelow, T* bq, T* bbelow, T* tmp,
+                         hipStream_t stream) {
+    if (rq > INT32_MAX || nbelow > INT32_MAX) return GPK_ERR_ARG(1);
+    // tmp = W bq
+    int st = gemv_launch<T>(rq, rq, 1, T(1), W, ldw, 0, bq, 1, 0, T(0), tmp, 1, 0, (T*)nullptr, 0, 1, stream);
+    if (st) return st;
+    // bq = tmp;  bbelow -= Lbelow tmp
+    return gemv_launch<T>(nbelow, rq, 1, T(-1), Lbelow, ld, 0, tmp, 1, 0, T(1), bbelow, 1, 0, bq, rq, 1, stream);
+}
+
 // ---------------------------------------------------------------------------
 // merge inv(L_cc) 128-blocks into inverses of SB x SB diagonal blocks
 //   dinv_sb : [batch][nsb][sb][sb], nsb = ceil(n / sb)
@@ -749,6 +760,7 @@ int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb
 
 #define GPK_INST(T)                                                                                 \
     template int gpk_trtri_launch<T>(const T*, int64_t, int64_t, const T*, int, T*, int64_t, T*, hipStream_t); \
+    template int gpk_trsv_step_launch<T>(const T*, int64_t, int64_t, const T*, int64_t, int64_t, T*, T*, T*, hipStream_t);  \
     template int gpk_gemv_launch<T>(int64_t, int64_t, int, T, const T*, int64_t, int64_t, const T*,  \
                                     int64_t, int64_t, T, T*, int64_t, int64_t, int64_t, hipStream_t); \
     template int gpk_trtri_merge_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,  \

@@ -637,10 +637,13 @@ static void test_potrf_la_case(int n, int nb, int mode, int64_t min_rows, int64_
 // factorisation with rows under the matrix (gpk_potrf_rows): the factor against the plain path's, the extra rows against E L^{-T}
 // by substitution on the host
 template <typename T>
-static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail, int agg = 2) {
-    const int64_t ld = n, rows = n + extra;
+static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail, int agg = 2, int flags = 0) {
+    // flags & 1: the last 64 rows are the right-hand side's strip -- `extra` counts the rows in front of it plus the vector itself
+    const int strip = (flags & 1) ? GPK_ROWS_RHS_STRIP : 0;
+    const int64_t ld = n, rows = n + extra + (strip ? strip - 1 : 0);
     auto A = make_spd<T>(n, 1, ld);
-    auto E = randv<T>((size_t)extra * ld);
+    auto E = randv<T>((size_t)(rows - n) * ld);
+    for (size_t i = (size_t)extra * ld; i < E.size(); ++i) E[i] = T(0);      // (the strip's padding)
     std::vector<T> full((size_t)rows * ld);
     std::copy(A.begin(), A.end(), full.begin());
     std::copy(E.begin(), E.end(), full.begin() + (size_t)n * ld);
@@ -651,7 +654,9 @@ static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail,
     Dev<int> info(1), info2(1);
     dA.up(full); dRef.up(A); info.zero(); info2.zero();
     gpk_tune(9, tail); gpk_tune(47, agg);
-    const int st = gpk_potrf_rows(DT<T>::v, dA.p, n, rows, ld, dinv.p, dbig.p, nb, sb, ws.p, info.p, nullptr);
+    // flags: the last row as a right-hand side (round 6) -- the same numbers are expected in it
+    const int st = flags ? gpk_potrf_rows_rhs(DT<T>::v, dA.p, n, rows, ld, dinv.p, dbig.p, nb, sb, ws.p, info.p, flags, nullptr)
+                         : gpk_potrf_rows(DT<T>::v, dA.p, n, rows, ld, dinv.p, dbig.p, nb, sb, ws.p, info.p, nullptr);
     gpk_tune(9, 0); gpk_tune(47, 2);
     const int st2 = gpk_potrf(DT<T>::v, dRef.p, n, ld, 0, 1, dinv2.p, info2.p, 0, nullptr);
     HIPCHK(hipDeviceSynchronize());
@@ -678,9 +683,9 @@ static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail,
         }
     }
     char nm[200];
-    snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d st%d/%d info%d: factor", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg, st, st2, info.down()[0]);
+    snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d flags%d st%d/%d info%d: factor", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg, flags, st, st2, info.down()[0]);
     report(nm, (st || st2 || !finite || info.down()[0]) ? INFINITY : num / den, DT<T>::eps);
-    snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d: rows = E L^-T", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg);
+    snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d flags%d: rows = E L^-T", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg, flags);
     report(nm, (st || !finite) ? INFINITY : znum / zden, DT<T>::eps * 2);
 }
 
@@ -704,6 +709,13 @@ static void test_potrf_rows() {
     test_potrf_rows_case<T>(5248, 200, 0, 0, 0);
     test_potrf_rows_case<T>(4224, 96, 1024, 0, 2048);
     test_potrf_rows_case<T>(7296, 64, 1024, 512, 3072);
+    // round 6: the last row as a right-hand side vector (side stream through the look-ahead steps, a row in the tail)
+    test_potrf_rows_case<T>(640, 65, 0, 0, 0, 2, 1);               // pipelined panel: a row like the others
+    test_potrf_rows_case<T>(3072, 301, 512, 0, 1024, 2, 1);
+    test_potrf_rows_case<T>(3072, 65, 512, 256, 1024, 2, 3);       // inverses narrower than the outer blocks, no tail inverses
+    test_potrf_rows_case<T>(4096, 1, 1024, 0, 2048, 1, 1);         // the right-hand side alone
+    test_potrf_rows_case<T>(7296, 129, 1024, 512, 3072, 2, 3);
+    test_potrf_rows_case<T>(2048, 78, 256, 0, 0, 2, 3);            // all plain
 }
 
 template <typename T>

@@ -781,10 +781,12 @@ class WhitenedT:
         return self.zt.transpose(-1, -2).contiguous()
 
 
-def _whiten(cache, K_z, k, z, x, own_cross=False):
+def _whiten(cache, K_z, k, z, x, own_cross=False, rhs=None):
     """``L^{-1} k(z, x)`` (memoised), ``L = chol(K_z)``.  ``own_cross``: nobody else will ask for ``k(z, x)`` itself (dense
     conditioning: ``K_z`` is the only matrix it is ever solved against) -- the cross matrix is then not kept and the blocked solve
-    takes it as its workspace instead of a copy (N x N* elements: 268 MB and 0.1 ms at cfg2)."""
+    takes it as its workspace instead of a copy (N x N* elements: 268 MB and 0.1 ms at cfg2).
+    ``rhs = (r, took)``: if THIS call is what factorises ``K_z`` (rows under the matrix), the residual ``r`` (n, 1) rides along as a
+    right-hand side (``matrix.config.posterior_rows_rhs``) and ``took(w)`` is called with ``w = L^{-1} r``."""
     key = ("v", id(K_z), id(k), id(z), id(x))
     if cache is not None and key in cache:
         return cache[key][0]
@@ -794,7 +796,14 @@ def _whiten(cache, K_z, k, z, x, own_cross=False):
     #  nothing to whiten and no business in the factorisation)
     if (own_cross and hasattr(K_z, "can_factor_with_rows") and k.terms() and not isinstance(k, ZeroKernel) and x.dim() == 2 and z.dim() == 2 and not x.requires_grad
             and ("kzx", id(k), id(z), id(x)) not in (cache or {}) and z is getattr(K_z, "x", None) and K_z.can_factor_with_rows(x.shape[-2])):
-        _, zt = K_z.chol_with_rows(k, x)
+        from .matrix import config as _mconfig
+        if rhs is not None and _mconfig.posterior_rows_rhs:
+            got = K_z.chol_with_rows(k, x, rhs=rhs[0])
+            if len(got) == 3:
+                rhs[1](got[2])
+            zt = got[1]
+        else:
+            _, zt = K_z.chol_with_rows(k, x)
         v = WhitenedT(zt)
         if cache is not None:
             cache[key] = (v, K_z, k, z, x)
@@ -897,11 +906,17 @@ class PosteriorMean(Mean):
         self.m_i, self.m_z, self.k_zi, self.z, self.K_z, self.y = m_i, m_z, k_zi, z, K_z, y
         self.own_cross = own_cross       # see _whiten
         self._w = None
+        self._r = None
+
+    def _residual(self):
+        if self._r is None:
+            y = uprank(self.y)
+            self._r = (y, y - self.m_z(self.z))
+        return self._r
 
     def _whitened_residual(self):
         if self._w is None:
-            y = uprank(self.y)
-            r = y - self.m_z(self.z)
+            y, r = self._residual()
             chol = self.K_z.chol()
             if isinstance(self.m_z, ZeroMean) and hasattr(chol, "solve_residual"):
                 self._w = chol.solve_residual(r, y)     # shared with the log-density of the same observations
@@ -909,9 +924,23 @@ class PosteriorMean(Mean):
                 self._w = chol.solve(r)                 # (..., N, 1)
         return self._w
 
+    def _took(self, w):
+        """``w = L^{-1} (y - m_z(z))`` came out of the factorisation (a right-hand side under the matrix): kept here and, for a zero
+        mean, filed with the factor under ``y`` -- the log-density of the same observations finds it (``Chol.solve_residual``)."""
+        self._w = w
+        if isinstance(self.m_z, ZeroMean):
+            chol = self.K_z.chol()
+            if hasattr(chol, "remember_residual"):
+                chol.remember_residual(self._residual()[0], w)
+
     def __call__(self, x, cache=None):
         x = uprank(x)
-        v = _whiten(cache, self.K_z, self.k_zi, self.z, x, self.own_cross)       # (first: it may be what factorises K_z)
+        rhs = None
+        if self._w is None and self.own_cross and hasattr(self.K_z, "can_factor_with_rows") and x.dim() == 2:
+            y, r = self._residual()
+            if r.dim() == 2 and r.shape[-1] == 1 and not r.requires_grad:
+                rhs = (r, self._took)
+        v = _whiten(cache, self.K_z, self.k_zi, self.z, x, self.own_cross, rhs)       # (first: it may be what factorises K_z)
         w = self._whitened_residual()
         if isinstance(v, WhitenedT):
             if w.shape[-1] == 1:

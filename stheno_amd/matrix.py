@@ -55,6 +55,10 @@ class _Config:
     #: and the separate many-column triangular solve disappears.  0 disables it.
     posterior_rows_from = 2048
     posterior_rows_min_points = 64
+    #: ... and the observations ``y - m(x)`` ride along as ONE more row, a right-hand side (``gpk_potrf_rows_rhs``): ``L^{-1} (y - m(x))``,
+    #: which the posterior mean and the log-density need, comes out of the factorisation -- its ~30 dependent matrix-vector launches
+    #: (0.7 ms at N = 16384) run beside the trailing updates instead of behind the factorisation.
+    posterior_rows_rhs = True
     #: Pseudo-point bounds (VFE / DTC) with many more observations than inducing points: build the cross-covariance transposed and padded
     #: to whole 128-tiles (``observations.py``), so that the M x N product runs in the GEMM kernel without bounds checks on two k-contiguous operands.
     pseudo_padded_transposed = True
@@ -173,6 +177,10 @@ def _solve_block(n, nrhs, fp64=True):
     return 128
 
 
+#: rows of the right-hand side's strip under the matrix (``gpk.h``: GPK_ROWS_RHS_STRIP)
+RHS_STRIP = 64
+
+
 class Chol:
     """Lower Cholesky factor ``L`` (possibly batched) with the diagonal-block inverses
     the HIP solve kernels use.  ``L``'s strict upper triangle is unspecified until
@@ -189,6 +197,7 @@ class Chol:
         self.lookahead_nb = 0
         self.lookahead_sb = 0
         self.rows_under = 0
+        self.rhs_rode = False         # the observations rode through the factorisation as a right-hand side (gpk_potrf_rows_rhs)
         self.refine = False           # one refinement step behind every solve (config.refine_solves; set by the matrix that owns the factor)
         self.refined = 0              # (how many solves took it; the tests ask)
         self._residuals = {}
@@ -223,11 +232,14 @@ class Chol:
         return c
 
     @classmethod
-    def factor_rows_(cls, buf, n, n_true=None):
+    def factor_rows_(cls, buf, n, n_true=None, rhs_row=False):
         """Factorise the leading ``n x n`` of ``buf`` (rows, n) IN PLACE, the rows under it riding along (``gpk_potrf_rows``): returns
         ``(chol, zt)`` with ``zt = buf[n:]`` holding ``buf[n:] L^{-T}`` afterwards.  The factor is a view of ``buf``.
         ``n_true < n``: the matrix is ``diag(A, I)`` with ``A`` of order ``n_true`` (``KernelDense.chol_with_rows`` pads to whole
-        128-blocks): the factor and the rows handed back are the leading-``n_true`` views."""
+        128-blocks): the factor and the rows handed back are the leading-``n_true`` views.
+        ``rhs_row``: the last ``RHS_STRIP`` (64) rows of ``buf`` are a strip whose first row is one right-hand side ``b``, the others zero
+        (``gpk_potrf_rows_rhs``); returns ``(chol, zt, w)`` with ``zt = buf[n:-64]`` and ``w = L^{-1} b`` as an (n_true, 1) view of that row.  The single-column solve was the only reader of the
+        tail's merged inverses in this flow, so they are not computed then (a later solve merges on demand, ``Chol._blocks``)."""
         be = ops.get_backend()
         n_true = n if n_true is None else n_true
         nb = sb = 0
@@ -236,20 +248,35 @@ class Chol:
             if nb > 512 and n < config.potrf_lookahead_wide_from:
                 nb = 512
             sb = min(nb, config.potrf_lookahead_inv.get(buf.dtype, nb)) if nb else 0
-        dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb)
+        if rhs_row:
+            dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb, rhs_row=True, tail_inverses=False)
+        else:
+            dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb)
         c = cls(buf[:n_true, :n_true], dinv, info)
         if nb:
             c.lookahead_nb, c.lookahead_sb = nb, sb
             # (a padded order: the solves merge their own inverses -- the blocks the look-ahead leaves are those of the padded matrix)
-            if n_true == n and sb == _solve_block(n, 1, buf.dtype == torch.float64):
+            if dnb is not None and n_true == n and sb == _solve_block(n, 1, buf.dtype == torch.float64):
                 c._dinv_sb[sb] = dnb
-        c.rows_under = buf.shape[0] - n        # (which path ran; the tests ask)
+        c.rows_under = buf.shape[0] - n - (RHS_STRIP if rhs_row else 0)       # (which path ran; the tests ask)
+        c.rhs_rode = bool(rhs_row)
         if config.check_info:
             if _deferred_state.pending is not None:
                 _deferred_state.pending.append(c)
             else:
                 c.check()
+        if rhs_row:
+            return c, buf[n:-RHS_STRIP, :n_true], buf[-RHS_STRIP, :n_true].unsqueeze(-1)
         return c, buf[n:, :n_true]
+
+    def remember_residual(self, source, w):
+        """File ``w = L^{-1} (y - 0)`` under the data tensor ``y`` it came from (see :meth:`solve_residual`): the log-density of the same
+        observations then finds it."""
+        ver = _version_of(source) if torch.is_tensor(source) else None
+        if ver is not None:
+            if len(self._residuals) >= 2:
+                self._residuals.clear()
+            self._residuals[id(source)] = (source, ver, w)
 
     def check(self):
         if self._error is not None:
@@ -755,34 +782,47 @@ class KernelDense(Dense):
         npad = -(-n // 128) * 128      # (round 6: any order -- the native path wants whole 128-blocks, `chol_with_rows` pads with the identity)
         if npad > 64 * 512:         # (the look-ahead's column groups are a 64-bit mask: at most 64 outer blocks of >= 512 columns)
             return False
-        if not rows_panels_fit(npad, ns, self.x.element_size(), bool(config.potrf_lookahead_from) and npad >= config.potrf_lookahead_from):
+        if not rows_panels_fit(npad, ns + RHS_STRIP, self.x.element_size(), bool(config.potrf_lookahead_from) and npad >= config.potrf_lookahead_from):
             return False
         return self._noise_parts()[2] is None
 
-    def chol_with_rows(self, k_cross, xs):
+    def chol_with_rows(self, k_cross, xs, rhs=None):
         """The factor AND ``k_cross(xs, x) L^{-T}`` (ns, n) from one factorisation: the kernel matrix is built in the first ``n`` rows
         of an (n + ns, n) buffer, the cross-covariance under it, and ``gpk_potrf_rows`` carries those rows through its panel solves
         and trailing updates.  Replaces ``cholesky`` + ``solve(L, K_zx)`` of mlkernels' PosteriorKernel (observations.py:148-168).
 
         An order that is no multiple of 128 (round 6) is PADDED to one: ``diag(K, I)`` in an (npad + ns, npad) buffer, zero columns
         under the identity -- its factor is ``diag(L, I)``, the rows come out as ``[K* L^{-T}, 0]``; the factor and the whitened rows
-        handed on are the leading-``n`` views of that buffer (every consumer takes a leading dimension)."""
+        handed on are the leading-``n`` views of that buffer (every consumer takes a leading dimension).
+
+        ``rhs`` (n, 1): one right-hand side that rides along as the last row (``config.posterior_rows_rhs``); returns
+        ``(chol, zt, w)`` with ``w = L^{-1} rhs`` then."""
         n, ns = self.x.shape[-2], xs.shape[-2]
         npad = -(-n // 128) * 128
-        buf = torch.empty((npad + ns, npad), dtype=self.x.dtype, device=self.x.device)
+        refine = self.wants_refinement()
+        if rhs is not None and (refine or tuple(rhs.shape) != (n, 1) or rhs.dtype != self.x.dtype or rhs.device != self.x.device):
+            rhs = None           # (a refined factor solves for it separately: Chol.solve refines, the row would not be)
+        nr = RHS_STRIP if rhs is not None else 0
+        buf = torch.empty((npad + ns + nr, npad), dtype=self.x.dtype, device=self.x.device)
         _, dvec, _ = self._noise_parts()
         top = self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n, :n])
-        low = k_cross.pairwise(xs, self.x, out=buf[npad:, :n])
+        low = k_cross.pairwise(xs, self.x, out=buf[npad:npad + ns, :n])
         # (a kernel that ignores `out=` would leave the buffer uninitialised and the factorisation would whiten garbage)
         if top.data_ptr() != buf.data_ptr() or low.data_ptr() != buf[npad:].data_ptr():
             raise RuntimeError(f"{type(self.kernel).__name__} / {type(k_cross).__name__}.pairwise did not write into `out`")
+        if nr:
+            buf[npad + ns, :n].copy_(rhs[:, 0])
+            buf[npad + ns + 1:].zero_()
         if npad > n:
             buf[n:npad].zero_()
             buf[n:npad, n:npad].fill_diagonal_(1.0)
             buf[npad:, n:].zero_()
+        if nr:
+            self._chol, zt, w = Chol.factor_rows_(buf, npad, n, rhs_row=True)
+            return self._chol, zt, w
         self._chol, zt = Chol.factor_rows_(buf, npad, n)
-        self._chol.refine = self.wants_refinement()
-        if self._chol.refine:
+        self._chol.refine = refine
+        if refine:
             self._chol.refine_rows_(zt, k_cross.pairwise(xs, self.x))
         return self._chol, zt
 

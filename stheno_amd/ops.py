@@ -250,9 +250,12 @@ class HipBackend:
         return dinv, info
 
     @_on_operand_device
-    def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0):
+    def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0, rhs_row=False, tail_inverses=True):
         """In-place lower Cholesky of the leading ``n x n`` of ``a`` (rows, n), rows > n, carrying the rows under it through the
-        factorisation (``gpk_potrf_rows``): they come out as ``a[n:] L^{-T}``.  ``n`` a multiple of 128.  Returns ``(dinv, info, dinv_sb or None)``."""
+        factorisation (``gpk_potrf_rows``): they come out as ``a[n:] L^{-T}``.  ``n`` a multiple of 128.  Returns ``(dinv, info, dinv_sb or None)``.
+        ``rhs_row``: the last 64 rows are a strip whose first row is ONE right-hand side, the rest zero padding (``gpk_potrf_rows_rhs``,
+        ``GPK_ROWS_RHS``: same result, ``L^{-1} b`` in that row, computed by matrix-vector products beside the look-ahead's trailing updates).  ``tail_inverses=False``: the merged inverses of the
+        look-ahead's plain tail are not computed -- ``dinv_sb`` comes back as ``None`` (incomplete), callers merge on demand."""
         if a.dim() != 2 or a.stride(-1) != 1 or a.shape[0] <= a.shape[1] or a.shape[1] % 128 != 0:
             raise ValueError("potrf_rows_ takes one (rows, n) matrix with rows > n, n a multiple of 128 and unit inner stride")
         self._check(a)
@@ -265,6 +268,12 @@ class HipBackend:
         if nb:
             dnb = torch.empty((1, (n + sb - 1) // sb, sb, sb), dtype=a.dtype, device=a.device)
             ws = torch.empty((int(self.lib.gpk_potrf_la_ws_elems(rows, nb)),), dtype=a.dtype, device=a.device)
+        flags = (1 if rhs_row else 0) | (0 if tail_inverses else 2)
+        if flags:
+            code = self.lib.gpk_potrf_rows_rhs(_dtype_id(a), self._ptr(a), n, rows, a.stride(0), self._ptr(dinv), self._ptr(dnb) if nb else None,
+                                               nb, sb if sb != nb else 0, self._ptr(ws) if nb else None, self._ptr(info), flags, self._stream())
+            self._st(code, "gpk_potrf_rows_rhs")
+            return dinv[:, : n // 128], info, (dnb if tail_inverses else None)
         code = self.lib.gpk_potrf_rows(_dtype_id(a), self._ptr(a), n, rows, a.stride(0), self._ptr(dinv), self._ptr(dnb) if nb else None, nb,
                                        sb if sb != nb else 0, self._ptr(ws) if nb else None, self._ptr(info), self._stream())
         self._st(code, "gpk_potrf_rows")

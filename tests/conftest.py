@@ -80,7 +80,7 @@ class OracleBackend:
         a.copy_(self._t(flat.reshape(arr.shape), a))
         return None, info
 
-    def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0):
+    def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0, rhs_row=False, tail_inverses=True):
         """Stand-in for ``HipBackend.potrf_rows_`` (``gpk_potrf_rows``): the leading n x n of ``a`` (rows, n) is factorised in place,
         the rows under it become ``a[n:] L^{-T}`` -- so that the host logic of the posterior-first path runs on the GPU-less box."""
         arr = _np(a).copy()

@@ -218,8 +218,8 @@ def _note(key, **vals):
 def test_hip_path_against_the_80_bit_reference(hip_backend, n, order):
     """kappa ~ 5e8 (n = 1536, 256-wide explicit inverses) and ~1e10 (n = 8192: 1024-wide inverses, the regime of the conditioning
     sweep): with the refinement step the HIP path sits within a small multiple of the fp64 oracle's OWN error against the 80-bit
-    numbers (both orders: the separate solves, and -- from 2048 observations -- the rows under the matrix); without it, it does not
-    (asserted for the variance at n = 8192, so that the test notices when the step stops mattering)."""
+    numbers (both orders: the separate solves, and -- from 2048 observations -- the rows under the matrix); without it, the separate
+    solves do not (asserted for the variance at n = 8192, so that the test notices when the step stops mattering)."""
     path = os.path.join(ROOT, "tests", "golden", f"illcond_n{n}.json")
     if not os.path.exists(path):
         pytest.skip(f"{path} has not been generated")
@@ -254,5 +254,5 @@ def test_hip_path_against_the_80_bit_reference(hip_backend, n, order):
     # the fp64 oracle's own distance from the truth is one draw of a rounding-error walk: a small multiple of it, and north_star's 1e-6
     assert e["mean"] <= max(30 * ref["mean"], 2e-8) and e["mean"] <= 1e-6, (errs, ref)
     assert e["var"] <= max(100 * ref["var"], 2e-7) and e["var"] <= 1e-6, (errs, ref)
-    if n == 8192:
+    if n == 8192 and order == "logpdf-first":      # (posterior-first at this order: pipelined panels, no wide inverse to repair)
         assert errs["False"]["var"] > 3 * e["var"], errs

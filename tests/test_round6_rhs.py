@@ -1,0 +1,145 @@
+"""Round 6: the observations as a right-hand side UNDER the matrix (``gpk_potrf_rows_rhs``, ``matrix.config.posterior_rows_rhs``).
+
+When the posterior is what factorises the observations' kernel matrix, ``K(x*, x)`` rides through the factorisation as rows
+(round 5); now ``y - m(x)`` rides along as one more row, so ``L^{-1} (y - m(x))`` -- which the posterior mean
+(``stheno/model/observations.py:161-168``) and the log-density (``stheno/random.py:272-279``) both need -- comes out of the same
+call instead of a 32-launch single-column sweep behind it.  Host logic over the test backend here; the HIP path against the
+oracle and against the separate solve on the MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import stheno_amd as st
+from oracle import gp_oracle as O
+from stheno_amd import matrix, ops
+
+from .conftest import DEVICE
+
+
+@pytest.fixture()
+def rows_from_128():
+    old = (matrix.config.posterior_rows_from, matrix.config.posterior_rows_min_points)
+    matrix.config.posterior_rows_from, matrix.config.posterior_rows_min_points = 128, 8
+    yield
+    matrix.config.posterior_rows_from, matrix.config.posterior_rows_min_points = old
+
+
+def _rel(a, ref):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    a, ref = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(ref, dtype=np.float64).reshape(-1)
+    return float(np.max(np.abs(a - ref)) / np.max(np.abs(ref)))
+
+
+def _case(n, ns, d, seed, dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    x, xs = rng.standard_normal((n, d)), rng.standard_normal((ns, d))
+    y = np.sin(x.sum(-1, keepdims=True)) + 0.1 * rng.standard_normal((n, 1))
+    return x.astype(dtype), y.astype(dtype), xs.astype(dtype)
+
+
+def test_the_observations_ride_along_and_serve_mean_and_logpdf(any_backend, rows_from_128):
+    dev = DEVICE[0]
+    x, y, xs = _case(384, 40, 2, 1)
+    terms = [("eq", 1.0, 1.0)]
+    ref_mean, _, ref_var = O.gp_posterior(terms, x, 0.05, y, xs, full_cov=False)
+    ref_lp = O.gp_logpdf(terms, x, 0.05, y)
+    tx, ty, txs = (torch.as_tensor(a, device=dev) for a in (x, y, xs))
+    solves = []
+    orig = matrix.Chol.solve
+
+    def counting(self, b):
+        solves.append(tuple(b.shape))
+        return orig(self, b)
+
+    matrix.Chol.solve = counting
+    try:
+        for on in (True, False):
+            matrix.config.posterior_rows_rhs = on
+            del solves[:]
+            f = st.GP(st.EQ())
+            fdd = f(tx, 0.05)
+            mean, var = (f | (fdd, ty))(txs).marginals()
+            lp = float(fdd.logpdf(ty))
+            chol = fdd.var.chol()
+            assert chol.rows_under == 40 and chol.rhs_rode is on
+            assert _rel(mean, ref_mean) <= 1e-9 and _rel(var, ref_var) <= 1e-9 and abs(lp - ref_lp) <= 1e-9 * abs(ref_lp)
+            if on and dev != "cpu":
+                assert solves == []          # neither the mean nor the log-density solved for the observations again
+            if not on:
+                assert (384, 1) in solves
+    finally:
+        matrix.Chol.solve = orig
+        matrix.config.posterior_rows_rhs = True
+
+
+def test_a_mean_function_rides_along_too_and_a_later_solve_merges_its_own_inverses(oracle_backend, rows_from_128):
+    x, y, xs = _case(300, 24, 1, 2)          # 300: padded to 384 inside
+    tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
+    f = st.GP(lambda t: 0.5 * t[:, :1], st.EQ())
+    fdd = f(tx, 0.1)
+    post = f | (fdd, ty)
+    mean, var = post(txs).marginals()
+    chol = fdd.var.chol()
+    assert chol.rhs_rode and chol.rows_under == 24
+    terms = [("eq", 1.0, 1.0)]
+    ref_mean, _, ref_var = O.gp_posterior(terms, x, 0.1, y - 0.5 * x[:, :1], xs, full_cov=False)
+    assert _rel(mean.reshape(-1) - 0.5 * txs[:, 0], ref_mean) <= 1e-9 and _rel(var, ref_var) <= 1e-9
+    # a second set of points: the factor is there, the separate solve runs (and finds its block inverses)
+    xs2 = torch.as_tensor(np.random.default_rng(3).standard_normal((16, 1)))
+    mean2, var2 = post(xs2).marginals()
+    ref_mean2, _, ref_var2 = O.gp_posterior(terms, x, 0.1, y - 0.5 * x[:, :1], xs2.numpy(), full_cov=False)
+    assert _rel(mean2.reshape(-1) - 0.5 * xs2[:, 0], ref_mean2) <= 1e-9 and _rel(var2, ref_var2) <= 1e-9
+
+
+def test_refined_factors_solve_for_the_observations_separately(oracle_backend, rows_from_128):
+    x, y, xs = _case(256, 16, 1, 4)
+    tx, ty, txs = (torch.as_tensor(a) for a in (x, y, xs))
+    f = st.GP(st.EQ())
+    fdd = f(tx, 1e-9)
+    (f | (fdd, ty))(txs).marginals()
+    chol = fdd.var.chol()
+    assert chol.refine and not chol.rhs_rode and chol.rows_under == 16 and chol.refined >= 2
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# MI355X
+# ----------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ns,d,dtype,tol", [
+    (2048, 64, 2, np.float64, 1e-9),          # pipelined panels: the right-hand side is a row like the others
+    (4100, 300, 3, np.float64, 1e-9),         # padded order
+    (11392, 200, 4, np.float64, 1e-9),        # look-ahead (1024-wide inverses) + plain tail, side stream
+    (12288, 2048, 8, np.float64, 1e-9),
+    (11520, 129, 4, np.float32, 2e-4),        # fp32: 512-wide inverses inside 1024-wide outer blocks
+])
+def test_hip_right_hand_side_under_the_matrix_equals_the_separate_solve(hip_backend, n, ns, d, dtype, tol):
+    x, y, xs = _case(n, ns, d, n)
+    x, y, xs = (a.astype(dtype) for a in (x / np.sqrt(d), y, xs / np.sqrt(d)))
+    tx, ty, txs = (torch.as_tensor(a, device="cuda") for a in (x, y, xs))
+    out = {}
+    try:
+        for on in (True, False):
+            matrix.config.posterior_rows_rhs = on
+            f = st.GP(st.EQ())
+            fdd = f(tx, 0.1)
+            mean, var = (f | (fdd, ty))(txs).marginals()
+            lp = float(fdd.logpdf(ty))
+            chol = fdd.var.chol()
+            assert chol.rows_under == ns and chol.rhs_rode is on
+            w = chol.solve_residual(ty.clone(), ty)          # what the factor remembers for y (on) / the separate sweep (off)
+            out[on] = (mean.double().cpu().numpy(), var.double().cpu().numpy(), lp, w.double().cpu().numpy())
+            # a later solve against the same factor (its merged inverses were skipped with the row): still right
+            if on:
+                b = torch.ones((n, 3), dtype=tx.dtype, device="cuda")
+                lo = torch.tril(chol.l)
+                r = lo @ chol.solve(b) - b
+                assert float(r.abs().max()) <= (1e-9 if dtype == np.float64 else 2e-3)
+    finally:
+        matrix.config.posterior_rows_rhs = True
+    assert _rel(out[True][3], out[False][3]) <= tol
+    assert _rel(out[True][0], out[False][0]) <= tol and _rel(out[True][1], out[False][1]) <= tol
+    assert abs(out[True][2] - out[False][2]) <= tol * abs(out[False][2])
+    if n <= 4100:
+        terms = [("eq", 1.0, 1.0)]
+        ref_mean, _, ref_var = O.gp_posterior(terms, x.astype(np.float64), 0.1, y.astype(np.float64), xs.astype(np.float64), full_cov=False)
+        assert _rel(out[True][0], ref_mean) <= 1e-8 and _rel(out[True][1], ref_var) <= 1e-8
