@@ -124,6 +124,16 @@ int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t bat
  * gpk_trtri_merge(sb = nb) would produce, so the solves below can take them as they are.
  * `ws`: gpk_potrf_la_ws_elems(n, nb) elements of scratch.  `info` as for gpk_potrf (one int, zeroed by the caller).
  * The helper stream is forked from / joined to `stream` with events; under stream capture it joins the capture. */
+/* gpk_potrf with ONE right-hand side per matrix solved along (round 6): `b` holds batch vectors of n entries (unit stride, sb elements
+ * apart), overwritten by L^{-1} b -- what gpk_trsv_lower(l, ..., sb = 128, nrhs = 1) would compute behind the factorisation.
+ * Batches that take the mixed-phase steps (fp32, >= 64 aligned matrices) run each 128-column step's share of the sweep on a side
+ * stream as soon as that block column is final, beside the MFMA-bound launches of the next step: the sweep's HBM traffic (the factor
+ * read once: 4.3 GB and 0.75 ms for 512 x 2048^2 fp32) hides under the factorisation.  Every other shape factorises, then sweeps.
+ * `tmp`: batch * 128 + GPK_TRSV_CTRL_ELEMS elements; dinv as for gpk_potrf (required).
+ * Replaces `B.cholesky` + the solve inside `B.iqf_diag(K, y - m)`: stheno/random.py:272-279 (batched: tests/model/test_cases.py:134-176). */
+int gpk_potrf_rhs(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv, int* info, int nbo, void* b, int64_t sb,
+                  void* tmp, void* stream);
+
 int64_t gpk_potrf_la_ws_elems(int64_t n, int nb);
 int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_nb, int nb, void* ws, int* info,
                  void* stream);

@@ -1,5 +1,6 @@
-"""A/B on ONE box: cfg2's step (posterior first) with the observations riding through the factorisation as a right-hand side
-(matrix.config.posterior_rows_rhs, gpk_potrf_rows_rhs) and with the separate single-column sweep.  Interleaved repetitions.
+"""A/B on ONE box: a bench step with the observations riding through the factorisation as a right-hand side
+(matrix.config.posterior_rows_rhs -> gpk_potrf_rows_rhs for one matrix, posterior first; matrix.config.logpdf_rhs -> gpk_potrf_rhs
+for batches) and with the separate single-column sweep.  Interleaved repetitions.
 
 usage: python scripts/dev_ab_rows_rhs.py [workload (dense_f64)] [steps (20)] [reps (3)]"""
 import json
@@ -22,13 +23,13 @@ step = make_step(wl, w, t)
 out = {True: [], False: []}
 vals = {}
 for on in (True, False):
-    matrix.config.posterior_rows_rhs = on
+    matrix.config.posterior_rows_rhs = matrix.config.logpdf_rhs = on
     for _ in range(3):
         r = step()
-    vals[on] = [float(torch.as_tensor(v).double().sum()) for v in r]
+    vals[on] = [float(torch.as_tensor(v).double().sum()) for v in (r if isinstance(r, (tuple, list)) else [r])]
 for rep in range(reps):
     for on in (True, False):
-        matrix.config.posterior_rows_rhs = on
+        matrix.config.posterior_rows_rhs = matrix.config.logpdf_rhs = on
         step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

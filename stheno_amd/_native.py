@@ -43,6 +43,7 @@ SIGNATURES = {
     "gpk_potrf_la": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     "gpk_potrf_la_split": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr]),
     "gpk_potrf_rows": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr]),
+    "gpk_potrf_rhs": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_i64, _c_ptr, _c_ptr]),
     "gpk_potrf_rows_rhs": (_c_int, [_c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr]),
     "gpk_gemm_update2": (_c_int, [_c_int, _c_ptr, _c_int, _c_dbl, _c_ptr, _c_int, _c_ptr]),
     "gpk_tune": (None, [_c_int, _c_i64]),

@@ -67,6 +67,11 @@ int gpk_potrf(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t bat
     D1(dtype, gpk_potrf_launch<T>((T*)a, n, ld, batch, sa, (T*)dinv, info, nbo, (hipStream_t)stream));
 }
 
+int gpk_potrf_rhs(int dtype, void* a, int64_t n, int64_t ld, int64_t sa, int64_t batch, void* dinv, int* info, int nbo, void* b, int64_t sb,
+                  void* tmp, void* stream) {
+    D1(dtype, gpk_potrf_rhs_launch<T>((T*)a, n, ld, batch, sa, (T*)dinv, info, nbo, (T*)b, sb, (T*)tmp, (hipStream_t)stream));
+}
+
 int64_t gpk_potrf_la_ws_elems(int64_t n, int nb) { return gpk_potrf_la_ws_elems_impl(n, nb); }
 
 int gpk_potrf_la(int dtype, void* a, int64_t n, int64_t ld, void* dinv, void* dinv_nb, int nb, void* ws, int* info,

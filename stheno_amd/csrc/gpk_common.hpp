@@ -258,6 +258,13 @@ int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t
 template <typename T>
 int gpk_trsv_step_launch(const T* W, int64_t ldw, int64_t rq, const T* Lbelow, int64_t ld, int64_t nbelow, T* bq, T* bbelow, T* tmp,
                          hipStream_t stream);
+template <typename T>
+int gpk_trsv_batch_step_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv, int64_t sD, T* B, int64_t sB, T* tmp,
+                               int64_t batch, int q, hipStream_t stream);
+// gpk_potrf + one right-hand side per matrix solved along (gpk_potrf_rhs in gpk.h)
+template <typename T>
+int gpk_potrf_rhs_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv, int* info, int nbo, T* B, int64_t sB, T* tmp,
+                         hipStream_t stream);
 // (flags of gpk_potrf_rows_rhs, as gpk.h defines them)
 #ifndef GPK_ROWS_RHS
 #define GPK_ROWS_RHS 1

@@ -38,6 +38,8 @@ struct DiagArgs {
     int info_base;     // added to the reported pivot order (the matrix may be a diagonal block of a larger one)
     long long* prof;   // debug: per-phase cycle stamps of workgroup 0 (nullable)
     int zero_next;     // clear the first 4 KiB of the NEXT block's slot in `dinv`: the flag words of the panel step that follows (gpk_panel_step_launch)
+    T* rhs = nullptr;          // round 6 (gpk_potrf_rhs): one right-hand side per matrix -- this block's 128 entries become inv(L_jj) b_j
+    int64_t rhs_stride = 0;
 };
 
 #define PROF_MARK(i)                                                            \
@@ -627,6 +629,24 @@ __global__ __launch_bounds__(D3_THREADS, WPE) void potrf_diag3_kernel(DiagArgs<T
     T* W = p.dinv == nullptr ? nullptr : p.dinv + b * p.dinv_bstride + (p.off / GPK_DB) * (int64_t)(GPK_DB * GPK_DB);
     long long* prof = (p.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0) ? p.prof + (p.off / GPK_DB) * 32 : nullptr;
     diag3_block<T, true>(S, S + GPK_DB * LDP, A, p.ld, rem < GPK_DB ? rem : GPK_DB, W, p.info + b, (int)p.off + p.info_base, p.zero_next, prof);
+    if (p.rhs != nullptr && W != nullptr) {
+        // the right-hand side that is solved along: b_j <- inv(L_jj) b_j (every earlier block column has been applied to b_j by the
+        // solve tiles of the steps before, batch_mix_kernel) -- four threads per row of the inverse this workgroup has just stored
+        gpk_barrier_stores_done();
+        const int tid = threadIdx.x;
+        const int nv = rem < GPK_DB ? rem : GPK_DB;
+        T* yb = p.rhs + b * p.rhs_stride + p.off;
+        if (tid < GPK_DB) S[tid] = tid < nv ? yb[tid] : T(0);
+        __syncthreads();
+        const int row = tid >> 2, q = tid & 3;
+        const T* wr = W + (int64_t)row * GPK_DB + q * 32;
+        T acc = T(0);
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) acc += wr[k] * S[q * 32 + k];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (q == 0 && row < nv) yb[row] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -946,6 +966,8 @@ struct BatchStepArgs {
     int nU;          // update tiles per matrix
     int lag;
     int opts;        // development (knob 56): 1 = an update tile does not pull its C tile into the L2 before it waits, 4 = solve tiles publish behind an agent-scope release
+    T* rhs;          // round 6 (gpk_potrf_rhs): one right-hand side per matrix (nullable); block jn of it holds inv(L_jj) b_j (the diagonal-block kernel)
+    int64_t srhs;
 };
 
 template <typename T>
@@ -997,6 +1019,28 @@ __global__ __launch_bounds__(256, 2) void batch_mix_kernel(BatchStepArgs<T> p) {
             __hip_atomic_fetch_add(batch_ctrl(p, m), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned seen = __hip_atomic_fetch_or(home, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | mybit;
             if (seen & (seen - 1u)) atomicExch(p.info + qx, -2);
+        }
+        if (p.rhs != nullptr) {
+            // the right-hand side's share of this tile, behind the publication (nobody in this launch waits for it):
+            //   b[rows of the tile] -= X w,   X = the 128 x 128 tile of L this workgroup has just stored (its own stores, acknowledged:
+            // read back through the CU's cache), w = block jn of b = inv(L_jj) b_j.  Two threads per row, 64 columns each.
+            typedef typename Traits<T>::vec_t vec_t;
+            constexpr int VEC = Traits<T>::VEC;
+            T* yb = p.rhs + (int64_t)m * p.srhs;
+            T* ws = reinterpret_cast<T*>(smem);             // (the tile's LDS is free: every wave is past the barrier above)
+            if (tid < GPK_DB) ws[tid] = yb[c1 - GPK_DB + tid];
+            __syncthreads();
+            const int row = tid >> 1, half = tid & 1;
+            const T* xr = p.A + (int64_t)m * p.bstride + (int64_t)(c1 + GPK_DB * r + row) * p.ld + (c1 - GPK_DB) + half * 64;
+            T acc = T(0);
+#pragma unroll 4
+            for (int k = 0; k < 64; k += VEC) {
+                const vec_t xv = *reinterpret_cast<const vec_t*>(xr + k);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc += xv[v] * ws[half * 64 + k + v];
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            if (half == 0) yb[c1 + GPK_DB * r + row] -= acc;
         }
         return;
     }
@@ -1324,12 +1368,25 @@ static bool stream_has_all_cus(hipStream_t stream) {
     return set >= cus;
 }
 
+// One right-hand side per matrix that is solved ALONG with a batched factorisation (gpk_potrf_rhs), inside the mixed-phase steps: the
+// diagonal-block kernel of step jn turns block jn of b into inv(L_jj) b_j (it has just stored that inverse), and every solve tile of the
+// step's launch, behind its publication, subtracts its 128 x 128 tile of L times that block from its own 128 entries of b -- the tile
+// is the workgroup's own store, read back through the cache: the separate sweep's 4.3 GB of HBM reads (0.75 ms for 512 x 2048^2 fp32)
+// become ~2 us of a solve tile's slot.  (First form: the sweep's steps as batched matrix-vector launches on a side stream beside the
+// launches of step jn + 1 -- 17.6 ms against 16.65 with the sweep behind the factorisation, profiles/r06_ab_batched_rhs_side_stream.json.)
+template <typename T>
+struct RhsRide {
+    T* B;
+    int64_t sB;
+    T* tmp;          // batch * 128 (+ GPK_TRSV_CTRL_ELEMS) elements
+    bool done;       // set by the path that took it along
+};
 // The batched factorisation with the solves and the update of every 128-column step in one mixed-phase launch (batch_mix_kernel),
 // the diagonal blocks in a launch of their own in front of it.  Same arithmetic, same order per entry as the lockstep path below:
 // recursive halving inside outer panels of `nbo` columns, rank-nbo trailing updates.
 template <typename T>
 static int potrf_batched_mixed(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv, int64_t dstride, int* info, int nbo,
-                               int info_base, hipStream_t stream) {
+                               int info_base, hipStream_t stream, RhsRide<T>* ride = nullptr) {
     const int nblk = (int)(n / GPK_DB), npb = nbo / GPK_DB;
     for (int jn = 0; jn < nblk; ++jn) {
         const bool below = jn + 1 < nblk;
@@ -1338,10 +1395,13 @@ static int potrf_batched_mixed(T* A, int64_t n, int64_t ld, int64_t batch, int64
         d.dinv = dinv; d.dinv_bstride = dstride; d.info = info; d.info_base = info_base;
         d.prof = g_diag_prof;
         d.zero_next = below ? 1 : 0;          // the control words of the step kernel behind it
+        if (ride != nullptr) { d.rhs = ride->B; d.rhs_stride = ride->sB; }
         launch_diag<T>(d, (unsigned)batch, stream);
         GPK_CHECK_LAUNCH();
         if (!below) break;
         BatchStepArgs<T> p;
+        p.rhs = ride != nullptr ? ride->B : nullptr;
+        p.srhs = ride != nullptr ? ride->sB : 0;
         p.A = A; p.ld = ld; p.bstride = bstride; p.n = (int)n; p.batch = (int)batch;
         p.dinv = dinv; p.dstride = dstride; p.info = info;
         p.jn = jn;
@@ -1376,12 +1436,13 @@ static int potrf_batched_mixed(T* A, int64_t n, int64_t ld, int64_t batch, int64
         gpk_prof_end(slot, stream);
         GPK_CHECK_LAUNCH();
     }
+    if (ride != nullptr) ride->done = true;
     return GPK_OK;
 }
 
 template <typename T>
 static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv,
-                       int* info, int nbo, int info_base, hipStream_t stream, int64_t rows = 0) {
+                       int* info, int nbo, int info_base, hipStream_t stream, int64_t rows = 0, RhsRide<T>* rhs_ride = nullptr) {
     if (n <= 0 || batch <= 0) return GPK_OK;
     if (rows < n) rows = n;
     if (rows > INT32_MAX) return GPK_ERR_ARG(2);
@@ -1400,7 +1461,7 @@ static int potrf_plain(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstri
     if (g_batch_mixed && batch >= g_batch_mixed_min && rows == n && dinv != nullptr && n % GPK_DB == 0 && n >= 4 * GPK_DB && nbo <= n &&
         (sizeof(T) == 4 || g_batch_mixed >= 2) && n <= 64 * 1024 && stream_has_all_cus(stream) && ld % Traits<T>::VEC == 0 && bstride % Traits<T>::VEC == 0 && (uintptr_t)A % 16 == 0 &&
         (uintptr_t)dinv % 16 == 0 && ld < GPK_PIPE_LD_MAX && batch <= INT32_MAX / 8)
-        return potrf_batched_mixed<T>(A, n, ld, batch, bstride, dinv, dstride, info, nbo, info_base, stream);
+        return potrf_batched_mixed<T>(A, n, ld, batch, bstride, dinv, dstride, info, nbo, info_base, stream, rhs_ride);
 
     PanelCtx<T> ctx{A, n, ld, batch, bstride, dinv, dstride, info, stream, info_base};
     ctx.rows = rows;
@@ -1870,6 +1931,21 @@ int gpk_potrf_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride
                      int* info, int nbo, hipStream_t stream) {
     return potrf_plain<T>(A, n, ld, batch, bstride, dinv, info, nbo, 0, stream);
 }
+
+template <typename T>
+int gpk_potrf_rhs_launch(T* A, int64_t n, int64_t ld, int64_t batch, int64_t bstride, T* dinv, int* info, int nbo, T* B, int64_t sB, T* tmp,
+                         hipStream_t stream) {
+    if (B == nullptr || tmp == nullptr || dinv == nullptr) return GPK_ERR_ARG(9);
+    if (batch > 1 && sB < n) return GPK_ERR_ARG(10);
+    RhsRide<T> ride{B, sB, tmp, false};
+    int st = potrf_plain<T>(A, n, ld, batch, bstride, dinv, info, nbo, 0, stream, 0, &ride);
+    if (st) return st;
+    // the paths that do not take it along (lockstep launches, one matrix): the sweep behind the factorisation, as the caller would
+    if (!ride.done) st = gpk_trsv_launch<T>(A, n, ld, bstride, dinv, GPK_DB, B, 1, 1, sB, tmp, batch, stream);
+    return st;
+}
+template int gpk_potrf_rhs_launch<double>(double*, int64_t, int64_t, int64_t, int64_t, double*, int*, int, double*, int64_t, double*, hipStream_t);
+template int gpk_potrf_rhs_launch<float>(float*, int64_t, int64_t, int64_t, int64_t, float*, int*, int, float*, int64_t, float*, hipStream_t);
 
 template <typename T>
 int gpk_potrf_rows_launch(T* A, int64_t n, int64_t rows, int64_t ld, T* dinv, int* info, hipStream_t stream) {

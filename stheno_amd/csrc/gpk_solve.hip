@@ -517,6 +517,22 @@ int gpk_gemv_launch(int64_t M, int64_t K, int nrhs, T alpha, const T* A, int64_t
                           stream);
 }
 
+// One 128-block step of the single-column sweep of a BATCH of factors (right-looking, as the loop of gpk_trsv_launch):
+//   tmp_b = inv(L_qq) b_q;   b_q = tmp_b;   b[below] -= L[below, q] tmp_b        for every matrix b of the batch
+// dinv: the 128-block inverses [batch][nblk][128][128] (stride sD); B: one vector of n entries per matrix (stride sB); tmp: batch * 128.
+template <typename T>
+int gpk_trsv_batch_step_launch(const T* L, int64_t n, int64_t ld, int64_t sL, const T* dinv, int64_t sD, T* B, int64_t sB, T* tmp,
+                               int64_t batch, int q, hipStream_t stream) {
+    const int64_t r0 = (int64_t)q * GPK_DB;
+    if (r0 >= n) return GPK_OK;
+    const int64_t rq = (n - r0 < GPK_DB) ? n - r0 : GPK_DB;
+    int st = gemv_launch<T>(rq, rq, 1, T(1), dinv + (int64_t)q * (GPK_DB * GPK_DB), GPK_DB, sD, B + r0, 1, sB, T(0), tmp, 1, GPK_DB,
+                            (T*)nullptr, 0, batch, stream);
+    if (st) return st;
+    const int64_t r1 = r0 + rq;
+    return gemv_launch<T>(n - r1, rq, 1, T(-1), L + r1 * ld + r0, ld, sL, tmp, 1, GPK_DB, T(1), B + r1, 1, sB, B + r0, rq, batch, stream);
+}
+
 template <typename T>
 int gpk_trsv_step_launch(const T* W, int64_t ldw, int64_t rq, const T* Lbelow, int64_t ld, int64_t nbelow, T* bq, T* bbelow, T* tmp,
                          hipStream_t stream) {
@@ -761,6 +777,7 @@ int gpk_trtri_launch(const T* L, int64_t n, int64_t ld, const T* dinv_sb, int sb
 #define GPK_INST(T)                                                                                 \
     template int gpk_trtri_launch<T>(const T*, int64_t, int64_t, const T*, int, T*, int64_t, T*, hipStream_t); \
     template int gpk_trsv_step_launch<T>(const T*, int64_t, int64_t, const T*, int64_t, int64_t, T*, T*, T*, hipStream_t);  \
+    template int gpk_trsv_batch_step_launch<T>(const T*, int64_t, int64_t, int64_t, const T*, int64_t, T*, int64_t, T*, int64_t, int, hipStream_t);  \
     template int gpk_gemv_launch<T>(int64_t, int64_t, int, T, const T*, int64_t, int64_t, const T*,  \
                                     int64_t, int64_t, T, T*, int64_t, int64_t, int64_t, hipStream_t); \
     template int gpk_trtri_merge_launch<T>(const T*, int64_t, int64_t, int64_t, int64_t, const T*,  \

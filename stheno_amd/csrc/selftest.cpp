@@ -689,6 +689,52 @@ static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail,
     report(nm, (st || !finite) ? INFINITY : znum / zden, DT<T>::eps * 2);
 }
 
+// batched factorisation with one right-hand side per matrix solved along (gpk_potrf_rhs): factors bit-identical to gpk_potrf's,
+// the solved vectors against gpk_trsv_lower on those factors
+template <typename T>
+static void test_potrf_rhs_case(int n, int batch) {
+    const int64_t ld = n, bs = (int64_t)n * ld;
+    auto A = make_spd<T>(n, batch, ld);
+    auto Bv = randv<T>((size_t)batch * n);
+    Dev<T> dA(A.size()), dR(A.size()), dinv((size_t)batch * gpk_dinv_elems(n)), dinv2((size_t)batch * gpk_dinv_elems(n)), dB(Bv.size()), dB2(Bv.size()),
+        tmp((size_t)batch * 128 + 16), tmp2((size_t)batch * 128 + 16);
+    Dev<int> info(batch), info2(batch);
+    dA.up(A); dR.up(A); dB.up(Bv); dB2.up(Bv); info.zero(); info2.zero();
+    const int st = gpk_potrf_rhs(DT<T>::v, dA.p, n, ld, bs, batch, dinv.p, info.p, 0, dB.p, n, tmp.p, nullptr);
+    const int st2 = gpk_potrf(DT<T>::v, dR.p, n, ld, bs, batch, dinv2.p, info2.p, 0, nullptr);
+    const int st3 = gpk_trsv_lower(DT<T>::v, dR.p, n, ld, bs, dinv2.p, 128, dB2.p, 1, 1, n, tmp2.p, batch, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    auto G = dA.down(), R = dR.down();
+    auto x = dB.down(), x2 = dB2.down();
+    size_t diff = 0;
+    for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) diff += G[(size_t)b * bs + (size_t)i * ld + j] != R[(size_t)b * bs + (size_t)i * ld + j];
+    double num = 0, den = 0;
+    bool finite = true;
+    for (size_t i = 0; i < x.size(); ++i) {
+        if (!std::isfinite((double)x[i])) finite = false;
+        num = std::max(num, std::fabs((double)x[i] - (double)x2[i])); den = std::max(den, std::fabs((double)x2[i]));
+    }
+    int bad = 0;
+    for (int v : info.down()) bad += v != 0;
+    char nm[200];
+    snprintf(nm, sizeof nm, "potrf_rhs_%s n%d batch%d st%d/%d/%d bad_info%d: factors differ in %zu entries", DT<T>::name(), n, batch, st, st2, st3, bad, diff);
+    report(nm, (st || st2 || st3 || bad || diff) ? INFINITY : 0.0, DT<T>::eps);
+    snprintf(nm, sizeof nm, "potrf_rhs_%s n%d batch%d: L^-1 b against gpk_trsv_lower", DT<T>::name(), n, batch);
+    report(nm, (st || !finite) ? INFINITY : num / den, DT<T>::eps * 200);
+}
+
+template <typename T>
+static void test_potrf_rhs() {
+    test_potrf_rhs_case<T>(512, 64);      // mixed-phase steps (fp32): the sweep's steps on the side stream
+    test_potrf_rhs_case<T>(1024, 70);
+    test_potrf_rhs_case<T>(2048, 64);
+    test_potrf_rhs_case<T>(640, 9);       // lockstep launches: the sweep behind the factorisation
+    test_potrf_rhs_case<T>(300, 5);       // ragged order
+    test_potrf_rhs_case<T>(1024, 1);
+}
+
 template <typename T>
 static void test_potrf_rows() {
     test_potrf_rows_case<T>(128, 64, 0, 0, 0);             // one diagonal block + rows
@@ -2087,6 +2133,8 @@ int main(int argc, char** argv) {
         }
         if (!strcmp(argv[i], "--rows")) {                      // only the factorisations with rows under the matrix
             test_potrf_rows<double>(); test_potrf_rows<float>();
+        test_potrf_rhs<double>(); test_potrf_rhs<float>();
+            test_potrf_rhs<double>(); test_potrf_rhs<float>();
             printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);
             return g_fail ? 1 : 0;
         }
@@ -2144,6 +2192,7 @@ int main(int argc, char** argv) {
         test_potrf<double>(); test_potrf<float>();
         test_lookahead<double>(); test_lookahead<float>();
         test_potrf_rows<double>(); test_potrf_rows<float>();
+        test_potrf_rhs<double>(); test_potrf_rhs<float>();
         test_misc<double>(); test_misc<float>();
         test_vjp_dense<double>(); test_vjp_dense<float>();
         printf("SUMMARY pass=%d fail=%d\n", g_pass, g_fail);

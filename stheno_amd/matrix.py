@@ -59,6 +59,10 @@ class _Config:
     #: which the posterior mean and the log-density need, comes out of the factorisation -- its ~30 dependent matrix-vector launches
     #: (0.7 ms at N = 16384) run beside the trailing updates instead of behind the factorisation.
     posterior_rows_rhs = True
+    #: A log-density that is what factorises ``k(x) + noise`` hands its residual ``y - m(x)`` to the factorisation (``gpk_potrf_rhs``): for
+    #: fp32 batches of >= 64 matrices (the mixed-phase steps) the single-column sweep runs on a side stream beside the factorisation
+    #: instead of behind it (cfg4: 0.75 ms of 16.5); every other shape factorises, then sweeps, as before.
+    logpdf_rhs = True
     #: Pseudo-point bounds (VFE / DTC) with many more observations than inducing points: build the cross-covariance transposed and padded
     #: to whole 128-tiles (``observations.py``), so that the M x N product runs in the GEMM kernel without bounds checks on two k-contiguous operands.
     pseudo_padded_transposed = True
@@ -203,8 +207,10 @@ class Chol:
         self._residuals = {}
 
     @classmethod
-    def factor_(cls, a):
-        """Factorise ``a`` (..., n, n; lower triangle read) IN PLACE."""
+    def factor_(cls, a, rhs=None):
+        """Factorise ``a`` (..., n, n; lower triangle read) IN PLACE.  ``rhs``: a contiguous (B, n) tensor, one right-hand side per
+        matrix, overwritten by ``L^{-1} rhs`` along the way where the path can (``gpk_potrf_rhs``: the plain / batched path of a backend
+        that says ``supports_potrf_rhs``); whether it did: ``chol.rhs_rode``."""
         be = ops.get_backend()
         n = a.shape[-1]
         nb = 0
@@ -221,6 +227,10 @@ class Chol:
             if sb == _solve_block(n, 1, a.dtype == torch.float64):
                 c._dinv_sb[sb] = dnb      # the merged inverses the solves want come for free
             # (otherwise nobody would ever read them: n * sb elements are released here)
+        elif rhs is not None and getattr(be, "supports_potrf_rhs", False):
+            dinv, info = be.potrf_(a, config.potrf_nbo, rhs=rhs)
+            c = cls(a, dinv, info)
+            c.rhs_rode = True
         else:
             dinv, info = be.potrf_(a, config.potrf_nbo)
             c = cls(a, dinv, info)
@@ -428,6 +438,12 @@ class Chol:
         second asker gets the first one's result (0.46 ms of a cfg2 eval).  The key is the tensor OBJECT ``y`` (the entry holds it, so
         its id cannot be recycled) at its version counter; no memory for tensors nothing vouches for (``_version_of``: host memory,
         inference tensors)."""
+        for key in (source, r):            # (what rode through the factorisation is filed under `r` itself too: any mean, any batch)
+            if torch.is_tensor(key) and self._residuals:
+                hit = self._residuals.get(id(key))
+                if hit is not None and hit[0] is key and hit[1] == _version_of(key) and tuple(hit[2].shape) == tuple(r.shape) \
+                        and not (torch.is_grad_enabled() and key.requires_grad):
+                    return hit[2]
         if source is None or not torch.is_tensor(source) or r.dim() != 2 or r.shape[-1] > 8 or torch.is_grad_enabled() and source.requires_grad:
             return self.solve(r)
         ver = _version_of(source)
@@ -733,6 +749,26 @@ class KernelDense(Dense):
             self._chol.refine = self.wants_refinement()
             return self._chol
         return self._chol.vetted()
+
+    def chol_with_rhs(self, r, source=None):
+        """:meth:`chol`, with the residual ``r`` (..., n, 1) of a log-density solved along if THIS call is what factorises the matrix
+        (``config.logpdf_rhs``, batched matrices): ``L^{-1} r`` is filed with the factor under ``r`` (and under the data tensor
+        ``source`` it equals for a zero mean), where :meth:`Chol.solve_residual` finds it."""
+        if (self._chol is not None or self._mat is not None or not config.logpdf_rhs or not torch.is_tensor(r) or r.dim() != 3 or r.shape[-1] != 1
+                or (torch.is_grad_enabled() and r.requires_grad) or self.wants_refinement()):
+            return self.chol()
+        a = self._build(lower=True, jitter=config.epsilon)
+        if a.dim() != 3 or tuple(r.shape[:-1]) != tuple(a.shape[:-1]) or r.dtype != a.dtype or r.device != a.device:
+            self._chol = Chol.factor_(a)
+            return self._chol
+        rhs = r[..., 0].clone(memory_format=torch.contiguous_format)
+        self._chol = c = Chol.factor_(a, rhs=rhs)
+        if c.rhs_rode:
+            w = rhs.unsqueeze(-1)
+            c.remember_residual(r, w)
+            if source is not None and source is not r:
+                c.remember_residual(source, w)
+        return c
 
     def cond_bound(self):
         """An a-priori upper bound on the condition number of ``k(x) + noise + epsilon I`` from what the HOST knows (no device read):

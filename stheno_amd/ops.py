@@ -213,9 +213,13 @@ class HipBackend:
         return out
 
     # -- factorisation -------------------------------------------------------
+    supports_potrf_rhs = True
+
     @_on_operand_device
-    def potrf_(self, a, nbo=0, lookahead_nb=0, lookahead_sb=0):
-        """In-place lower Cholesky of ``a`` (..., n, n).  Returns ``(dinv, info)``, or
+    def potrf_(self, a, nbo=0, lookahead_nb=0, lookahead_sb=0, rhs=None):
+        """In-place lower Cholesky of ``a`` (..., n, n).  ``rhs`` (plain path only): a contiguous (B, n) tensor, one right-hand side per
+        matrix, overwritten by ``L^{-1} rhs`` (``gpk_potrf_rhs``: for large fp32 batches the sweep runs beside the factorisation).
+        Returns ``(dinv, info)``, or
         ``(dinv, info, dinv_sb)`` when ``lookahead_nb`` (256 ... 4096) selects the look-ahead
         factorisation of ONE large matrix: ``dinv_sb`` are the inverses of the ``sb x sb`` diagonal
         blocks of the factor (what ``trtri_merge(l, dinv, sb)`` would compute), ``sb = lookahead_sb`` or ``lookahead_nb``."""
@@ -228,8 +232,8 @@ class HipBackend:
         dinv = torch.empty((B, nblk, 128, 128), dtype=a.dtype, device=a.device)
         info = torch.zeros((B,), dtype=torch.int32, device=a.device)
         if lookahead_nb:
-            if B != 1:
-                raise ValueError("the look-ahead factorisation takes one matrix")
+            if B != 1 or rhs is not None:
+                raise ValueError("the look-ahead factorisation takes one matrix (and no right-hand side: gpk_potrf_rows_rhs)")
             nb = int(lookahead_nb)
             sb = int(lookahead_sb) or nb
             dnb = torch.empty((1, (n + sb - 1) // sb, sb, sb), dtype=a.dtype, device=a.device)
@@ -244,6 +248,15 @@ class HipBackend:
             # `ws` is freed here while the factorisation may still be running: torch's caching allocator only reuses the
             # block for work enqueued later on this same stream, and the helper stream has joined it by then
             return dinv, info, dnb
+        if rhs is not None:
+            if tuple(rhs.shape) != (B, n) or not rhs.is_contiguous() or rhs.dtype != a.dtype or rhs.device != a.device:
+                raise ValueError("potrf_: rhs must be a contiguous (batch, n) tensor of the matrices' dtype and device")
+            tmp = torch.empty((B * 128 + 16,), dtype=a.dtype, device=a.device)
+            code = self.lib.gpk_potrf_rhs(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._ptr(dinv), self._ptr(info), int(nbo),
+                                          self._ptr(rhs), n, self._ptr(tmp), self._stream())
+            self._st(code, "gpk_potrf_rhs")
+            # (`tmp` is released here: the caching allocator hands it to later work of THIS stream only, which the side stream has joined)
+            return dinv, info
         code = self.lib.gpk_potrf(_dtype_id(a3), self._ptr(a3), n, _ld(a3), _bs(a3), B, self._ptr(dinv),
                                   self._ptr(info), int(nbo), self._stream())
         self._st(code, "gpk_potrf")

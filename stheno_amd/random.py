@@ -292,9 +292,11 @@ class Normal(RandomVector):
         if isinstance(var, Zero):
             raise torch.linalg.LinAlgError("the variance is identically zero")
         with deferred_checks():      # the factor's `info` is read after the log-determinant and the solve are queued behind it
-            logdet = var.logdet()
             # (a zero prior mean: `r` IS `x`; naming it lets the factor hand the same L^{-1} y to the posterior mean later)
             src = x if (getattr(self, "_zero_mean", False) and isinstance(var, Dense)) else None
+            if hasattr(var, "chol_with_rhs"):
+                var.chol_with_rhs(r, src)      # (a batch that has not been factorised yet: L^{-1} r comes out of the factorisation)
+            logdet = var.logdet()
             iqf = var.iqf_diag(r, src) if src is not None else var.iqf_diag(r)
             logpdfs = -(logdet[..., None] + n * LOG_2_PI + iqf) / 2
         return (logpdfs[..., 0] if logpdfs.shape[-1] == 1 else logpdfs), False

@@ -65,19 +65,26 @@ class OracleBackend:
     def kdiag(self, terms, x):
         return self._t(O.kernel_diag(terms.terms, _np(x)), x)
 
-    def potrf_(self, a, nbo=0):
+    supports_potrf_rhs = True
+
+    def potrf_(self, a, nbo=0, rhs=None):
         arr = _np(a)
         batch = int(np.prod(arr.shape[:-2])) if arr.ndim > 2 else 1
         info = torch.zeros((batch,), dtype=torch.int32)
         flat = arr.reshape((-1,) + arr.shape[-2:]).copy()
+        sol = _np(rhs).copy() if rhs is not None else None      # (batch, n): one right-hand side per matrix, solved along (gpk_potrf_rhs)
         for b in range(flat.shape[0]):
             sym = np.tril(flat[b]) + np.tril(flat[b], -1).T
             try:
                 flat[b] = np.linalg.cholesky(sym)
+                if sol is not None:
+                    sol[b] = O.solve_lower(flat[b], sol[b][:, None])[:, 0]
             except np.linalg.LinAlgError:
                 info[b] = 1
                 flat[b] = np.nan
         a.copy_(self._t(flat.reshape(arr.shape), a))
+        if sol is not None:
+            rhs.copy_(self._t(sol, rhs))
         return None, info
 
     def potrf_rows_(self, a, lookahead_nb=0, lookahead_sb=0, rhs_row=False, tail_inverses=True):

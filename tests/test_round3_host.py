@@ -131,9 +131,9 @@ def test_dense_posterior_consumes_the_cross_matrix_and_the_pseudo_point_posterio
     seen = []
     real = kernels._whiten
 
-    def spy(cache, K_z, k, z, xx, own_cross=False):
+    def spy(cache, K_z, k, z, xx, own_cross=False, *more):
         seen.append(own_cross)
-        return real(cache, K_z, k, z, xx, own_cross)
+        return real(cache, K_z, k, z, xx, own_cross, *more)
 
     monkeypatch.setattr(kernels, "_whiten", spy)
     f = st.GP(st.EQ())

@@ -143,3 +143,65 @@ def test_hip_right_hand_side_under_the_matrix_equals_the_separate_solve(hip_back
         terms = [("eq", 1.0, 1.0)]
         ref_mean, _, ref_var = O.gp_posterior(terms, x.astype(np.float64), 0.1, y.astype(np.float64), xs.astype(np.float64), full_cov=False)
         assert _rel(out[True][0], ref_mean) <= 1e-8 and _rel(out[True][1], ref_var) <= 1e-8
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# batches: the log-density's residual solved along with the batched factorisation (``gpk_potrf_rhs``, ``matrix.config.logpdf_rhs``)
+# ----------------------------------------------------------------------------------------------------------------------------------
+def _batched_case(b, n, d, seed, dtype):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((b, n, d)) / np.sqrt(d)
+    y = np.sin(x.sum(-1, keepdims=True)) + 0.3 * rng.standard_normal((b, n, 1))
+    return x.astype(dtype), y.astype(dtype)
+
+
+def test_batched_logpdf_hands_its_residual_to_the_factorisation(any_backend):
+    dev = DEVICE[0]
+    x, y = _batched_case(5, 96, 2, 7, np.float64)
+    terms = [("eq", 1.0, 1.0)]
+    ref = np.array([O.gp_logpdf(terms, x[i], 0.2, y[i]) for i in range(5)])
+    tx, ty = torch.as_tensor(x, device=dev), torch.as_tensor(y, device=dev)
+    try:
+        for on in (True, False):
+            matrix.config.logpdf_rhs = on
+            fdd = st.GP(st.EQ())(tx, 0.2)
+            lp = fdd.logpdf(ty)
+            chol = fdd.var.chol()
+            assert chol.rhs_rode is on
+            assert _rel(lp, ref) <= 1e-10
+            # a mean function: the residual is not the data, it rides all the same
+            fdd2 = st.GP(lambda t: 0.25 * t[..., :1], st.EQ())(tx, 0.2)
+            lp2 = fdd2.logpdf(ty)
+            assert fdd2.var.chol().rhs_rode is on
+            ref2 = np.array([O.gp_logpdf(terms, x[i], 0.2, y[i] - 0.25 * x[i][:, :1]) for i in range(5)])
+            assert _rel(lp2, ref2) <= 1e-10
+    finally:
+        matrix.config.logpdf_rhs = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,dtype,tol", [
+    (64, 1024, np.float32, 2e-5),         # mixed-phase steps: the sweep's steps on the side stream
+    (200, 2048, np.float32, 2e-5),
+    (70, 512, np.float64, 1e-11),         # fp64 batches keep the lockstep launches: factorise, then sweep (inside the native call)
+    (8, 640, np.float32, 2e-5),
+])
+def test_hip_batched_logpdf_with_the_residual_under_way_equals_the_separate_sweep(hip_backend, b, n, dtype, tol):
+    x, y = _batched_case(b, n, 3, b + n, dtype)
+    tx, ty = torch.as_tensor(x, device="cuda"), torch.as_tensor(y, device="cuda")
+    got = {}
+    try:
+        for on in (True, False):
+            matrix.config.logpdf_rhs = on
+            fdd = st.GP(st.EQ())(tx, 0.2)
+            lp = fdd.logpdf(ty)
+            chol = fdd.var.chol()
+            assert chol.rhs_rode is on
+            got[on] = (lp.double().cpu().numpy(), chol.l.clone())
+    finally:
+        matrix.config.logpdf_rhs = True
+    assert torch.equal(torch.tril(got[True][1]), torch.tril(got[False][1]))          # the same factors, bit for bit
+    assert _rel(got[True][0], got[False][0]) <= tol
+    terms = [("eq", 1.0, 1.0)]
+    ref = np.array([O.gp_logpdf(terms, x[i].astype(np.float64), 0.2, y[i].astype(np.float64)) for i in (0, b // 2, b - 1)])
+    assert _rel(got[True][0][[0, b // 2, b - 1]], ref) <= (1e-3 if dtype == np.float32 else 1e-9)
