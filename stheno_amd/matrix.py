@@ -242,14 +242,15 @@ class Chol:
         return c
 
     @classmethod
-    def factor_rows_(cls, buf, n, n_true=None, rhs_row=False):
+    def factor_rows_(cls, buf, n, n_true=None, rhs_row=False, tail_inverses=False):
         """Factorise the leading ``n x n`` of ``buf`` (rows, n) IN PLACE, the rows under it riding along (``gpk_potrf_rows``): returns
         ``(chol, zt)`` with ``zt = buf[n:]`` holding ``buf[n:] L^{-T}`` afterwards.  The factor is a view of ``buf``.
         ``n_true < n``: the matrix is ``diag(A, I)`` with ``A`` of order ``n_true`` (``KernelDense.chol_with_rows`` pads to whole
         128-blocks): the factor and the rows handed back are the leading-``n_true`` views.
         ``rhs_row``: the last ``RHS_STRIP`` (64) rows of ``buf`` are a strip whose first row is one right-hand side ``b``, the others zero
         (``gpk_potrf_rows_rhs``); returns ``(chol, zt, w)`` with ``zt = buf[n:-64]`` and ``w = L^{-1} b`` as an (n_true, 1) view of that row.  The single-column solve was the only reader of the
-        tail's merged inverses in this flow, so they are not computed then (a later solve merges on demand, ``Chol._blocks``)."""
+        tail's merged inverses in the posterior-first flow, so they are not computed then unless ``tail_inverses`` asks (a later solve
+        merges on demand, ``Chol._blocks``)."""
         be = ops.get_backend()
         n_true = n if n_true is None else n_true
         nb = sb = 0
@@ -259,7 +260,7 @@ class Chol:
                 nb = 512
             sb = min(nb, config.potrf_lookahead_inv.get(buf.dtype, nb)) if nb else 0
         if rhs_row:
-            dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb, rhs_row=True, tail_inverses=False)
+            dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb, rhs_row=True, tail_inverses=bool(tail_inverses))
         else:
             dinv, info, dnb = be.potrf_rows_(buf, lookahead_nb=nb, lookahead_sb=sb)
         c = cls(buf[:n_true, :n_true], dinv, info)
@@ -754,9 +755,26 @@ class KernelDense(Dense):
         """:meth:`chol`, with the residual ``r`` (..., n, 1) of a log-density solved along if THIS call is what factorises the matrix
         (``config.logpdf_rhs``, batched matrices): ``L^{-1} r`` is filed with the factor under ``r`` (and under the data tensor
         ``source`` it equals for a zero mean), where :meth:`Chol.solve_residual` finds it."""
-        if (self._chol is not None or self._mat is not None or not config.logpdf_rhs or not torch.is_tensor(r) or r.dim() != 3 or r.shape[-1] != 1
+        if (self._chol is not None or self._mat is not None or not config.logpdf_rhs or not torch.is_tensor(r) or r.dim() not in (2, 3) or r.shape[-1] != 1
                 or (torch.is_grad_enabled() and r.requires_grad) or self.wants_refinement()):
             return self.chol()
+        if r.dim() == 2:
+            # ONE matrix of an order the rows-under-the-matrix path takes: the residual is the only "row" (its strip), the solve that
+            # usually follows a log-density (a posterior) finds its merged inverses where the look-ahead leaves them
+            be = ops.get_backend()
+            n = self.x.shape[-2] if self.x.dim() == 2 else -1
+            npad = -(-n // 128) * 128
+            if (n < max(config.posterior_rows_from, 1) or not config.posterior_rows_from or not hasattr(be, "potrf_rows_") or self.x.requires_grad
+                    or n != self.kernel.num_outputs(self.x) or tuple(r.shape) != (n, 1) or npad > 64 * 512 or self._noise_parts()[2] is not None
+                    or not rows_panels_fit(npad, RHS_STRIP, self.x.element_size(), bool(config.potrf_lookahead_from) and npad >= config.potrf_lookahead_from)):
+                return self.chol()
+            got = self.chol_with_rows(None, None, rhs=r, tail_inverses=True)
+            c = got[0]
+            if len(got) == 3:
+                c.remember_residual(r, got[2])
+                if source is not None and source is not r:
+                    c.remember_residual(source, got[2])
+            return c
         a = self._build(lower=True, jitter=config.epsilon)
         if a.dim() != 3 or tuple(r.shape[:-1]) != tuple(a.shape[:-1]) or r.dtype != a.dtype or r.device != a.device:
             self._chol = Chol.factor_(a)
@@ -822,7 +840,7 @@ class KernelDense(Dense):
             return False
         return self._noise_parts()[2] is None
 
-    def chol_with_rows(self, k_cross, xs, rhs=None):
+    def chol_with_rows(self, k_cross, xs, rhs=None, tail_inverses=False):
         """The factor AND ``k_cross(xs, x) L^{-T}`` (ns, n) from one factorisation: the kernel matrix is built in the first ``n`` rows
         of an (n + ns, n) buffer, the cross-covariance under it, and ``gpk_potrf_rows`` carries those rows through its panel solves
         and trailing updates.  Replaces ``cholesky`` + ``solve(L, K_zx)`` of mlkernels' PosteriorKernel (observations.py:148-168).
@@ -832,8 +850,10 @@ class KernelDense(Dense):
         handed on are the leading-``n`` views of that buffer (every consumer takes a leading dimension).
 
         ``rhs`` (n, 1): one right-hand side that rides along as the last row (``config.posterior_rows_rhs``); returns
-        ``(chol, zt, w)`` with ``w = L^{-1} rhs`` then."""
-        n, ns = self.x.shape[-2], xs.shape[-2]
+        ``(chol, zt, w)`` with ``w = L^{-1} rhs`` then.  ``k_cross = None``: no rows but the right-hand side's (a log-density that
+        factorises: :meth:`chol_with_rhs`); ``tail_inverses``: with a right-hand side, compute the merged inverses of the look-ahead's
+        tail all the same (a many-column solve is expected to follow)."""
+        n, ns = self.x.shape[-2], (xs.shape[-2] if k_cross is not None else 0)
         npad = -(-n // 128) * 128
         refine = self.wants_refinement()
         if rhs is not None and (refine or tuple(rhs.shape) != (n, 1) or rhs.dtype != self.x.dtype or rhs.device != self.x.device):
@@ -842,9 +862,9 @@ class KernelDense(Dense):
         buf = torch.empty((npad + ns + nr, npad), dtype=self.x.dtype, device=self.x.device)
         _, dvec, _ = self._noise_parts()
         top = self.kernel.pairwise(self.x, None, lower=True, diag_add=config.epsilon, diag_vec=dvec, out=buf[:n, :n])
-        low = k_cross.pairwise(xs, self.x, out=buf[npad:npad + ns, :n])
+        low = k_cross.pairwise(xs, self.x, out=buf[npad:npad + ns, :n]) if k_cross is not None else None
         # (a kernel that ignores `out=` would leave the buffer uninitialised and the factorisation would whiten garbage)
-        if top.data_ptr() != buf.data_ptr() or low.data_ptr() != buf[npad:].data_ptr():
+        if top.data_ptr() != buf.data_ptr() or (low is not None and low.data_ptr() != buf[npad:].data_ptr()):
             raise RuntimeError(f"{type(self.kernel).__name__} / {type(k_cross).__name__}.pairwise did not write into `out`")
         if nr:
             buf[npad + ns, :n].copy_(rhs[:, 0])
@@ -854,8 +874,12 @@ class KernelDense(Dense):
             buf[n:npad, n:npad].fill_diagonal_(1.0)
             buf[npad:, n:].zero_()
         if nr:
-            self._chol, zt, w = Chol.factor_rows_(buf, npad, n, rhs_row=True)
+            self._chol, zt, w = Chol.factor_rows_(buf, npad, n, rhs_row=True, tail_inverses=tail_inverses)
             return self._chol, zt, w
+        if k_cross is None:          # (nothing to carry: the plain factorisation)
+            self._chol = Chol.factor_(buf[:n, :n] if npad == n else buf[:n, :n].contiguous())
+            self._chol.refine = refine
+            return self._chol, buf[npad:, :n]
         self._chol, zt = Chol.factor_rows_(buf, npad, n)
         self._chol.refine = refine
         if refine:

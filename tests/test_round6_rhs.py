@@ -205,3 +205,58 @@ def test_hip_batched_logpdf_with_the_residual_under_way_equals_the_separate_swee
     terms = [("eq", 1.0, 1.0)]
     ref = np.array([O.gp_logpdf(terms, x[i].astype(np.float64), 0.2, y[i].astype(np.float64)) for i in (0, b // 2, b - 1)])
     assert _rel(got[True][0][[0, b // 2, b - 1]], ref) <= (1e-3 if dtype == np.float32 else 1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# one large matrix, log-density FIRST: the residual is the only thing under the matrix (its strip), the posterior's solve follows
+# ----------------------------------------------------------------------------------------------------------------------------------
+def test_logpdf_first_hands_its_residual_to_the_factorisation_of_one_matrix(any_backend, rows_from_128):
+    dev = DEVICE[0]
+    x, y, xs = _case(300, 20, 2, 11)
+    terms = [("eq", 1.0, 1.0)]
+    ref_lp = O.gp_logpdf(terms, x, 0.05, y)
+    ref_mean, _, ref_var = O.gp_posterior(terms, x, 0.05, y, xs, full_cov=False)
+    tx, ty, txs = (torch.as_tensor(a, device=dev) for a in (x, y, xs))
+    try:
+        for on in (True, False):
+            matrix.config.logpdf_rhs = on
+            f = st.GP(st.EQ())
+            fdd = f(tx, 0.05)
+            lp = float(fdd.logpdf(ty))
+            chol = fdd.var.chol()
+            assert chol.rhs_rode is on and chol.rows_under == 0
+            mean, var = (f | (fdd, ty))(txs).marginals()
+            assert abs(lp - ref_lp) <= 1e-9 * abs(ref_lp) and _rel(mean, ref_mean) <= 1e-9 and _rel(var, ref_var) <= 1e-9
+    finally:
+        matrix.config.logpdf_rhs = True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ns,d,dtype,tol", [
+    (2048, 70, 2, np.float64, 1e-9),
+    (4100, 64, 3, np.float64, 1e-9),          # padded order
+    (12288, 2048, 8, np.float64, 1e-9),       # look-ahead: the posterior's 2048-column solve finds the merged inverses it needs
+    (11520, 300, 4, np.float32, 2e-4),
+])
+def test_hip_logpdf_first_with_the_residual_under_the_matrix_equals_the_separate_sweep(hip_backend, n, ns, d, dtype, tol):
+    x, y, xs = _case(n, ns, d, n + 1)
+    x, y, xs = (a.astype(dtype) for a in (x / np.sqrt(d), y, xs / np.sqrt(d)))
+    tx, ty, txs = (torch.as_tensor(a, device="cuda") for a in (x, y, xs))
+    out = {}
+    try:
+        for on in (True, False):
+            matrix.config.logpdf_rhs = on
+            f = st.GP(st.EQ())
+            fdd = f(tx, 0.1)
+            lp = float(fdd.logpdf(ty))
+            chol = fdd.var.chol()
+            assert chol.rhs_rode is on and chol.rows_under == 0
+            merged_before = set(chol._dinv_sb)
+            mean, var = (f | (fdd, ty))(txs).marginals()
+            if n >= matrix.config.potrf_lookahead_from and dtype == np.float64:
+                assert set(chol._dinv_sb) == merged_before          # the look-ahead's inverses served the solve: nothing merged again
+            out[on] = (mean.double().cpu().numpy(), var.double().cpu().numpy(), lp)
+    finally:
+        matrix.config.logpdf_rhs = True
+    assert _rel(out[True][0], out[False][0]) <= tol and _rel(out[True][1], out[False][1]) <= tol
+    assert abs(out[True][2] - out[False][2]) <= tol * abs(out[False][2])
