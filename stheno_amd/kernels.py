@@ -860,7 +860,12 @@ class PosteriorKernel(Kernel):
         vx = _whiten(cache, self.K_z, self.k_zi, self.z, x, self.own_cross)
         if self.k_zi is self.k_zj:
             if isinstance(vx, WhitenedT):
-                _, ss = ops.get_backend().rowreduce(vx.zt, want_dot=False, want_ss=True)
+                # (the posterior mean of the same evaluation has read these rows already and left their sums of squares: one pass)
+                hit = cache.pop(("rowss", id(vx)), None) if cache is not None else None
+                if hit is not None and hit[1] is vx:
+                    ss = hit[0]
+                else:
+                    _, ss = ops.get_backend().rowreduce(vx.zt, want_dot=False, want_ss=True)
             else:
                 _, ss = ops.get_backend().colreduce(vx, want_ss=True)
             return out - ss[..., None]
@@ -944,7 +949,11 @@ class PosteriorMean(Mean):
         w = self._whitened_residual()
         if isinstance(v, WhitenedT):
             if w.shape[-1] == 1:
-                dot, _ = ops.get_backend().rowreduce(v.zt, w, want_dot=True, want_ss=False)
+                # mean AND the rows' sums of squares (what the marginal variance of the same evaluation subtracts, PosteriorKernel.elwise)
+                # from ONE pass over the whitened rows: they are N* x N elements, read from HBM either way
+                dot, ss = ops.get_backend().rowreduce(v.zt, w, want_dot=True, want_ss=cache is not None)
+                if cache is not None and ss is not None:
+                    cache[("rowss", id(v))] = (ss, v)
                 return self.m_i(x) + dot[..., None]
             v = v.plain()
         dot, _ = ops.get_backend().colreduce(v, w, want_dot=True, want_ss=False)

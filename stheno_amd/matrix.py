@@ -294,7 +294,9 @@ class Chol:
             raise self._error
         if not self._checked:
             bad = 0
-            if self.info.numel():
+            if self.info.numel() == 1:
+                bad = int(self.info.item())       # (one matrix: the word itself -- no reduction, no stacking: two launches less in front of the read)
+            elif self.info.numel():
                 lo, hi = torch.stack(tuple(torch.aminmax(self.info))).tolist()       # (one host read)
                 bad = lo if lo < 0 else hi
             self._checked = True
