@@ -26,6 +26,7 @@ def rows_from_128():
 
 def _rel(a, ref):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    ref = ref.detach().cpu().numpy() if torch.is_tensor(ref) else ref
     a, ref = np.asarray(a, dtype=np.float64).reshape(-1), np.asarray(ref, dtype=np.float64).reshape(-1)
     return float(np.max(np.abs(a - ref)) / np.max(np.abs(ref)))
 
@@ -260,3 +261,43 @@ def test_hip_logpdf_first_with_the_residual_under_the_matrix_equals_the_separate
         matrix.config.logpdf_rhs = True
     assert _rel(out[True][0], out[False][0]) <= tol and _rel(out[True][1], out[False][1]) <= tol
     assert abs(out[True][2] - out[False][2]) <= tol * abs(out[False][2])
+
+
+@pytest.mark.gpu
+def test_right_hand_side_under_the_matrix_inside_a_stream_capture(hip_backend):
+    """``gpk_potrf_rows_rhs`` forks onto the helper stream AND onto its sibling (the right-hand side's products): under stream capture
+    both join the capture (``include/gpk.h``).  Capture one look-ahead factorisation with rows and a right-hand side, replay it on
+    fresh data, compare with the eager call."""
+    n, ns = 4096, 192
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 4, generator=g, dtype=torch.float64).to("cuda")
+    xs = torch.randn(ns, 4, generator=g, dtype=torch.float64).to("cuda")
+    y = torch.randn(n, generator=g, dtype=torch.float64).to("cuda")
+    a0 = torch.empty((n + ns + 64, n), dtype=torch.float64, device="cuda")
+    a0[:n] = st.EQ().pairwise(x, None)
+    a0[:n].diagonal().add_(0.1)
+    a0[n:n + ns] = st.EQ().pairwise(xs, x)
+    a0[n + ns:] = 0
+    a0[n + ns] = y
+    be = ops.get_backend()
+    eager = a0.clone()
+    be.potrf_rows_(eager, lookahead_nb=512, rhs_row=True, tail_inverses=False)      # (also creates the helper streams outside the capture)
+    torch.cuda.synchronize()
+    lo = torch.tril(eager[:n])
+    want_w = torch.linalg.solve_triangular(lo, y[:, None], upper=False)[:, 0]
+    assert _rel(eager[n + ns], want_w) < 1e-10
+    buf = a0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            outs = be.potrf_rows_(buf, lookahead_nb=512, rhs_row=True, tail_inverses=False)
+    torch.cuda.current_stream().wait_stream(side)
+    buf.copy_(a0)
+    outs[1].zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(outs[1].max()) == 0
+    assert torch.equal(torch.tril(buf[:n]), torch.tril(eager[:n]))
+    assert _rel(buf[n:n + ns], eager[n:n + ns]) < 1e-13 and _rel(buf[n + ns], eager[n + ns]) < 1e-13
