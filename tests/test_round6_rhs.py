@@ -301,3 +301,94 @@ def test_right_hand_side_under_the_matrix_inside_a_stream_capture(hip_backend):
     assert int(outs[1].max()) == 0
     assert torch.equal(torch.tril(buf[:n]), torch.tril(eager[:n]))
     assert _rel(buf[n:n + ns], eager[n:n + ns]) < 1e-13 and _rel(buf[n + ns], eager[n + ns]) < 1e-13
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# determinism / concurrency of the right-hand sides that ride along
+# ----------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_batched_right_hand_sides_on_four_concurrent_streams_give_the_single_stream_bits(hip_backend):
+    """``gpk_potrf_rhs`` inside the mixed-phase steps: sub-batches of 64 fp32 matrices on four streams at once, 60 rounds -- factors AND
+    solved right-hand sides equal the single-stream run bit for bit (each entry of b is written by exactly one solve tile per step, in
+    step order: nothing about the result depends on what runs beside)."""
+    be = ops.get_backend()
+    terms = ops.KTerms([("eq", 1.0, 1.0)])
+    g = torch.Generator().manual_seed(1)
+    parts, per, n = 4, 64, 1024
+    x = torch.randn(parts * per, n, 3, generator=g, dtype=torch.float64).float().cuda()
+    b = torch.randn(parts * per, n, generator=g, dtype=torch.float64).float().cuda()
+
+    def factor(i):
+        a = be.kmat(terms, x[i * per:(i + 1) * per], lower=True, diag_add=0.1 + 1e-6)
+        rhs = b[i * per:(i + 1) * per].clone()
+        dinv, info = be.potrf_(a, rhs=rhs)
+        return torch.tril(a), rhs, info
+
+    ref = [factor(i) for i in range(parts)]
+    torch.cuda.synchronize()
+    # the solved vectors against the separate sweep on the same factors
+    a0 = be.kmat(terms, x[:per], lower=True, diag_add=0.1 + 1e-6)
+    dinv0, _ = be.potrf_(a0)
+    want = be.tri_solve_(a0, dinv0, 128, b[:per].clone().unsqueeze(-1))[..., 0]
+    assert _rel(ref[0][1], want) < 2e-5
+    streams = [torch.cuda.Stream() for _ in range(parts)]
+    for it in range(60):
+        cur = torch.cuda.current_stream()
+        outs = [None] * parts
+        for i, s in enumerate(streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                outs[i] = factor(i)
+        for s in streams:
+            cur.wait_stream(s)
+        torch.cuda.synchronize()
+        for i in range(parts):
+            for got, wanted, what in zip(outs[i], ref[i], ("factor", "solved right-hand side", "info")):
+                assert torch.equal(got, wanted), f"round {it}, sub-batch {i}: {what} differs from the single-stream run"
+
+
+@pytest.mark.gpu
+def test_look_ahead_with_rows_and_a_right_hand_side_is_reproducible_and_survives_company(hip_backend):
+    """``gpk_potrf_rows_rhs`` shares ONE helper stream and ONE side stream per device between all callers: the same posterior evaluated
+    ten times in a row, and then from two host threads on two streams at once, gives the same bits every time."""
+    import threading
+
+    n, ns = 11392, 256
+    x, y, xs = _case(n, ns, 4, 99)
+    tx, ty, txs = (torch.as_tensor(a / (2.0 if i != 1 else 1.0), device="cuda") for i, a in enumerate((x, y, xs)))
+
+    def evaluate():
+        f = st.GP(st.EQ())
+        fdd = f(tx, 0.1)
+        mean, var = (f | (fdd, ty))(txs).marginals()
+        lp = fdd.logpdf(ty)
+        assert fdd.var.chol().rhs_rode
+        return mean.clone(), var.clone(), lp.clone()
+
+    ref = evaluate()
+    torch.cuda.synchronize()
+    for _ in range(10):
+        got = evaluate()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(4):
+                    results[k] = evaluate()
+                s.synchronize()
+        except Exception as e:        # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert all(torch.equal(a, b) for a, b in zip(results[k], ref)), f"thread {k}"
