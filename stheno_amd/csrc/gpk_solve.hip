@@ -79,12 +79,16 @@ struct GemvArgs {
 };
 
 constexpr int GEMV_ROWS = 16;    // rows per workgroup
-constexpr int GEMV_MAXK = 512;
+// columns of x staged per pass: one right-hand side gets 4096 (32 KB in fp64) -- a long row (the pseudo-point path's V y: 200 000 columns)
+// was 390 passes of two barriers with eight loads per lane between them, latency-bound at 3.4 TB/s; per-lane summation order unchanged
+template <int NR>
+struct GemvChunk { static constexpr int value = NR == 1 ? 4096 : (NR == 2 ? 2048 : 512); };
 
 template <typename T, int NR>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs<T> p) {
     typedef typename Traits<T>::vec_t vec_t;
     constexpr int VEC = Traits<T>::VEC;
+    constexpr int GEMV_MAXK = GemvChunk<NR>::value;
     __shared__ T xs[GEMV_MAXK * NR];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -59,9 +59,10 @@ class _Config:
     #: which the posterior mean and the log-density need, comes out of the factorisation -- its ~30 dependent matrix-vector launches
     #: (0.7 ms at N = 16384) run beside the trailing updates instead of behind the factorisation.
     posterior_rows_rhs = True
-    #: A log-density that is what factorises ``k(x) + noise`` hands its residual ``y - m(x)`` to the factorisation (``gpk_potrf_rhs``): for
-    #: fp32 batches of >= 64 matrices (the mixed-phase steps) the single-column sweep runs on a side stream beside the factorisation
-    #: instead of behind it (cfg4: 0.75 ms of 16.5); every other shape factorises, then sweeps, as before.
+    #: A log-density that is what factorises ``k(x) + noise`` hands its residual ``y - m(x)`` to the factorisation: a batch through
+    #: ``gpk_potrf_rhs`` (fp32 batches of >= 64 matrices: solved inside the mixed-phase launches -- cfg4 16.59 -> 16.23 ms; every other
+    #: batch factorises, then sweeps, inside the one native call), ONE matrix of at least ``posterior_rows_from`` rows as the only strip
+    #: under the matrix (``gpk_potrf_rows_rhs``, the merged inverses kept for the posterior's solve that usually follows).
     logpdf_rhs = True
     #: Pseudo-point bounds (VFE / DTC) with many more observations than inducing points: build the cross-covariance transposed and padded
     #: to whole 128-tiles (``observations.py``), so that the M x N product runs in the GEMM kernel without bounds checks on two k-contiguous operands.
