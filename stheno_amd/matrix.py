@@ -67,6 +67,9 @@ class _Config:
     #: Pseudo-point bounds (VFE / DTC) with many more observations than inducing points: build the cross-covariance transposed and padded
     #: to whole 128-tiles (``observations.py``), so that the M x N product runs in the GEMM kernel without bounds checks on two k-contiguous operands.
     pseudo_padded_transposed = True
+    #: ... and that cross-covariance is built on a side stream BESIDE the factorisation and inversion of the pseudo-points' ``K_z``
+    #: (chain-bound, 1.6 ms at M = 4096; the build is an HBM-bound write that depends on neither).
+    pseudo_overlap_build = True
     #: fp32 kernel matrices that are regularised by the jitter alone (the pseudo-points' ``K_z``) are evaluated in fp64 and rounded
     #: once up to this order (``observations._kernel_matrix``); 0 disables it
     fp64_build_max_order = 4096

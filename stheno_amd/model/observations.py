@@ -82,6 +82,18 @@ def _syrk_lower(be, v, out):
     return out
 
 
+_build_streams = {}
+
+
+def _build_stream(device):
+    """One side stream per device for kernel-matrix builds that run beside a factorisation (``PseudoObs._compute``)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    s = _build_streams.get(key)
+    if s is None:
+        s = _build_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _kernel_matrix(kernel, x, noise, round_once=False):
     """``k(x) + noise`` with a cached Cholesky (``observations.py:139,286``).
 
@@ -338,12 +350,29 @@ class AbstractPseudoObservations(AbstractObservations):
         n_obs = x.shape[-2]
         n_pad = (n_obs + 127) // 128 * 128
         padded = (config.pseudo_padded_transposed and self.method != "fitc" and x.dim() == 2 and z.dim() == 2 and n_obs >= 8 * z.shape[-2]
-                  and z.shape[-2] % 128 == 0 and k_zx.terms() is not None and not x.requires_grad and not z.requires_grad
-                  and K_z.chol().solves_by_full_inverse(n_pad))
+                  and z.shape[-2] % 128 == 0 and k_zx.terms() is not None and not x.requires_grad and not z.requires_grad)
+        K_zx = None
         if padded:
             x_pad = x if n_pad == n_obs else torch.cat([x, x[: n_pad - n_obs]], dim=0)       # (any finite points: their columns are scaled to zero)
-            K_zx = k_zx.pairwise(x_pad, z)                                    # :285, transposed: (N_pad, M)
-        else:
+            if config.pseudo_overlap_build and x.is_cuda and K_z._chol is None:
+                # Round 6: K_z is about to be factorised and inverted (a chain-bound pipelined panel + the merges: 1.6 ms at M = 4096 that
+                # leave the memory system idle), the N x M cross-covariance is an HBM-bound write of its own (0.67 ms at cfg5) and
+                # depends on neither: it is enqueued on a side stream FIRST and runs beside them.
+                cur = torch.cuda.current_stream(x.device)
+                side = _build_stream(x.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    K_zx = k_zx.pairwise(x_pad, z)                            # :285, transposed: (N_pad, M)
+                K_zx.record_stream(cur)
+                padded = K_z.chol().solves_by_full_inverse(n_pad)
+                cur.wait_stream(side)
+                if not padded:
+                    K_zx = None
+            else:
+                padded = K_z.chol().solves_by_full_inverse(n_pad)
+                if padded:
+                    K_zx = k_zx.pairwise(x_pad, z)                            # :285, transposed: (N_pad, M)
+        if K_zx is None:
             K_zx = k_zx.pairwise(z, x)                                        # :285
 
         if not isinstance(noise_x, Diagonal):                                 # :293-297
