@@ -1759,164 +1759,164 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     };
     // (a lambda, so that the side stream is joined on every way out)
     auto steps = [&]() -> int {
-    int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, 0, stream);
-    if (st) return st;
-    if (nblk > 1) {   // the first panel enters the workspace as it is
-        st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, R - nb, nb, 1, stream);
+        int st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, 0, stream);
         if (st) return st;
-    }
-    // applied[c]: panels 0 .. applied[c] - 1 have been subtracted from column block c (columns c nb ..., the rows from its diagonal
-    // block down).  Column block c is updated with its pending panels  L[:, applied[c] nb : k1]  -- contiguous columns of the factor.
-    const int agg = (g_la_agg > 1 && nblk <= 64) ? (int)g_la_agg : 1;      // (the column groups of a segment are a 64-bit mask)
-    std::vector<int> applied((size_t)nblk, 0);
-    struct ColGroup { int from; uint64_t mask; };          // column blocks (bit c - c_first) that are `from` panels deep
-    auto group_cols = [&](int64_t c_first, int64_t j, bool all, std::vector<ColGroup>& out) {
-        out.clear();
-        // more column blocks than a mask has bits (N / nb > 64): agg is 1 then, every block is updated in every step and they all
-        // have the same depth -- ONE group that means "every column" (all-ones; col_segment turns it into the plain triangle)
-        const bool wide = nblk - c_first > 64;
-        for (int64_t c = c_first; c < nblk; ++c) {
-            if (!all && (c - j) % agg != 0) continue;
-            size_t g = 0;
-            while (g < out.size() && out[g].from != applied[(size_t)c]) ++g;
-            if (g == out.size()) out.push_back(ColGroup{applied[(size_t)c], 0});
-            if (wide) out[g].mask = ~(uint64_t)0;
-            else out[g].mask |= (uint64_t)1 << (c - c_first);
-            applied[(size_t)c] = (int)(j + 1);
-        }
-    };
-    // column blocks c_first ... of the trailing matrix A[kc:, kc:] (kc = c_first nb), one segment per depth
-    auto col_segment = [&](const ColGroup& cg, int64_t c_first, int64_t k1) -> GpkSeg<T> {
-        const int64_t kc = c_first * nb, ka = (int64_t)cg.from * nb;
-        const T* P = A + kc * ld + ka;
-        const uint64_t every = (nblk - c_first >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << (nblk - c_first)) - 1);
-        return GpkSeg<T>{R - kc, n - kc, k1 - ka, P, ld, P, ld, A + kc * ld + kc, ld, A + kc * ld + kc, ld, 1, 0, 0,
-                         (cg.mask == every && R == n) ? 0 : cg.mask, nb};
-    };
-    std::vector<ColGroup> groups;
-    for (int64_t j = 0; j + 1 < nblk; ++j) {
-        const int64_t k0 = j * nb, k1 = k0 + nb;
-        const int64_t k2 = (k1 + nb < n) ? k1 + nb : n;
-        // solve(j): rows k1.. of panel j  (k clipped to W's triangle)
-        if (sb < nb) {
-            // the explicit inverses are sb wide (fp32: the error of the posterior mean grows with the width of an explicit inverse): block
-            // substitution over the nb / sb column blocks of the panel -- X_i = (T_i - sum_{p<i} X_p L_ip^T) W_ii^T, same flops as the
-            // single product, 2 nb / sb - 1 launches
-            for (int64_t i = 0; i * sb < nb && st == GPK_OK; ++i) {
-                const int64_t c = i * sb;
-                if (i > 0)
-                    st = gpk_gemm_launch<T>(true, true, R - k1, sb, c, T(-1), A + k1 * ld + k0, ld, 0, A + (k0 + c) * ld + k0, ld, 0, T(1),
-                                            Tp + k1 * ldt + c, ldt, 0, 1, 0, stream);
-                if (st == GPK_OK)
-                    st = gpk_gemm_launch<T>(true, true, R - k1, sb, sb, T(1), Tp + k1 * ldt + c, ldt, 0, dinv_big + (k0 / sb + i) * per, sb, 0, T(0),
-                                            A + k1 * ld + k0 + c, ld, 0, 1, 8, stream);
-            }
-        } else if (g_la_ps_mode == 0) {
-            st = gpk_gemm_launch<T>(true, true, R - k1, nb, nb, T(1), Tp + k1 * ldt, ldt, 0, dinv_big + j * per, nb, 0, T(0),
-                                    A + k1 * ld + k0, ld, 0, 1, 8, stream);
-        } else {
-            GpkSeg<T> ps{R - k1, nb, nb, Tp + k1 * ldt, ldt, dinv_big + j * per, nb, nullptr, 0, A + k1 * ld + k0, ld, 0, g_la_ps_mode};
-            st = gpk_gemm_persist_launch<T>(&ps, 1, T(1), ctrl, 0, stream);
-        }
-        if (st) return st;
-        st = rhs_panel(j);
-        if (st) return st;
-        if (n - k1 <= tail_rows) {
-            // last look-ahead step: the whole trailing matrix is brought up to date in place (every column block with the panels it
-            // has not seen: one segment per depth), the rest is factorised the plain way
-            group_cols(j + 1, j, true, groups);
-            for (size_t g0 = 0; g0 < groups.size(); g0 += GPK_PERSIST_MAX_SEG) {
-                GpkSeg<T> sg[GPK_PERSIST_MAX_SEG];
-                int ns = 0;
-                for (size_t g = g0; g < groups.size() && ns < GPK_PERSIST_MAX_SEG; ++g) sg[ns++] = col_segment(groups[g], j + 1, k1);
-                st = gpk_gemm_persist_launch<T>(sg, ns, T(-1), ctrl, 0, stream);
-                if (st) return st;
-            }
-            st = rhs_join();          // (the tail carries the right-hand side as a row: all look-ahead panels applied to it first)
-            if (st) return st;
-            return finish_plain(k1);
-        }
-        // the next panel's column block (diagonal block + strip): the panels it has not seen yet (one with m <= 2, m - 1 in general)
-        const int64_t ka1 = (int64_t)applied[(size_t)(j + 1)] * nb, kd1 = k1 - ka1;
-        applied[(size_t)(j + 1)] = (int)(j + 1);
-        const T* P1 = A + k1 * ld + ka1;
-        const bool overlap = g_la_mode == 1 && dev->aux != nullptr && (n - k2) >= g_la_min_rows;
-        // diag(j+1): a launch of its own -- or, while the trailing update is long enough to hide a chain that starts a tile later, the
-        // FIRST tiles of that update: the chain's kernel waits for them through a counter word instead of a kernel boundary
-        // (one dependent launch less on the main stream per step)
-        // (measured: fp32 N = 32768 with 512-blocks, 60 steps: cfg3 127.8 -> 127.0 ms; fp64 N = 16384 with 1024-blocks, 10 steps whose
-        // 36 diagonal tiles take ~300 us as 128-tiles of the persistent kernel against 46 us as a launch of 64-tiles: 26.7 -> 26.8 ms.
-        // So: blocks up to 512 only.)
-        const bool fuse_diag = overlap && nb <= g_la_fuse_diag_nb && g_la_fuse_diag_rows > 0 && (n - k2) >= g_la_fuse_diag_rows && g_pipe &&
-                               (k2 - k1) > GPK_DB;
-        if (!fuse_diag) {
-            st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, kd1, T(-1), P1, ld, 0, P1, ld, 0, T(1),
-                                    A + k1 * ld + k1, ld, 0, 1, 1, stream);
+        if (nblk > 1) {   // the first panel enters the workspace as it is
+            st = gpk_copy2d_launch<T>(A + (int64_t)nb * ld, ld, 0, Tp + (int64_t)nb * ldt, ldt, 0, R - nb, nb, 1, stream);
             if (st) return st;
         }
-        // which column blocks behind the next panel are updated in this step, and how deep
-        if (k2 < n) group_cols(j + 2, j, agg == 1 || (n - k2) < g_la_agg_min_rows, groups);
-        else groups.clear();
-        {   // more depths than the launch below has segments for (only at a change of policy): in-place launches of their own, up front
-            const size_t room = (size_t)(GPK_PERSIST_MAX_SEG - 1 - (fuse_diag ? 1 : 0));
-            while (groups.size() > room) {
-                GpkSeg<T> sg = col_segment(groups.back(), j + 2, k1);
-                groups.pop_back();
-                st = gpk_gemm_persist_launch<T>(&sg, 1, T(-1), ctrl, 0, stream);
-                if (st) return st;
+        // applied[c]: panels 0 .. applied[c] - 1 have been subtracted from column block c (columns c nb ..., the rows from its diagonal
+        // block down).  Column block c is updated with its pending panels  L[:, applied[c] nb : k1]  -- contiguous columns of the factor.
+        const int agg = (g_la_agg > 1 && nblk <= 64) ? (int)g_la_agg : 1;      // (the column groups of a segment are a 64-bit mask)
+        std::vector<int> applied((size_t)nblk, 0);
+        struct ColGroup { int from; uint64_t mask; };          // column blocks (bit c - c_first) that are `from` panels deep
+        auto group_cols = [&](int64_t c_first, int64_t j, bool all, std::vector<ColGroup>& out) {
+            out.clear();
+            // more column blocks than a mask has bits (N / nb > 64): agg is 1 then, every block is updated in every step and they all
+            // have the same depth -- ONE group that means "every column" (all-ones; col_segment turns it into the plain triangle)
+            const bool wide = nblk - c_first > 64;
+            for (int64_t c = c_first; c < nblk; ++c) {
+                if (!all && (c - j) % agg != 0) continue;
+                size_t g = 0;
+                while (g < out.size() && out[g].from != applied[(size_t)c]) ++g;
+                if (g == out.size()) out.push_back(ColGroup{applied[(size_t)c], 0});
+                if (wide) out[g].mask = ~(uint64_t)0;
+                else out[g].mask |= (uint64_t)1 << (c - c_first);
+                applied[(size_t)c] = (int)(j + 1);
             }
-        }
-        hipEvent_t e_fork = nullptr, e_join = nullptr;
-        if (overlap) {
-            e_fork = la_event(*dev, ev++);
-            e_join = la_event(*dev, ev++);
-            if (e_fork == nullptr || e_join == nullptr) return GPK_ERR_LAUNCH;
-            // the tile counter is zeroed BEFORE the fork: the helper stream's rejoin launch reads it, so it must be ordered behind
-            if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
-            if (hipEventRecord(e_fork, stream) != hipSuccess) return GPK_ERR_LAUNCH;
-        } else {
-            st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, stream);
-            if (st) return st;
-        }
-        GpkPersistSaved saved;
-        saved.valid = 0;
-        // Everything between the fork and the join: on ANY failure in here the helper stream is still joined to `stream` below --
-        // work already enqueued on it references `ws`, `dinv128` and `A`, which the caller releases as soon as it sees the error
-        // (a caching allocator would hand that memory to later work on the caller's stream).
-        auto forked = [&]() -> int {
-            // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
-            // ~0.3 ms for those, which the main stream would otherwise spend idle
-            if (k2 < n) {
-                const T* P2 = A + k2 * ld + ka1;
-                GpkSeg<T> seg[GPK_PERSIST_MAX_SEG];
-                int ns = 0;
-                if (fuse_diag) seg[ns++] = GpkSeg<T>{k2 - k1, k2 - k1, kd1, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0, 1};
-                const GpkSeg<T> strip{R - k2, k2 - k1, kd1, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
-                // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
-                if (!g_la_strip_last) seg[ns++] = strip;
-                for (const ColGroup& cg : groups) seg[ns++] = col_segment(cg, j + 2, k1);
-                if (g_la_strip_last) seg[ns++] = strip;
-                const int s2 = gpk_gemm_persist_launch<T>(seg, ns, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
-                if (s2) return s2;
-            }
-            if (overlap) {
-                if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-                const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8, ctrl + 2, (unsigned)saved.signal_tiles)
-                                         : la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8);
-                if (s2) return s2;
-                if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
-                    return gpk_gemm_persist_rejoin<T>(&saved, dev->aux);
-            }
-            return GPK_OK;
         };
-        st = forked();
-        if (overlap) {
-            const bool joined = hipEventRecord(e_join, dev->aux) == hipSuccess && hipStreamWaitEvent(stream, e_join, 0) == hipSuccess;
-            if (!joined && st == GPK_OK) st = GPK_ERR_LAUNCH;
+        // column blocks c_first ... of the trailing matrix A[kc:, kc:] (kc = c_first nb), one segment per depth
+        auto col_segment = [&](const ColGroup& cg, int64_t c_first, int64_t k1) -> GpkSeg<T> {
+            const int64_t kc = c_first * nb, ka = (int64_t)cg.from * nb;
+            const T* P = A + kc * ld + ka;
+            const uint64_t every = (nblk - c_first >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << (nblk - c_first)) - 1);
+            return GpkSeg<T>{R - kc, n - kc, k1 - ka, P, ld, P, ld, A + kc * ld + kc, ld, A + kc * ld + kc, ld, 1, 0, 0,
+                             (cg.mask == every && R == n) ? 0 : cg.mask, nb};
+        };
+        std::vector<ColGroup> groups;
+        for (int64_t j = 0; j + 1 < nblk; ++j) {
+            const int64_t k0 = j * nb, k1 = k0 + nb;
+            const int64_t k2 = (k1 + nb < n) ? k1 + nb : n;
+            // solve(j): rows k1.. of panel j  (k clipped to W's triangle)
+            if (sb < nb) {
+                // the explicit inverses are sb wide (fp32: the error of the posterior mean grows with the width of an explicit inverse): block
+                // substitution over the nb / sb column blocks of the panel -- X_i = (T_i - sum_{p<i} X_p L_ip^T) W_ii^T, same flops as the
+                // single product, 2 nb / sb - 1 launches
+                for (int64_t i = 0; i * sb < nb && st == GPK_OK; ++i) {
+                    const int64_t c = i * sb;
+                    if (i > 0)
+                        st = gpk_gemm_launch<T>(true, true, R - k1, sb, c, T(-1), A + k1 * ld + k0, ld, 0, A + (k0 + c) * ld + k0, ld, 0, T(1),
+                                                Tp + k1 * ldt + c, ldt, 0, 1, 0, stream);
+                    if (st == GPK_OK)
+                        st = gpk_gemm_launch<T>(true, true, R - k1, sb, sb, T(1), Tp + k1 * ldt + c, ldt, 0, dinv_big + (k0 / sb + i) * per, sb, 0, T(0),
+                                                A + k1 * ld + k0 + c, ld, 0, 1, 8, stream);
+                }
+            } else if (g_la_ps_mode == 0) {
+                st = gpk_gemm_launch<T>(true, true, R - k1, nb, nb, T(1), Tp + k1 * ldt, ldt, 0, dinv_big + j * per, nb, 0, T(0),
+                                        A + k1 * ld + k0, ld, 0, 1, 8, stream);
+            } else {
+                GpkSeg<T> ps{R - k1, nb, nb, Tp + k1 * ldt, ldt, dinv_big + j * per, nb, nullptr, 0, A + k1 * ld + k0, ld, 0, g_la_ps_mode};
+                st = gpk_gemm_persist_launch<T>(&ps, 1, T(1), ctrl, 0, stream);
+            }
+            if (st) return st;
+            st = rhs_panel(j);
+            if (st) return st;
+            if (n - k1 <= tail_rows) {
+                // last look-ahead step: the whole trailing matrix is brought up to date in place (every column block with the panels it
+                // has not seen: one segment per depth), the rest is factorised the plain way
+                group_cols(j + 1, j, true, groups);
+                for (size_t g0 = 0; g0 < groups.size(); g0 += GPK_PERSIST_MAX_SEG) {
+                    GpkSeg<T> sg[GPK_PERSIST_MAX_SEG];
+                    int ns = 0;
+                    for (size_t g = g0; g < groups.size() && ns < GPK_PERSIST_MAX_SEG; ++g) sg[ns++] = col_segment(groups[g], j + 1, k1);
+                    st = gpk_gemm_persist_launch<T>(sg, ns, T(-1), ctrl, 0, stream);
+                    if (st) return st;
+                }
+                st = rhs_join();          // (the tail carries the right-hand side as a row: all look-ahead panels applied to it first)
+                if (st) return st;
+                return finish_plain(k1);
+            }
+            // the next panel's column block (diagonal block + strip): the panels it has not seen yet (one with m <= 2, m - 1 in general)
+            const int64_t ka1 = (int64_t)applied[(size_t)(j + 1)] * nb, kd1 = k1 - ka1;
+            applied[(size_t)(j + 1)] = (int)(j + 1);
+            const T* P1 = A + k1 * ld + ka1;
+            const bool overlap = g_la_mode == 1 && dev->aux != nullptr && (n - k2) >= g_la_min_rows;
+            // diag(j+1): a launch of its own -- or, while the trailing update is long enough to hide a chain that starts a tile later, the
+            // FIRST tiles of that update: the chain's kernel waits for them through a counter word instead of a kernel boundary
+            // (one dependent launch less on the main stream per step)
+            // (measured: fp32 N = 32768 with 512-blocks, 60 steps: cfg3 127.8 -> 127.0 ms; fp64 N = 16384 with 1024-blocks, 10 steps whose
+            // 36 diagonal tiles take ~300 us as 128-tiles of the persistent kernel against 46 us as a launch of 64-tiles: 26.7 -> 26.8 ms.
+            // So: blocks up to 512 only.)
+            const bool fuse_diag = overlap && nb <= g_la_fuse_diag_nb && g_la_fuse_diag_rows > 0 && (n - k2) >= g_la_fuse_diag_rows && g_pipe &&
+                                   (k2 - k1) > GPK_DB;
+            if (!fuse_diag) {
+                st = gpk_gemm_launch<T>(true, true, k2 - k1, k2 - k1, kd1, T(-1), P1, ld, 0, P1, ld, 0, T(1),
+                                        A + k1 * ld + k1, ld, 0, 1, 1, stream);
+                if (st) return st;
+            }
+            // which column blocks behind the next panel are updated in this step, and how deep
+            if (k2 < n) group_cols(j + 2, j, agg == 1 || (n - k2) < g_la_agg_min_rows, groups);
+            else groups.clear();
+            {   // more depths than the launch below has segments for (only at a change of policy): in-place launches of their own, up front
+                const size_t room = (size_t)(GPK_PERSIST_MAX_SEG - 1 - (fuse_diag ? 1 : 0));
+                while (groups.size() > room) {
+                    GpkSeg<T> sg = col_segment(groups.back(), j + 2, k1);
+                    groups.pop_back();
+                    st = gpk_gemm_persist_launch<T>(&sg, 1, T(-1), ctrl, 0, stream);
+                    if (st) return st;
+                }
+            }
+            hipEvent_t e_fork = nullptr, e_join = nullptr;
+            if (overlap) {
+                e_fork = la_event(*dev, ev++);
+                e_join = la_event(*dev, ev++);
+                if (e_fork == nullptr || e_join == nullptr) return GPK_ERR_LAUNCH;
+                // the tile counter is zeroed BEFORE the fork: the helper stream's rejoin launch reads it, so it must be ordered behind
+                if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
+                if (hipEventRecord(e_fork, stream) != hipSuccess) return GPK_ERR_LAUNCH;
+            } else {
+                st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, stream);
+                if (st) return st;
+            }
+            GpkPersistSaved saved;
+            saved.valid = 0;
+            // Everything between the fork and the join: on ANY failure in here the helper stream is still joined to `stream` below --
+            // work already enqueued on it references `ws`, `dinv128` and `A`, which the caller releases as soon as it sees the error
+            // (a caching allocator would hand that memory to later work on the caller's stream).
+            auto forked = [&]() -> int {
+                // trail(j) goes to the device BEFORE the ~45 launches of the chain are enqueued: the host needs
+                // ~0.3 ms for those, which the main stream would otherwise spend idle
+                if (k2 < n) {
+                    const T* P2 = A + k2 * ld + ka1;
+                    GpkSeg<T> seg[GPK_PERSIST_MAX_SEG];
+                    int ns = 0;
+                    if (fuse_diag) seg[ns++] = GpkSeg<T>{k2 - k1, k2 - k1, kd1, P1, ld, P1, ld, A + k1 * ld + k1, ld, A + k1 * ld + k1, ld, 1, 0, 1};
+                    const GpkSeg<T> strip{R - k2, k2 - k1, kd1, P2, ld, P1, ld, A + k2 * ld + k1, ld, Tp + k2 * ldt, ldt, 0, 0};
+                    // the strip is what the next panel GEMM streams: written last, it is still in the Infinity Cache
+                    if (!g_la_strip_last) seg[ns++] = strip;
+                    for (const ColGroup& cg : groups) seg[ns++] = col_segment(cg, j + 2, k1);
+                    if (g_la_strip_last) seg[ns++] = strip;
+                    const int s2 = gpk_gemm_persist_launch<T>(seg, ns, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
+                    if (s2) return s2;
+                }
+                if (overlap) {
+                    if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
+                    const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8, ctrl + 2, (unsigned)saved.signal_tiles)
+                                             : la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8);
+                    if (s2) return s2;
+                    if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
+                        return gpk_gemm_persist_rejoin<T>(&saved, dev->aux);
+                }
+                return GPK_OK;
+            };
+            st = forked();
+            if (overlap) {
+                const bool joined = hipEventRecord(e_join, dev->aux) == hipSuccess && hipStreamWaitEvent(stream, e_join, 0) == hipSuccess;
+                if (!joined && st == GPK_OK) st = GPK_ERR_LAUNCH;
+            }
+            if (st) return st;
         }
-        if (st) return st;
-    }
-    return GPK_OK;
+        return GPK_OK;
     };
     const int st_all = steps();
     const int st_join = rhs_join();
