@@ -916,7 +916,8 @@ class PosteriorMean(Mean):
     def _residual(self):
         if self._r is None:
             y = uprank(self.y)
-            self._r = (y, y - self.m_z(self.z))
+            # (a zero mean: the residual IS the data -- nobody below writes into it)
+            self._r = (y, y if (isinstance(self.m_z, ZeroMean) and torch.is_tensor(y) and not y.requires_grad) else y - self.m_z(self.z))
         return self._r
 
     def _whitened_residual(self):

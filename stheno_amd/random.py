@@ -238,7 +238,13 @@ class Normal(RandomVector):
 
         var = self.var
         n = self.dim
-        r = x - self._mean_t
+        # (a zero prior mean: the residual IS the data -- no zeros materialised, nothing subtracted; aliasing is safe: every consumer
+        #  below reads `r` or copies it before solving in place)
+        if (getattr(self, "_zero_mean", False) and x.dtype == self.dtype and x.dim() == 2 and x.shape[0] == n and not x.requires_grad
+                and x.device == self.var.device):
+            r = x
+        else:
+            r = x - self._mean_t
         # hyper-parameter learning: differentiable path for a kernel-matrix variance
         batched_ok = (r.dim() == 3 and r.shape[-1] == 1 and torch.is_tensor(getattr(var, "x", None)) and var.x.dim() == 3
                       and tuple(var.x.shape[:-2]) == tuple(r.shape[:-2]))
@@ -298,7 +304,7 @@ class Normal(RandomVector):
                 var.chol_with_rhs(r, src)      # (a batch that has not been factorised yet: L^{-1} r comes out of the factorisation)
             logdet = var.logdet()
             iqf = var.iqf_diag(r, src) if src is not None else var.iqf_diag(r)
-            logpdfs = -(logdet[..., None] + n * LOG_2_PI + iqf) / 2
+            logpdfs = torch.add(logdet[..., None], iqf).add_(n * LOG_2_PI).mul_(-0.5)       # -(logdet + n log 2 pi + iqf) / 2 in three launches
         return (logpdfs[..., 0] if logpdfs.shape[-1] == 1 else logpdfs), False
 
     def entropy(self):
