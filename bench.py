@@ -638,6 +638,9 @@ def main():
                        "nan_scan": "every step (the library's per-tensor memo is cleared at the start of each step)",
                        "call_order": (ORDER if name in ("dense_f64", "sum_f32") else None),
                        "info_check": ("once per step, at the end of the step's st.deferred_checks() block (dense workloads)" if DEFER_CHECKS else "behind the call that factorised (the library's default)"),
+                       "single_column_solve": "L^-1 (y - m(x)) is computed INSIDE the factorisation (a right-hand side under the matrix / inside the batched steps: "
+                                              "the library's defaults matrix.config.posterior_rows_rhs, logpdf_rhs) -- the same quantity as the separate sweep, "
+                                              "shared by the log-density and the posterior mean as before",
                        "parallelism": ("replicas only (%d independent evals in flight, one process per GPU)" % world) if name != "batched_f32"
                        else "GPs sharded over %d ranks, all-gather of log-densities" % world},
             "roofline": roofline,
