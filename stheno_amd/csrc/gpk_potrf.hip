@@ -1640,8 +1640,14 @@ void gpk_tune_potrf(int key, int64_t value) {
 }
 
 #define GPK_LA_PAD 16
+#ifndef GPK_LA_CTRL_PINGPONG
+#define GPK_LA_CTRL_PINGPONG 0       // 1: the next step's control words zeroed on the helper stream instead of by a memset on the main stream in front of every
+                                     // fork (`make ab ABFLAGS=-DGPK_LA_CTRL_PINGPONG=1`).  Measured flat on one box (fp64 N = 16384 + 2048 rows 33.11 against
+                                     // 33.16 ms, fp32 N = 32768 101.45 against 101.56: the memset sits in a dependent-launch gap that is there anyway): OFF
+                                     // (profiles/r06_ab_control_words_pingpong.log)
+#endif
 int64_t gpk_potrf_la_ws_elems_impl(int64_t n, int nb) {
-    return (n > nb ? n : nb) * (int64_t)(nb + GPK_LA_PAD) + (int64_t)nb * nb / 4 + 16 + 64 + nb;   // panel, merge scratch, 64 elements >= the control words, one block of the right-hand side
+    return (n > nb ? n : nb) * (int64_t)(nb + GPK_LA_PAD) + (int64_t)nb * nb / 4 + 16 + 128 + nb;   // panel, merge scratch, 128 elements >= two sets of control words, one block of the right-hand side
 }
 
 template <typename T>
@@ -1701,11 +1707,17 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
     const int64_t Rall = rows;           // rows of the buffer (>= n), the right-hand side among them
     const int64_t R = rhs ? rows - GPK_ROWS_RHS_STRIP : rows;     // ... the rows the look-ahead's GEMMs carry
     T* bvec = rhs ? A + R * ld : nullptr;
-    unsigned* ctrl = reinterpret_cast<unsigned*>(ws);                   // 64 elements reserved
+    // 128 elements reserved: TWO sets of control words.  Step j's persistent update (and the helper's rejoin launch) count in set j & 1;
+    // the other set is zeroed on the HELPER stream during the step (nobody uses it then: its last users were joined before the fork), so
+    // that the next step finds its counters at zero without a memset -- one launch and one dependent-launch gap less on the main
+    // stream per outer step.  Launches of a step in front of its fork (rare: a change of aggregation policy) count in the other set.
+    unsigned* const ctrl_sets[2] = {reinterpret_cast<unsigned*>(ws), reinterpret_cast<unsigned*>(ws) + GPK_PERSIST_CTRL_WORDS};
+    unsigned* ctrl = ctrl_sets[0];
+    bool next_set_zeroed = false;        // the set of the step about to run has been zeroed by the previous step's helper-stream memset
     // n x nb, leading dimension nb + 16: with a power-of-two pitch the rows of a tile sit on a few memory channels and
     // the panel GEMM, which streams this buffer once, crawls (measured 2x)
     const int64_t ldt = nb + GPK_LA_PAD;
-    T* Tp = ws + 64;
+    T* Tp = ws + 128;
     T* tmp = Tp + (Rall > nb ? Rall : nb) * ldt;
     T* vtmp = tmp + (int64_t)nb * nb / 4 + 16;       // one block of the right-hand side (side stream only)
     const int64_t nblk = gpk_cdiv(n, nb);
@@ -1797,6 +1809,10 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
         for (int64_t j = 0; j + 1 < nblk; ++j) {
             const int64_t k0 = j * nb, k1 = k0 + nb;
             const int64_t k2 = (k1 + nb < n) ? k1 + nb : n;
+            unsigned* const ctrl_step = ctrl_sets[j & 1];       // this step's persistent update / rejoin
+            ctrl = ctrl_sets[(j + 1) & 1];                      // every other launch of the step (they zero it themselves)
+            const bool step_set_zeroed = next_set_zeroed;
+            next_set_zeroed = false;
             // solve(j): rows k1.. of panel j  (k clipped to W's triangle)
             if (sb < nb) {
                 // the explicit inverses are sb wide (fp32: the error of the posterior mean grows with the width of an explicit inverse): block
@@ -1872,7 +1888,8 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
                 e_join = la_event(*dev, ev++);
                 if (e_fork == nullptr || e_join == nullptr) return GPK_ERR_LAUNCH;
                 // the tile counter is zeroed BEFORE the fork: the helper stream's rejoin launch reads it, so it must be ordered behind
-                if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
+                // (by the previous step's helper-stream memset, joined since; the first overlapped step zeroes its own)
+                if (!step_set_zeroed && hipMemsetAsync(ctrl_step, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), stream) != hipSuccess) return GPK_ERR_LAUNCH;
                 if (hipEventRecord(e_fork, stream) != hipSuccess) return GPK_ERR_LAUNCH;
             } else {
                 st = la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, stream);
@@ -1896,12 +1913,17 @@ static int potrf_la_body(LaDevice* dev, T* A, int64_t n, int64_t ld, T* dinv128,
                     if (!g_la_strip_last) seg[ns++] = strip;
                     for (const ColGroup& cg : groups) seg[ns++] = col_segment(cg, j + 2, k1);
                     if (g_la_strip_last) seg[ns++] = strip;
-                    const int s2 = gpk_gemm_persist_launch<T>(seg, ns, T(-1), ctrl, overlap ? 1 : 0, stream, &saved, overlap);
+                    const int s2 = gpk_gemm_persist_launch<T>(seg, ns, T(-1), ctrl_step, overlap ? 1 : 0, stream, &saved, overlap);
                     if (s2) return s2;
                 }
                 if (overlap) {
                     if (hipStreamWaitEvent(dev->aux, e_fork, 0) != hipSuccess) return GPK_ERR_LAUNCH;
-                    const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8, ctrl + 2, (unsigned)saved.signal_tiles)
+                    // the NEXT step's set (free since the join in front of this fork), off the main stream
+                    if (GPK_LA_CTRL_PINGPONG) {
+                        if (hipMemsetAsync(ctrl, 0, GPK_PERSIST_CTRL_WORDS * sizeof(unsigned), dev->aux) != hipSuccess) return GPK_ERR_LAUNCH;
+                        next_set_zeroed = true;
+                    }
+                    const int s2 = fuse_diag ? la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8, ctrl_step + 2, (unsigned)saved.signal_tiles)
                                              : la_chain<T>(A, n, ld, dinv128, dinv_big, nb, sb, tmp, info, j + 1, dev->aux, 8);
                     if (s2) return s2;
                     if (g_la_rejoin && saved.valid)         // chain done: the reserved CUs take tiles of the update that is still running
