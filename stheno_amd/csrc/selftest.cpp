@@ -15,6 +15,9 @@
 #include <string>
 #include <limits>
 #include <vector>
+#include <atomic>
+#include <functional>
+#include <thread>
 #include "../../include/gpk.h"
 
 #define HIPCHK(x)                                                                       \
@@ -52,6 +55,27 @@ struct Dev {
     }
     void zero() { HIPCHK(hipMemset(p, 0, n * sizeof(T))); }
 };
+
+// The host references are O(n^3) scalar loops; on one core they were 300 of the GPU suite's 510 seconds (round 6: 72 factorisations of
+// order 2048 for ONE batched case).  They run on every host core now -- over the members of a batch, the rows of a column block, the
+// rows under a matrix -- with every entry's summation order unchanged (same bits as the serial loops).
+static void parallel_for(int n, const std::function<void(int)>& f, int grain = 1) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (int)std::min<unsigned>((unsigned)std::max((n + grain - 1) / grain, 1), std::min(hw ? hw : 1u, 64u));
+    if (nt <= 1) {
+        for (int i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            for (int i0 = next.fetch_add(grain); i0 < n; i0 = next.fetch_add(grain))
+                for (int i = i0; i < std::min(n, i0 + grain); ++i) f(i);
+        });
+    for (auto& t : th) t.join();
+}
 
 static std::mt19937_64 rng(1234);
 template <typename T>
@@ -119,19 +143,20 @@ static void test_gemm_case(bool ak, bool bk, int M, int N, int K, double alpha, 
     HIPCHK(hipDeviceSynchronize());
     auto got = dC.down();
     std::vector<double> ref(C.begin(), C.end());
-    for (int b = 0; b < batch; ++b)
-        for (int m = 0; m < M; ++m)
-            for (int n = 0; n < N; ++n) {
-                if (lower && n > m) { ref[b * sC + m * ldc + n] = (double)got[b * sC + m * ldc + n]; continue; }   // above the diagonal: unspecified
-                double s = 0;
-                for (int k = 0; k < K; ++k) {
-                    const double a = ak ? A[b * sA + m * lda + k] : A[b * sA + k * lda + m];
-                    const double bb = bk ? B[b * sB + n * ldb + k] : B[b * sB + k * ldb + n];
-                    s += a * bb;
-                }
-                const double c0 = (beta != 0.0) ? beta * (double)C[b * sC + m * ldc + n] : 0.0;
-                ref[b * sC + m * ldc + n] = alpha * s + c0;
+    parallel_for(batch * M, [&](int bm) {          // (one output row each)
+        const int b = bm / M, m = bm % M;
+        for (int n = 0; n < N; ++n) {
+            if (lower && n > m) { ref[b * sC + m * ldc + n] = (double)got[b * sC + m * ldc + n]; continue; }   // above the diagonal: unspecified
+            double s = 0;
+            for (int k = 0; k < K; ++k) {
+                const double a = ak ? A[b * sA + m * lda + k] : A[b * sA + k * lda + m];
+                const double bb = bk ? B[b * sB + n * ldb + k] : B[b * sB + k * ldb + n];
+                s += a * bb;
             }
+            const double c0 = (beta != 0.0) ? beta * (double)C[b * sC + m * ldc + n] : 0.0;
+            ref[b * sC + m * ldc + n] = alpha * s + c0;
+        }
+    }, 8);
     char nm[160];
     snprintf(nm, sizeof nm, "gemm_%s %c%c M%d N%d K%d a%.0f b%.0f batch%d low%d pad%d st%d", DT<T>::name(), ak ? 'k' : 'r', bk ? 'k' : 'r', M, N, K, alpha, beta, batch, (int)lower, pad, st);
     report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * std::sqrt((double)K + 1));
@@ -147,11 +172,13 @@ static void test_gemm_trilow_case(bool bk, int M, int N) {
     int st = gpk_gemm(DT<T>::v, 1, bk, M, N, K, 1.0, dA.p, K, 0, dB.p, bk ? K : N, 0, 0.0, dC.p, N, 0, 1, GPK_GEMM_TRI_K_LOWER, nullptr);
     HIPCHK(hipDeviceSynchronize());
     std::vector<double> ref((size_t)M * N, 0.0);
-    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
-        double s = 0;
-        for (int k = 0; k <= m; ++k) s += (double)A[(size_t)m * K + k] * (double)(bk ? B[(size_t)n * K + k] : B[(size_t)k * N + n]);
-        ref[(size_t)m * N + n] = s;
-    }
+    parallel_for(M, [&](int m) {
+        for (int n = 0; n < N; ++n) {
+            double s = 0;
+            for (int k = 0; k <= m; ++k) s += (double)A[(size_t)m * K + k] * (double)(bk ? B[(size_t)n * K + k] : B[(size_t)k * N + n]);
+            ref[(size_t)m * N + n] = s;
+        }
+    }, 4);
     char nm[160];
     snprintf(nm, sizeof nm, "gemm_trilow_%s k%c M%d N%d st%d", DT<T>::name(), bk ? 'k' : 'r', M, N, st);
     report(nm, st ? INFINITY : relerr(dC.down(), ref), DT<T>::eps * std::sqrt((double)K + 1));
@@ -168,13 +195,14 @@ static void test_gemm_inplace_case(int M, int64_t lda, int batch) {
     HIPCHK(hipDeviceSynchronize());
     auto got = dA.down();
     std::vector<double> ref(A.begin(), A.end());
-    for (int b = 0; b < batch; ++b)
-        for (int m = 0; m < M; ++m)
-            for (int n = 0; n < N; ++n) {
-                double s = 0;
-                for (int k = 0; k < K; ++k) s += (double)A[b * sA + m * lda + k] * (double)W[(size_t)n * K + k];
-                ref[b * sA + m * lda + n] = s;
-            }
+    parallel_for(batch * M, [&](int bm) {
+        const int b = bm / M, m = bm % M;
+        for (int n = 0; n < N; ++n) {
+            double s = 0;
+            for (int k = 0; k < K; ++k) s += (double)A[b * sA + m * lda + k] * (double)W[(size_t)n * K + k];
+            ref[b * sA + m * lda + n] = s;
+        }
+    }, 64);
     char nm[160];
     snprintf(nm, sizeof nm, "gemm_inplace_%s M%d lda%d batch%d st%d", DT<T>::name(), M, (int)lda, batch, st);
     report(nm, st ? INFINITY : relerr(got, ref), DT<T>::eps * 12);
@@ -347,7 +375,7 @@ static std::vector<T> make_spd(int n, int batch, int64_t ld) {
     std::vector<T> A((size_t)batch * n * ld, (T)0);
     for (int b = 0; b < batch; ++b) {
         auto X = randv<double>((size_t)n * 3);
-        for (int i = 0; i < n; ++i)
+        auto fill_row = [&](int i) {
             for (int j = 0; j <= i; ++j) {
                 double r2 = 0;
                 for (int k = 0; k < 3; ++k) { double df = X[i * 3 + k] - X[j * 3 + k]; r2 += df * df; }
@@ -355,20 +383,48 @@ static std::vector<T> make_spd(int n, int batch, int64_t ld) {
                 A[(size_t)b * n * ld + (size_t)i * ld + j] = (T)v;
                 A[(size_t)b * n * ld + (size_t)j * ld + i] = (T)v;
             }
+        };
+        if (n >= 1024) parallel_for(n, fill_row);       // (row i writes the pairs (i, j <= i): no two rows share an element)
+        else for (int i = 0; i < n; ++i) fill_row(i);
     }
     return A;
 }
-static void host_chol(std::vector<double>& A, int n, int64_t ld) {
-    for (int j = 0; j < n; ++j) {
-        double d = A[j * ld + j];
-        for (int k = 0; k < j; ++k) d -= A[j * ld + k] * A[j * ld + k];
-        d = std::sqrt(d);
-        A[j * ld + j] = d;
-        for (int i = j + 1; i < n; ++i) {
-            double s = A[i * ld + j];
-            for (int k = 0; k < j; ++k) s -= A[i * ld + k] * A[j * ld + k];
-            A[i * ld + j] = s / d;
+// L[i][j] = (A[i][j] - sum_{k<j} L[i][k] L[j][k]) / L[j][j], every sum over ascending k (the bits of the plain column-by-column loop,
+// whatever the schedule).  Row i's entries in the columns [j0, min(j1, i + 1)) of a column block: eight sums at a time over the columns
+// in front of the block -- independent chains for the core to overlap -- then each entry's few terms inside the block.
+static void host_chol_row(double* A, int64_t ld, int i, int j0, int j1) {
+    double* Li = A + (int64_t)i * ld;
+    const int je = std::min(j1, i + 1);
+    for (int jb = j0; jb < je; jb += 8) {
+        const int nj = std::min(8, je - jb);
+        double s[8];
+        const double* Lj[8];
+        for (int q = 0; q < 8; ++q) {
+            const int j = jb + std::min(q, nj - 1);
+            Lj[q] = A + (int64_t)j * ld;
+            s[q] = Li[j];
         }
+        for (int k = 0; k < j0; ++k) {
+            const double a = Li[k];
+            s[0] -= a * Lj[0][k]; s[1] -= a * Lj[1][k]; s[2] -= a * Lj[2][k]; s[3] -= a * Lj[3][k];
+            s[4] -= a * Lj[4][k]; s[5] -= a * Lj[5][k]; s[6] -= a * Lj[6][k]; s[7] -= a * Lj[7][k];
+        }
+        for (int q = 0; q < nj; ++q) {
+            const int j = jb + q;
+            double t = s[q];
+            for (int k = j0; k < j; ++k) t -= Li[k] * Lj[q][k];
+            Li[j] = (i == j) ? std::sqrt(t) : t / Lj[q][j];
+        }
+    }
+}
+// column blocks of 32: the block's own rows (serial), then every row below it on its own (`par`: spread over the host's cores)
+static void host_chol(double* A, int n, int64_t ld, bool par) {
+    constexpr int W = 32;
+    for (int j0 = 0; j0 < n; j0 += W) {
+        const int j1 = std::min(n, j0 + W);
+        for (int i = j0; i < j1; ++i) host_chol_row(A, ld, i, j0, j1);
+        if (par && n - j1 >= 1024) parallel_for(n - j1, [&](int r) { host_chol_row(A, ld, j1 + r, j0, j1); }, 32);
+        else for (int i = j1; i < n; ++i) host_chol_row(A, ld, i, j0, j1);
     }
 }
 template <typename T>
@@ -386,11 +442,8 @@ static void test_potrf_case(int n, int batch, int nbo, int nrhs_small, int nrhs_
     auto inf = info.down();
     // host reference factor
     std::vector<double> Lref(A.begin(), A.end());
-    for (int b = 0; b < batch; ++b) {
-        std::vector<double> sub(Lref.begin() + b * sA, Lref.begin() + (b + 1) * sA);
-        host_chol(sub, n, ld);
-        std::copy(sub.begin(), sub.end(), Lref.begin() + b * sA);
-    }
+    if (batch == 1) host_chol(Lref.data(), n, ld, true);
+    else parallel_for(batch, [&](int b) { host_chol(Lref.data() + b * sA, n, ld, false); });      // (the members of a batch are independent)
     double num = 0, den = 0;
     bool finite = true;
     for (int b = 0; b < batch; ++b)
@@ -449,13 +502,14 @@ static void test_potrf_case(int n, int batch, int nbo, int nrhs_small, int nrhs_
                            : gpk_trsm_lower(DT<T>::v, dA.p, n, ld, sA, dsb.p, sb, dB.p, nrhs, ldb, (int64_t)n * ldb, tmp.p, batch, nullptr);
         HIPCHK(hipDeviceSynchronize());
         std::vector<double> ref(Bm.begin(), Bm.end());
-        for (int b = 0; b < batch; ++b)
-            for (int c = 0; c < nrhs; ++c)
-                for (int i = 0; i < n; ++i) {
-                    double s = ref[((size_t)b * n + i) * ldb + c];
-                    for (int k = 0; k < i; ++k) s -= Lref[b * sA + i * ld + k] * ref[((size_t)b * n + k) * ldb + c];
-                    ref[((size_t)b * n + i) * ldb + c] = s / Lref[b * sA + i * ld + i];
-                }
+        parallel_for(batch * nrhs, [&](int bc) {          // (column c of member b touches only its own entries of `ref`)
+            const int b = bc / nrhs, c = bc % nrhs;
+            for (int i = 0; i < n; ++i) {
+                double s = ref[((size_t)b * n + i) * ldb + c];
+                for (int k = 0; k < i; ++k) s -= Lref[b * sA + i * ld + k] * ref[((size_t)b * n + k) * ldb + c];
+                ref[((size_t)b * n + i) * ldb + c] = s / Lref[b * sA + i * ld + i];
+            }
+        });
         // compare only the nrhs columns
         auto got = dB.down();
         double nu = 0, de2 = 0;
@@ -669,18 +723,27 @@ static void test_potrf_rows_case(int n, int extra, int nb, int sb, int64_t tail,
             if (!std::isfinite(g)) finite = false;
             num = std::max(num, std::fabs(g - r)); den = std::max(den, std::fabs(r));
         }
-    std::vector<double> z(n);
-    for (int e = 0; e < extra; ++e) {           // z L^T = E[e]:  z_j = (E[e][j] - sum_{k<j} z_k L[j][k]) / L[j][j]
+    std::vector<double> znum_e(extra, 0.0), zden_e(extra, 0.0);
+    std::vector<char> bad_e(extra, 0);
+    parallel_for(extra, [&](int e) {            // z L^T = E[e]:  z_j = (E[e][j] - sum_{k<j} z_k L[j][k]) / L[j][j]   (the rows are independent)
+        std::vector<double> z(n);
         for (int j = 0; j < n; ++j) {
             double acc = E[(size_t)e * ld + j];
             for (int k = 0; k < j; ++k) acc -= z[k] * (double)R[(size_t)j * ld + k];
             z[j] = acc / (double)R[(size_t)j * ld + j];
         }
+        double zn = 0, zd = 0;
+        char bad = 0;
         for (int j = 0; j < n; ++j) {
             const double g = G[(size_t)(n + e) * ld + j];
-            if (!std::isfinite(g)) finite = false;
-            znum = std::max(znum, std::fabs(g - z[j])); zden = std::max(zden, std::fabs(z[j]));
+            if (!std::isfinite(g)) bad = 1;
+            zn = std::max(zn, std::fabs(g - z[j])); zd = std::max(zd, std::fabs(z[j]));
         }
+        znum_e[e] = zn; zden_e[e] = zd; bad_e[e] = bad;
+    });
+    for (int e = 0; e < extra; ++e) {
+        if (bad_e[e]) finite = false;
+        znum = std::max(znum, znum_e[e]); zden = std::max(zden, zden_e[e]);
     }
     char nm[200];
     snprintf(nm, sizeof nm, "potrf_rows_%s n%d +%d rows nb%d sb%d tail%lld agg%d flags%d st%d/%d info%d: factor", DT<T>::name(), n, extra, nb, wb, (long long)tail, agg, flags, st, st2, info.down()[0]);
