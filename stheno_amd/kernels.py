@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .matrix import Chol, Dense, KernelDense
+from .matrix import Dense, KernelDense
 
 __all__ = [
     "Kernel", "EQ", "Exp", "Matern12", "Matern32", "Matern52", "Linear", "OneKernel", "ZeroKernel",

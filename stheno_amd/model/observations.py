@@ -7,7 +7,7 @@ import torch
 
 from .. import kernels as _k
 from .. import ops
-from ..matrix import AbstractMatrix, ChainChol, Chol, Dense, Diagonal, FactoredDense, KernelDense, Zero, any_missing, config
+from ..matrix import ChainChol, Chol, Dense, Diagonal, FactoredDense, KernelDense, Zero, any_missing, config
 from .fdd import FDD, take
 from .gp import cross
 

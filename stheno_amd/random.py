@@ -12,7 +12,7 @@ import types
 import torch
 
 from . import ops
-from .matrix import LOG_2_PI, AbstractMatrix, Chol, Dense, Diagonal, KernelDense, Zero, any_missing, config, deferred_checks, to_matrix
+from .matrix import LOG_2_PI, AbstractMatrix, Dense, Diagonal, KernelDense, Zero, any_missing, config, deferred_checks, to_matrix
 
 __all__ = ["Random", "RandomProcess", "RandomVector", "Normal"]
 
